@@ -1,0 +1,199 @@
+/* pdp_hip.h - C-ABI of the MI355X-native batched PDP inner loop.
+ *
+ * The reference (wanxinjin/Pontryagin-Differentiable-Programming) has no FFI seam: its boundary is the
+ * Python class surface of PDP/PDP.py and, beneath it, casadi.Function.__call__ + numpy.linalg.  This
+ * header is the C boundary inserted beneath that class surface.  Every entry point
+ * cites the reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - all arrays are contiguous IEEE fp64, row-major per matrix, batch-major: [B][T][rows][cols];
+ *     all pointers are DEVICE pointers (HBM); the caller owns every buffer; the library allocates nothing
+ *     persistent and keeps no global state besides immutable generated model code;
+ *   - `stream` is a hipStream_t passed as void*; work is stream-ordered, nothing synchronises the device;
+ *   - return value: 0 ok, <0 argument error (PDP_E_*); numerical trouble is reported per trajectory in
+ *     `status[B]` (bit 0: non-finite value met, bit 1: pivot below 1e-300 in the m x m solve), the analogue
+ *     of numpy.linalg.LinAlgError in the reference (PDP.py:566, 575);
+ *   - a matrix family that is time-invariant may be passed with time stride 0, one shared by the whole
+ *     batch with batch stride 0 (strides in doubles, see pdp_lqr_problem).
+ *
+ * Two libraries export these symbols:
+ *   libpdp_hip.so              model-independent kernels  (section A)
+ *   libpdp_model_<name>.so     one per generated model    (section B), built from generated HIP source
+ */
+#ifndef PDP_HIP_H
+#define PDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDP_E_ARG (-1)      /* null pointer / non-positive size */
+#define PDP_E_SIZE (-2)     /* dimension outside what the kernels are built for (n<=16, m<=4, p<=64 ...) */
+#define PDP_E_LAUNCH (-3)   /* HIP launch error (hipGetLastError() has the detail) */
+#define PDP_E_MODE (-4)     /* entry point not provided by this model kind */
+
+#define PDP_STATUS_NONFINITE 1
+#define PDP_STATUS_PIVOT 2
+
+/* library identification: returns a static string "pdp_hip <version> gfx950" */
+const char* pdp_hip_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Section A - model-independent kernels (libpdp_hip.so)
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* One matrix family of the auxiliary control system: base pointer + strides in doubles.
+ * element(b,t,i,j) = ptr[b*bstride + t*tstride + i*cols + j]; ptr may be NULL where noted (treated as 0). */
+typedef struct pdp_mat {
+    const double* ptr;
+    int64_t bstride;
+    int64_t tstride;
+} pdp_mat;
+
+/* Inputs of LQR.lqrSolver (PDP/PDP.py:446-555 normalises them; 557-608 consumes them).
+ * Hux is accepted by the reference but never read - Hxu^T is used (PDP.py:569, 593, 598) - so it is absent. */
+typedef struct pdp_lqr_problem {
+    int B, T, n, m, p;
+    pdp_mat F;    /* dynF  [n x n] */
+    pdp_mat G;    /* dynG  [n x m] */
+    pdp_mat E;    /* dynE  [n x p]  (NULL = 0, PDP.py:496) */
+    pdp_mat Hxx;  /* [n x n] */
+    pdp_mat Hxu;  /* [n x m]        (NULL = 0, PDP.py:517-518) */
+    pdp_mat Hxe;  /* [n x p]        (NULL = 0, PDP.py:537-538) */
+    pdp_mat Huu;  /* [m x m] */
+    pdp_mat Hue;  /* [m x p]        (NULL = 0, PDP.py:547-548) */
+    pdp_mat hxx;  /* terminal [n x n], tstride ignored */
+    pdp_mat hxe;  /* terminal [n x p], tstride ignored (the reference requires it, PDP.py:562) */
+    pdp_mat X0;   /* ini_state [n x p] (NULL = 0), tstride ignored */
+} pdp_lqr_problem;
+
+/* Size in bytes of the scratch buffer pdp_lqr_solve_batched needs (feedback gains, and P/W when Lam != NULL). */
+int64_t pdp_lqr_workspace_bytes(int B, int T, int n, int m, int p, int want_costate);
+
+/* Batched LQR.lqrSolver (PDP/PDP.py:446-615): backward Riccati sweep (557-580) and forward rollout of
+ * X [B][T+1][n][p], U [B][T][m][p], Lam [B][T][n][p] (582-608; Lam may be NULL).  One wavefront per
+ * trajectory, 16x16 fp64 MFMA tiles held in registers.  Limits: n <= 16, m <= 4, p <= 64 - m. */
+int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, double* Lam, int32_t* status,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Batched ControlPlanning.integrateAuxSys (PDP/PDP.py:813-838): U_t = Ux_t X_t + Ue_t, X_{t+1} = F_t X_t + G_t U_t.
+ * F [B][T][n][n], G [B][T][n][m], Ux [B][T][m][n], Ue [B][T][m][p], X0 [B][n][p] (NULL = 0)
+ * -> X [B][T+1][n][p], U [B][T][m][p]. */
+int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double* F, const double* G, const double* Ux,
+                                 const double* Ue, const double* X0, double* X, double* U, void* stream);
+
+/* Batched SysID.integrateAuxSys (PDP/PDP.py:1241-1259): X_{t+1} = F_t X_t + E_t.
+ * F [B][T][n][n], E [B][T][n][p], X0 [B][n][p] (NULL = 0) -> X [B][T+1][n][p]. */
+int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0,
+                                    double* X, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Section B - per-model entry points (libpdp_model_<name>.so, generated by pdp_amd.codegen from the
+ * symbolic problem definition; the CasADi Function objects of diffPMP, PDP.py:222-270, become device code)
+ * ------------------------------------------------------------------------------------------------------ */
+
+#define PDP_KIND_OC 0      /* OCSys            (PDP.py:57-314)    x+ = f(x,u,theta), c(x,u,theta), h(x,theta) */
+#define PDP_KIND_CP 1      /* ControlPlanning  (PDP.py:640-878)   x+ = f(x,u), c(x,u), h(x), policy u = pi(t,x,theta) */
+#define PDP_KIND_SYSID 2   /* SysID            (PDP.py:1157-1296) x+ = f(x,u,theta) */
+
+typedef struct pdp_model_info {
+    int kind;          /* PDP_KIND_* */
+    int n, m, p;       /* state, control, auxvar dimension (p = 0 for PDP_KIND_CP: theta lives in the policy) */
+    int nnz_path;      /* structural non-zeros of the per-step aux matrices (packed LDS pool width) */
+    int chunk;         /* time steps evaluated per lane-parallel aux pass of the fused kernel */
+    const char* name;  /* "<model>_<kind>_<hash>" */
+} pdp_model_info;
+
+void pdp_model_get_info(pdp_model_info* info);
+
+/* theta handling, all per-model entry points: theta[(b * theta_bstride) + k]; theta_bstride = 0 shares one
+ * parameter vector over the batch (reference semantics), = p gives every trajectory its own. */
+
+/* ---- PDP_KIND_OC ----------------------------------------------------------------------------------- */
+
+/* Forward trajectory for given controls: x_{t+1} = f(x_t,u_t,theta) (the NLP equality constraints of
+ * OCSys.ocSolver, PDP.py:148-170) and J = sum c + h (157-173).
+ * x0 [B][n], u [B][T][m] -> x [B][T+1][n], cost [B] (cost may be NULL). */
+int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, const double* theta, int theta_bstride,
+                           double* x, double* cost, void* stream);
+
+/* PMP costate recursion, ocSolver costate_option=1 (PDP.py:199-209): lam[T-1] = h_x(x_T),
+ * lam[k-1] = c_x(x_k,u_k) + f_x(x_k,u_k)^T lam[k].  lam [B][T][n] with lam[t] = lambda_{t+1}. */
+int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const double* theta, int theta_bstride,
+                           double* lam, void* stream);
+
+/* OCSys.getAuxSys (PDP.py:272-314), materialised: dynF [B][T][n][n], dynG [B][T][n][m], dynE [B][T][n][p],
+ * Hxx, Hxu [n x m], Hxe [n x p], Hux [m x n], Huu [m x m], Hue [m x p] (all [B][T]...), hxx [B][n][n], hxe [B][n][p].
+ * Any output pointer may be NULL (skipped). */
+typedef struct pdp_oc_auxsys {
+    double *dynF, *dynG, *dynE, *Hxx, *Hxu, *Hxe, *Hux, *Huu, *Hue, *hxx, *hxe;
+} pdp_oc_auxsys;
+int pdp_oc_auxsys_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta,
+                          int theta_bstride, const pdp_oc_auxsys* out, void* stream);
+
+/* Fused "forward + Riccati + PDP gradient" unit (the loop body of the IRL drivers,
+ * Examples/IRL/cartpole/cartpole_PDP.py:45-74, with ocSolver replaced by the given controls, or by the
+ * caller's optimal (x,u,lam) when flags has PDP_OC_GIVEN_TRAJ):
+ *   rollout -> costates -> aux system in LDS (never in HBM) -> lqrSolver backward/forward on MFMA tiles ->
+ *   loss = |x-x_demo|^2 + |u-u_demo|^2 ; grad = sum_t (x_t-xd_t)^T X_t + (u_t-ud_t)^T U_t + (x_T-xd_T)^T X_T
+ * Inputs : x0 [B][n], u [B][T][m], theta, demo_x [B][T+1][n], demo_u [B][T][m]
+ * In/out : x [B][T+1][n], lam [B][T][n]  (outputs, or inputs with PDP_OC_GIVEN_TRAJ; never NULL)
+ * Outputs: loss [B], grad [B][p], optional dxdp [B][T+1][n][p], dudp [B][T][m][p] (NULL = not stored),
+ *          status [B].  workspace: pdp_oc_pdp_workspace_bytes(B,T). */
+#define PDP_OC_GIVEN_TRAJ 1
+int64_t pdp_oc_pdp_workspace_bytes(int B, int T);
+int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta,
+                            int theta_bstride, const double* demo_x, const double* demo_u, double* x, double* lam,
+                            double* loss, double* grad, double* dxdp, double* dudp, int32_t* status,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- PDP_KIND_CP ------------------------------------------------------------------------------------ */
+
+/* Policy descriptor: Lagrange polynomial (ControlPlanning.setPolyControl, PDP.py:699-725; theta =
+ * vcat(U_0..U_N), p = (N+1) m) or tanh MLP (setNeuralPolicy, 727-759; theta = [vec_F(A_0), b_0, vec_F(A_1), b_1, ...],
+ * column-major vec, layers = hidden + [m]). */
+#define PDP_POLICY_POLY 0
+#define PDP_POLICY_MLP 1
+typedef struct pdp_policy {
+    int kind;
+    int n_pivots;            /* POLY: number of pivots (<= 16) */
+    double pivots[16];       /* POLY: pivot times */
+    int n_layers;            /* MLP: number of weight layers (<= 8), sizes[k] = rows of A_k, last = m */
+    int sizes[8];
+} pdp_policy;
+
+/* ControlPlanning.integrateSys (PDP.py:763-786): x0 [B][n], theta -> x [B][T+1][n], u [B][T][m], cost [B]. */
+int pdp_cp_integrate_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta,
+                             int theta_bstride, double* x, double* u, double* cost, void* stream);
+
+/* ControlPlanning.getAuxSys (PDP.py:788-811): dynF [B][T][n][n], dynG [B][T][n][m], dUx [B][T][m][n], dUe [B][T][m][p]. */
+int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const double* x, const double* u, const double* theta,
+                          int theta_bstride, double* dynF, double* dynG, double* dUx, double* dUe, void* stream);
+
+/* ControlPlanning.step (PDP.py:850-878), fused: loss [B] = sum c + h, grad [B][p] = sum_t c_x X_t + c_u U_t + h_x X_T;
+ * optional x [B][T+1][n], u [B][T][m] (NULL = not stored). */
+int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int theta_bstride,
+                        double* loss, double* grad, double* x, double* u, void* stream);
+
+/* ---- PDP_KIND_SYSID --------------------------------------------------------------------------------- */
+
+/* SysID.integrateDyn (PDP.py:1209-1223): x0 [B][n], u [B][T][m] -> x [B][T+1][n]. */
+int pdp_sysid_integrate_batched(int B, int T, const double* x0, const double* u, const double* theta, int theta_bstride,
+                                double* x, void* stream);
+
+/* SysID.getAuxSys (PDP.py:1225-1239): dynF [B][T][n][n], dynE [B][T][n][p]. */
+int pdp_sysid_auxsys_batched(int B, int T, const double* x, const double* u, const double* theta, int theta_bstride,
+                             double* dynF, double* dynE, void* stream);
+
+/* SysID.step per trajectory (PDP.py:1261-1296 without the final mean): u [B][T][m], x_obs [B][T+1][n] ->
+ * loss [B] = |x - x_obs|^2, grad [B][p] = sum_{t<=T} (x_t - x_obs_t)^T X_t  (= half the gradient, as in the
+ * reference); the caller averages over the batch (PDP.py:1293-1294). */
+int pdp_sysid_step_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int theta_bstride,
+                           double* loss, double* grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDP_HIP_H */

@@ -1,0 +1,228 @@
+// pdp_lqr.hip - model-independent batched kernels of libpdp_hip.so (section A of include/pdp_hip.h):
+//   pdp_lqr_solve_batched            LQR.lqrSolver              (reference PDP/PDP.py:446-615)
+//   pdp_cp_aux_integrate_batched     ControlPlanning.integrateAuxSys (PDP/PDP.py:813-838)
+//   pdp_sysid_aux_integrate_batched  SysID.integrateAuxSys      (PDP/PDP.py:1241-1259)
+// One wavefront (= one 64-thread workgroup) per trajectory; matrices are read from HBM straight into the
+// register tile layout, every product is a chain of v_mfma_f64_16x16x4_f64 (pdp_tile.h / pdp_riccati.h).
+#include <hip/hip_runtime.h>
+#include "../../include/pdp_hip.h"
+#include "pdp_riccati.h"
+
+using namespace pdp;
+
+namespace {
+
+constexpr int MAX_NT = 4;   // parameter tiles: p <= (16 - m) + 16 * (MAX_NT - 1)
+
+PDP_DEV const double* mat_at(const pdp_mat& M, int b, int t) {
+    return M.ptr ? M.ptr + (int64_t)b * M.bstride + (int64_t)t * M.tstride : nullptr;
+}
+
+// gains workspace per (b,t): KT [n*m] then k [m*p];  P/W workspace per (b,t): P [n*n] then W [n*p]
+template <int M, int NT>
+__global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
+                                                        double* __restrict__ Lo, int32_t* __restrict__ status,
+                                                        double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
+    __shared__ double scratch[RICCATI_SCRATCH];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = pr.n, p = pr.p, T = pr.T;
+    const int p0 = min(p, 16 - M);
+    const d4 z = zero4();
+    const int gsz = n * M + M * p, pwsz = n * n + n * p;
+    bool ok = true, finite = true;
+
+    // terminal condition: PP[T-1] = hxx, WW[T-1] = hxe (PDP.py:561-562)
+    d4 P = load_dense<false>(mat_at(pr.hxx, b, 0), n, n, n, 0, 0, lane);
+    d4 W[NT];
+    {
+        const double* hxe = mat_at(pr.hxe, b, 0);
+        W[0] = hxe ? load_dense<false>(hxe, n, p0, p, 0, M, lane) : z;
+#pragma unroll
+        for (int j = 1; j < NT; ++j) W[j] = hxe ? load_dense<false>(hxe + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane) : z;
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        if (ws_pw) {   // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
+            double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
+            store_dense(pw, n, n, n, 0, 0, lane, P);
+            store_dense(pw + n * n, n, p0, p, 0, M, lane, W[0]);
+#pragma unroll
+            for (int j = 1; j < NT; ++j) store_dense(pw + n * n + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane, W[j]);
+        }
+        const double *F = mat_at(pr.F, b, t), *G = mat_at(pr.G, b, t), *E = mat_at(pr.E, b, t), *Hxx = mat_at(pr.Hxx, b, t),
+                     *Hxu = mat_at(pr.Hxu, b, t), *Hxe = mat_at(pr.Hxe, b, t), *Huu = mat_at(pr.Huu, b, t), *Hue = mat_at(pr.Hue, b, t);
+        d4 Ft = load_dense<false>(F, n, n, n, 0, 0, lane);
+        d4 Y2 = load_dense<false>(G, n, M, M, 0, 0, lane);
+        Y2 = load_dense_into<false>(Y2, E, n, p0, p, 0, M, lane);
+        d4 Hxxt = load_dense<false>(Hxx, n, n, n, 0, 0, lane);
+        d4 HX2 = Hxu ? load_dense<false>(Hxu, n, M, M, 0, 0, lane) : z;
+        HX2 = load_dense_into<false>(HX2, Hxe, n, p0, p, 0, M, lane);
+        d4 HU2 = load_dense<false>(Huu, M, M, M, 0, 0, lane);
+        HU2 = load_dense_into<false>(HU2, Hue, M, p0, p, 0, M, lane);
+        RiccatiGains g;
+        d4 P_old;
+        ok = riccati_backward<M>(P, W[0], Ft, Y2, Hxxt, HX2, HU2, scratch, lane, p0, g, P_old) && ok;
+        double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
+        store_dense(gw, n, M, M, 0, 0, lane, g.KT);
+        store_dense(gw + n * M, M, p0, p, 0, M, lane, g.IK);
+#pragma unroll
+        for (int j = 1; j < NT; ++j) {
+            const int c0 = p0 + 16 * (j - 1), w = min(16, p - c0);
+            d4 Ej = E ? load_dense<false>(E + c0, n, w, p, 0, 0, lane) : z;
+            d4 Hxej = Hxe ? load_dense<false>(Hxe + c0, n, w, p, 0, 0, lane) : z;
+            d4 Huej = Hue ? load_dense<false>(Hue + c0, M, w, p, 0, 0, lane) : z;
+            d4 kj;
+            riccati_backward_extra(P_old, W[j], Ft, Y2, Ej, Hxej, Huej, g, kj);
+            store_dense(gw + n * M + c0, M, w, p, 0, 0, lane, kj);
+        }
+        finite = finite && tile_finite(P) && tile_finite(W[0]);
+    }
+    // ---- forward rollout (PDP.py:582-608)
+    d4 X[NT];
+    {
+        const double* X0 = mat_at(pr.X0, b, 0);
+        X[0] = X0 ? load_dense<false>(X0, n, p0, p, 0, M, lane) : z;
+#pragma unroll
+        for (int j = 1; j < NT; ++j) X[j] = X0 ? load_dense<false>(X0 + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane) : z;
+        double* x0o = Xo + (int64_t)b * (T + 1) * n * p;
+        store_dense(x0o, n, p0, p, 0, M, lane, X[0]);
+#pragma unroll
+        for (int j = 1; j < NT; ++j) store_dense(x0o + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane, X[j]);
+    }
+    __threadfence_block();
+    for (int t = 0; t < T; ++t) {
+        const double *F = mat_at(pr.F, b, t), *G = mat_at(pr.G, b, t), *E = mat_at(pr.E, b, t);
+        const double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
+        d4 FT = load_dense<true>(F, n, n, n, 0, 0, lane);       // F^T
+        d4 GT = load_dense<true>(G, n, M, M, 0, 0, lane);       // G^T (m x n)
+        d4 KTn = -load_dense<false>(gw, n, M, M, 0, 0, lane);
+        d4 Pt = z;
+        const double* pw = nullptr;
+        if (ws_pw) { pw = ws_pw + ((int64_t)b * T + t) * pwsz; Pt = load_dense<false>(pw, n, n, n, 0, 0, lane); }
+        double* xo = Xo + ((int64_t)b * (T + 1) + t + 1) * n * p;
+        double* uo = Uo + ((int64_t)b * T + t) * M * p;
+        double* lo = Lo ? Lo + ((int64_t)b * T + t) * n * p : nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c0 = (j == 0) ? 0 : p0 + 16 * (j - 1), w = (j == 0) ? p0 : min(16, p - c0), sh = (j == 0) ? M : 0;
+            d4 kn = -load_dense<false>(gw + n * M + c0, M, w, p, 0, sh, lane);
+            d4 Et = E ? load_dense<false>(E + c0, n, w, p, 0, sh, lane) : z;
+            d4 U, Xn;
+            riccati_forward(KTn, kn, FT, GT, Et, X[j], U, Xn);
+            X[j] = Xn;
+            store_dense(uo + c0, M, w, p, 0, sh, lane, U);
+            store_dense(xo + c0, n, w, p, 0, sh, lane, Xn);
+            if (lo) {
+                d4 Wt = load_dense<false>(pw + n * n + c0, n, w, p, 0, sh, lane);
+                d4 L = mma_tn(Pt, Xn, Wt);                      // P x+ + W  (P symmetric)
+                store_dense(lo + c0, n, w, p, 0, sh, lane, L);
+            }
+            finite = finite && tile_finite(Xn);
+        }
+    }
+    int st = 0;
+    if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
+    if (!ok) st |= PDP_STATUS_PIVOT;
+    if (lane == 0 && status) status[b] = st;
+}
+
+// U_t = Ux X + Ue ; X+ = F X + G U.   Generic n <= 16, m <= 16, p tiled by 16 columns (grid.y).
+__global__ void __launch_bounds__(64) cp_aux_kernel(int B, int T, int n, int m, int p, const double* __restrict__ F, const double* __restrict__ G,
+                                                     const double* __restrict__ Ux, const double* __restrict__ Ue, const double* __restrict__ X0,
+                                                     double* __restrict__ Xo, double* __restrict__ Uo) {
+    const int b = blockIdx.x, c0 = blockIdx.y * 16, lane = threadIdx.x;
+    const int w = min(16, p - c0);
+    const d4 z = zero4();
+    d4 X = X0 ? load_dense<false>(X0 + (int64_t)b * n * p + c0, n, w, p, 0, 0, lane) : z;
+    store_dense(Xo + (int64_t)b * (T + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
+    for (int t = 0; t < T; ++t) {
+        const int64_t bt = (int64_t)b * T + t;
+        d4 FT = load_dense<true>(F + bt * n * n, n, n, n, 0, 0, lane);
+        d4 GT = load_dense<true>(G + bt * n * m, n, m, m, 0, 0, lane);       // m x n
+        d4 UxT = load_dense<true>(Ux + bt * m * n, m, n, n, 0, 0, lane);     // n x m
+        d4 Uet = load_dense<false>(Ue + bt * m * p + c0, m, w, p, 0, 0, lane);
+        d4 U = mma_tn(UxT, X, Uet);        // Ux X + Ue
+        d4 Xn = mma_tn(FT, X, z);
+        Xn = mma_tn(GT, U, Xn);
+        X = Xn;
+        store_dense(Uo + bt * m * p + c0, m, w, p, 0, 0, lane, U);
+        store_dense(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + c0, n, w, p, 0, 0, lane, Xn);
+    }
+}
+
+__global__ void __launch_bounds__(64) sysid_aux_kernel(int B, int T, int n, int p, const double* __restrict__ F, const double* __restrict__ E,
+                                                        const double* __restrict__ X0, double* __restrict__ Xo) {
+    const int b = blockIdx.x, c0 = blockIdx.y * 16, lane = threadIdx.x;
+    const int w = min(16, p - c0);
+    const d4 z = zero4();
+    d4 X = X0 ? load_dense<false>(X0 + (int64_t)b * n * p + c0, n, w, p, 0, 0, lane) : z;
+    store_dense(Xo + (int64_t)b * (T + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
+    for (int t = 0; t < T; ++t) {
+        const int64_t bt = (int64_t)b * T + t;
+        d4 FT = load_dense<true>(F + bt * n * n, n, n, n, 0, 0, lane);
+        d4 Et = load_dense<false>(E + bt * n * p + c0, n, w, p, 0, 0, lane);
+        X = mma_tn(FT, X, Et);
+        store_dense(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
+    }
+}
+
+template <int M>
+int launch_lqr(const pdp_lqr_problem& pr, int nt, double* X, double* U, double* Lam, int32_t* status, double* wg, double* wpw, hipStream_t s) {
+    dim3 grid(pr.B), block(64);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((lqr_solve_kernel<M, 1>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+        case 2: hipLaunchKernelGGL((lqr_solve_kernel<M, 2>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+        case 3: hipLaunchKernelGGL((lqr_solve_kernel<M, 3>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+        default: hipLaunchKernelGGL((lqr_solve_kernel<M, 4>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pdp_hip_version(void) { return "pdp_hip 0.1 gfx950"; }
+
+int64_t pdp_lqr_workspace_bytes(int B, int T, int n, int m, int p, int want_costate) {
+    int64_t per = (int64_t)n * m + (int64_t)m * p + (want_costate ? (int64_t)n * n + (int64_t)n * p : 0);
+    return (int64_t)B * T * per * (int64_t)sizeof(double);
+}
+
+int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, double* Lam, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    if (!prob || !X || !U || !workspace) return PDP_E_ARG;
+    const pdp_lqr_problem& pr = *prob;
+    if (pr.B <= 0 || pr.T <= 0 || pr.n <= 0 || pr.m <= 0 || pr.p <= 0) return PDP_E_ARG;
+    if (!pr.F.ptr || !pr.G.ptr || !pr.Hxx.ptr || !pr.Huu.ptr || !pr.hxx.ptr) return PDP_E_ARG;
+    if (pr.n > 16 || pr.m > 4) return PDP_E_SIZE;
+    const int p0 = pr.p < 16 - pr.m ? pr.p : 16 - pr.m;
+    const int nt = 1 + (pr.p - p0 + 15) / 16;
+    if (nt > MAX_NT) return PDP_E_SIZE;
+    if (workspace_bytes < pdp_lqr_workspace_bytes(pr.B, pr.T, pr.n, pr.m, pr.p, Lam != nullptr)) return PDP_E_ARG;
+    double* wg = (double*)workspace;
+    double* wpw = Lam ? wg + (int64_t)pr.B * pr.T * (pr.n * pr.m + pr.m * pr.p) : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    switch (pr.m) {
+        case 1: return launch_lqr<1>(pr, nt, X, U, Lam, status, wg, wpw, s);
+        case 2: return launch_lqr<2>(pr, nt, X, U, Lam, status, wg, wpw, s);
+        case 3: return launch_lqr<3>(pr, nt, X, U, Lam, status, wg, wpw, s);
+        default: return launch_lqr<4>(pr, nt, X, U, Lam, status, wg, wpw, s);
+    }
+}
+
+int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double* F, const double* G, const double* Ux, const double* Ue,
+                                 const double* X0, double* X, double* U, void* stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !F || !G || !Ux || !Ue || !X || !U) return PDP_E_ARG;
+    if (n > 16 || m > 16) return PDP_E_SIZE;
+    hipLaunchKernelGGL(cp_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
+    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+}
+
+int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0, double* X, void* stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || p <= 0 || !F || !E || !X) return PDP_E_ARG;
+    if (n > 16) return PDP_E_SIZE;
+    hipLaunchKernelGGL(sysid_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, p, F, E, X0, X);
+    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// pdp_riccati.h - one time step of the auxiliary-control-system solve (LQR.lqrSolver, reference
+// PDP/PDP.py:557-608) on register tiles, one wavefront per trajectory.
+//
+// Mathematics.  The reference writes the backward step with (I + P R)^-1 and Huu^-1 (PDP.py:563-580):
+//     A = F - G Huu^-1 Hxu',  R = G Huu^-1 G',  M = E - G Huu^-1 Hue,  Q = Hxx - Hxu Huu^-1 Hxu',
+//     N = Hxe - Hxu Huu^-1 Hue,  S = A'(I + P R)^-1,  P- = Q + S P A,  W- = N + S (W + P M)
+// By the matrix-inversion lemma this is the Schur complement of the control block of
+//     Theta = [F G E]' P [F G E] + [Hxx Hxu Hxe; Hxu' Huu Hue; . . .]  (+ [0 0 F'W; 0 0 G'W]):
+//     Quu = Huu + G'PG,  Qux = Hxu' + G'PF,  Que = Hue + G'(PE + W)
+//     K = Quu^-1 Qux,  k = Quu^-1 Que,  P- = Hxx + F'PF - Qux'K,  W- = Hxe + F'(PE + W) - Qux'k
+// and the forward pass (PDP.py:588-608)  u = -K x - k,  x+ = F x + G u + E,  lambda+ = P x+ + W.
+// Only an m x m system is solved per step (m <= 4) instead of two n x n inversions; results agree with the
+// reference order of operations to rounding (tests: <= 1e-10 relative against oracle/pdp_oracle.py).
+//
+// Tile packing (16 columns per tile): the n x p sensitivity block shares a tile with the n x m control
+// block - Y2 = [G | E], HX2 = [Hxu | Hxe], HU2 = [Huu | Hue], W2 = [0 | W] - so one 16x16x16 product yields
+// both [PG | PE+W], one yields [Qux' | W-part], one yields [Quu | Que].  Columns m .. m+p0-1 carry the first
+// p0 = min(p, 16-m) parameters; further parameters live in extra tiles (E_j, Hxe_j, Hue_j, W_j), 16 each.
+// Backward step: 5 full products + 5 rank-m products = 25 MFMAs (1600 cycles) for p <= 16 - m.
+#pragma once
+#include "pdp_tile.h"
+
+namespace pdp {
+
+constexpr int RICCATI_SCRATCH = 256 + 272 + 272;   // Q2 / Z | FY (stride 17) | P (stride 17)
+
+PDP_DEV void tile_to_lds17(double* s, const d4 v, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[tile_row(lane, r) * 17 + tile_col(lane)] = v[r];
+}
+PDP_DEV d4 tile_from_lds17_transposed(const double* s, int lane) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = s[tile_col(lane) * 17 + tile_row(lane, r)];
+    return v;
+}
+
+struct RiccatiGains {
+    d4 KT;   // K^T  (n x m) in columns 0..m-1               -> forward: U = -(KT)^T X - k
+    d4 IK;   // rows 0..m-1: [ I | k_0 ] (k_0 in columns m..m+p0-1)
+    d4 Z;    // Quu^-T (m x m, top-left)
+    d4 Qux;  // m x n, rows 0..m-1
+};
+
+// Symmetry.  P is symmetric in exact arithmetic and the products use P^T in place of P.  Left alone, the
+// skew-symmetric rounding error of P- = Hxx + F'PF - Qux'K is amplified from step to step (measured on the
+// reference's quadrotor demo, T=50: 3.4e-10 relative error in X vs a 50-digit solution, against 1e-15 once P
+// is re-symmetrised each step), so every step ends with P <- (P + P^T)/2 through a padded LDS transpose.
+//
+// scratch: LDS, RICCATI_SCRATCH doubles, private to the wave.  Returns false when the m x m pivot test fails.
+template <int M>
+PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Hxx, const d4 HX2, const d4 HU2,
+                              double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
+    const d4 z = zero4();
+    d4 PF = mma_tn(P, Ft, z);        // P F        (P symmetric)
+    d4 PY2 = mma_tn(P, Y2, W0);      // [P G | P E + W]
+    d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
+    d4 FY = mma_tn(Ft, PY2, HX2);    // [Hxu + F'PG | Hxe + F'(PE+W)] = [Qux' | Wn]
+    d4 Q2 = mma_tn(Y2, PY2, HU2);    // rows<m: [Quu | Que]
+    P_old_out = P;
+    // ---- m x m inverse: broadcast Quu through LDS, every lane inverts it (uniform, registers)
+    __syncthreads();
+    tile_to_lds(scratch, Q2, lane);
+    tile_to_lds17(scratch + 256, FY, lane);
+    __syncthreads();
+    double a[M * M], ai[M * M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) a[i * M + j] = scratch[i * 16 + j];
+    bool ok = inverse_small<M>(a, ai);
+    // Qux tile (m x n): transpose of the first m columns of FY
+    d4 Qux = z, Z = z;
+    {
+        int row = lane >> 4, col = lane & 15;          // register 0 holds rows 0..3
+        if (row < M) Qux[0] = scratch[256 + col * 17 + row];
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) scratch[i * 16 + j] = ai[j * M + i];   // Z = Quu^-T
+    }
+    __syncthreads();
+    {
+        int row = lane >> 4, col = lane & 15;
+        if (row < M && col < M) Z[0] = scratch[row * 16 + col];
+    }
+    d4 K = mma_tn_r0(Z, Qux, z);          // Quu^-1 Qux            (m x n)
+    g.IK = mma_tn_r0(Z, Q2, z);           // Quu^-1 [Quu | Que] = [I | k]
+    g.KT = mma_tn_r0(Qux, Z, z);          // Qux' Quu^-T = K'      (n x m)
+    g.Z = Z;
+    g.Qux = Qux;
+    P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
+    tile_to_lds17(scratch + 528, P, lane);
+    __syncthreads();
+    P = 0.5 * (P + tile_from_lds17_transposed(scratch + 528, lane));
+    d4 Wn = mms_tn_r0(Qux, g.IK, FY);     // [Qux' - Qux' I | Wn - Qux' k]
+    W0 = keep_cols(Wn, M, M + p0, lane);
+    g.IK = keep_cols(g.IK, M, M + p0, lane);
+    return ok;
+}
+
+// Extra parameter tile j >= 1 (16 columns of E / Hxe / Hue / W, unshifted).  P_old = P before the update.
+PDP_DEV void riccati_backward_extra(const d4 P_old, d4& Wj, const d4 Ft, const d4 Y2, const d4 Ej, const d4 Hxej, const d4 Huej,
+                                    const RiccatiGains& g, d4& kj) {
+    const d4 z = zero4();
+    d4 S1 = mma_tn(P_old, Ej, Wj);        // P E_j + W_j
+    d4 Wn = mma_tn(Ft, S1, Hxej);         // Hxe_j + F'(..)
+    d4 Que = mma_tn(Y2, S1, Huej);        // rows<m: Hue_j + G'(..)   (rows >= m: E-related, killed by Z's zero rows)
+    kj = mma_tn_r0(g.Z, Que, z);          // Quu^-1 Que_j
+    Wj = mms_tn_r0(g.Qux, kj, Wn);
+}
+
+// Forward step for one parameter tile: U = -K X - k ; X+ = F X + G U + E.   FT = F^T tile, GT = G^T tile (m x n).
+PDP_DEV void riccati_forward(const d4 KTneg, const d4 kneg, const d4 FT, const d4 GT, const d4 Etile, const d4 X, d4& U, d4& Xn) {
+    U = mma_tn(KTneg, X, kneg);           // -(K X) - k   (rows < m)
+    Xn = mma_tn(FT, X, Etile);            // F X + E
+    Xn = mma_tn_r0(GT, U, Xn);            // + G U
+}
+
+}  // namespace pdp

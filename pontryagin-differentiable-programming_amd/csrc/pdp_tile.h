@@ -1,0 +1,148 @@
+// pdp_tile.h - register-resident 16x16 fp64 tile algebra for one gfx950 wavefront.
+//
+// A tile is a 16x16 row-major fp64 matrix spread over the 64 lanes: lane l, register r (0..3) holds the
+// element with flat index 64*r + l, i.e. row = (l >> 4) + 4r, col = l & 15.  This is exactly the C/D layout
+// of v_mfma_f64_16x16x4_f64, and (measured, profiles/r01_probe_mfma_f64.txt) feeding register r of two tiles
+// X, Y as the A and B operands of the r-th MFMA accumulates X^T * Y - bit-exact with a k-ascending fma chain.
+// So every product of the Riccati recursion is phrased as  C + X^T Y  and never leaves the register file:
+// no LDS traffic, no shuffles.  A transposed operand is obtained by loading the source transposed.
+//
+// v_mfma_f64_16x16x4_f64 on MI355X: 64 cycles issue (= the fp64 vector rate, the DP units are shared), so a
+// 16x16x16 product costs 256 cycles; products whose inner dimension is <= 4 (the control dimension) cost 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define PDP_DEV __device__ __forceinline__
+
+namespace pdp {
+
+PDP_DEV int lane_id() { return threadIdx.x & 63; }
+PDP_DEV int tile_row(int lane, int r) { return (lane >> 4) + 4 * r; }
+PDP_DEV int tile_col(int lane) { return lane & 15; }
+
+PDP_DEV d4 zero4() { d4 z = {0.0, 0.0, 0.0, 0.0}; return z; }
+
+// C + X^T Y, inner dimension 16 (4 MFMAs)
+PDP_DEV d4 mma_tn(const d4 x, const d4 y, d4 c) {
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], y[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], y[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], y[3], c, 0, 0, 0);
+    return c;
+}
+// C + X^T Y restricted to the first 4 rows of X and Y (1 MFMA): products over the control dimension m <= 4
+PDP_DEV d4 mma_tn_r0(const d4 x, const d4 y, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], y[0], c, 0, 0, 0);
+}
+// C - X^T Y over the first 4 rows
+PDP_DEV d4 mms_tn_r0(const d4 x, const d4 y, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(-x[0], y[0], c, 0, 0, 0);
+}
+
+// Load a dense row-major R x C matrix (leading dimension ld) into the tile at offset (roff, coff); elements
+// outside the matrix are 0.  TRANS loads the transpose (tile(i,j) = M[j-coff'...]) - see callers.
+template <bool TRANS>
+PDP_DEV d4 load_dense(const double* __restrict__ M, int R, int C, int ld, int roff, int coff, int lane) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = tile_row(lane, r) - roff, col = tile_col(lane) - coff;
+        bool ok = TRANS ? (row >= 0 && row < C && col >= 0 && col < R) : (row >= 0 && row < R && col >= 0 && col < C);
+        double x = 0.0;
+        if (ok) x = TRANS ? M[col * ld + row] : M[row * ld + col];
+        v[r] = x;
+    }
+    return v;
+}
+// Add-load: tile += dense block (used to pack two matrices side by side in one tile)
+template <bool TRANS>
+PDP_DEV d4 load_dense_into(d4 v, const double* __restrict__ M, int R, int C, int ld, int roff, int coff, int lane) {
+    if (M == nullptr) return v;
+    d4 w = load_dense<TRANS>(M, R, C, ld, roff, coff, lane);
+    return v + w;
+}
+PDP_DEV void store_dense(double* __restrict__ M, int R, int C, int ld, int roff, int coff, int lane, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = tile_row(lane, r) - roff, col = tile_col(lane) - coff;
+        if (row >= 0 && row < R && col >= 0 && col < C) M[row * ld + col] = v[r];
+    }
+}
+// zero every column outside [c0, c1)
+PDP_DEV d4 keep_cols(const d4 v, int c0, int c1, int lane) {
+    int col = tile_col(lane);
+    return (col >= c0 && col < c1) ? v : zero4();
+}
+PDP_DEV bool tile_finite(const d4 v) {
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok = ok && (fabs(v[r]) <= 1.7e308);
+    return ok;
+}
+
+// tile <-> 16x16 row-major LDS scratch (conflict-free: consecutive lanes, consecutive addresses)
+PDP_DEV void tile_to_lds(double* s, const d4 v, int lane) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[64 * r + lane] = v[r];
+}
+
+// In-register inverse of an M x M matrix (M <= 4) by Gauss-Jordan with partial pivoting, executed
+// redundantly (uniformly) by every lane.  a is row-major a[i*M+j]; returns false on a tiny/non-finite pivot.
+template <int M>
+PDP_DEV bool inverse_small(const double* a_in, double* inv) {
+    double a[M][M], b[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) { a[i][j] = a_in[i * M + j]; b[i][j] = (i == j) ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        // partial pivoting: bring the largest |a[i][k]|, i >= k, to row k (branch-free swaps)
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            bool sw = fabs(a[i][k]) > fabs(a[k][k]);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                double t = a[k][j], s = a[i][j];
+                a[k][j] = sw ? s : t; a[i][j] = sw ? t : s;
+                t = b[k][j]; s = b[i][j];
+                b[k][j] = sw ? s : t; b[i][j] = sw ? t : s;
+            }
+        }
+        double piv = a[k][k];
+        ok = ok && (fabs(piv) > 1e-300) && (fabs(piv) <= 1.7e308);
+        double ip = 1.0 / piv;
+#pragma unroll
+        for (int j = 0; j < M; ++j) { a[k][j] *= ip; b[k][j] *= ip; }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i == k) continue;
+            double f = a[i][k];
+#pragma unroll
+            for (int j = 0; j < M; ++j) { a[i][j] -= f * a[k][j]; b[i][j] -= f * b[k][j]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) inv[i * M + j] = b[i][j];
+    return ok;
+}
+
+// wave-level sum over the 4 lane groups that share a column (lanes l, l+16, l+32, l+48)
+PDP_DEV double sum_over_rowgroups(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+PDP_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace pdp

@@ -1,0 +1,124 @@
+"""GPU parity: pdp_lqr_solve_batched / aux integrators (HIP, through the C-ABI) vs
+  - outputs of the reference's own LQR.lqrSolver (tests/golden/ref_lqr_*.npz), and
+  - the numpy oracle on seeded random problems (incl. p > 16 - m tiles, shared/time-invariant strides).
+Tolerance: 1e-10 relative to the largest entry of each trajectory (stated fp64 tolerance)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def _to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_lqr_matches_reference_random_cases(golden_dir):
+    from pdp_amd import runtime as rt
+    r = np.load(os.path.join(golden_dir, "ref_lqr_random.npz"))
+    for c in range(int(r["n_cases"])):
+        g = lambda k: r["c%d_%s" % (c, k)]
+        T = int(g("T"))
+        tv = bool(g("time_varying"))
+        sel = (lambda a: a) if tv else (lambda a: a[0])
+        X, U, Lam, st = rt.lqr_solve(sel(g("F")), sel(g("G")), sel(g("Hxx")), sel(g("Huu")), g("hxx"), g("hxe"), E=sel(g("E")), Hxu=sel(g("Hxu")),
+                                     Hxe=sel(g("Hxe")), Hue=sel(g("Hue")), X0=g("X0"), T=T)
+        assert int(st.sum()) == 0
+        assert _rel(_to_np(X)[0], g("X")) < TOL, "case %d X" % c
+        assert _rel(_to_np(U)[0], g("U")) < TOL, "case %d U" % c
+        assert _rel(_to_np(Lam)[0], g("Lam")) < TOL, "case %d Lam" % c
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
+def test_lqr_matches_reference_on_demo_aux_systems(golden_dir, name):
+    """aux systems of the stored demos (reference getAuxSys) -> reference lqrSolver outputs, all demos as one batch."""
+    from pdp_amd import runtime as rt
+    a = np.load(os.path.join(golden_dir, "ref_auxsys_%s.npz" % name))
+    l = np.load(os.path.join(golden_dir, "ref_lqr_%s.npz" % name))
+    X, U, Lam, st = rt.lqr_solve(a["dynF"], a["dynG"], a["Hxx"], a["Huu"], a["hxx"][:, 0], a["hxe"][:, 0], E=a["dynE"], Hxu=a["Hxu"],
+                                 Hxe=a["Hxe"], Hue=a["Hue"])
+    assert int(st.sum()) == 0
+    assert _rel(_to_np(X), l["X"]) < TOL
+    assert _rel(_to_np(U), l["U"]) < TOL
+    assert _rel(_to_np(Lam), l["Lam"]) < TOL
+
+
+@pytest.mark.parametrize("n,m,p,T,B", [(13, 4, 9, 50, 64), (13, 3, 10, 100, 16), (4, 1, 7, 50, 256), (16, 4, 12, 8, 3), (7, 2, 40, 11, 5),
+                                        (13, 4, 60, 6, 2), (2, 1, 1, 1, 1), (5, 3, 13, 2, 4)])
+def test_lqr_matches_oracle_seeded(n, m, p, T, B):
+    from oracle import pdp_oracle as po
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(1000 * n + 10 * p + T)
+
+    def spd(k, s):
+        A = rng.standard_normal((k, k))
+        return s * (A @ A.T / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.1 * rng.standard_normal((B, T, n, n))
+    G = 0.3 * rng.standard_normal((B, T, n, m))
+    E = 0.1 * rng.standard_normal((B, T, n, p))
+    Hxx = np.stack([np.stack([spd(n, 1.0) for _ in range(T)]) for _ in range(B)])
+    Huu = np.stack([np.stack([spd(m, 0.5) for _ in range(T)]) for _ in range(B)])
+    Hxu = 0.05 * rng.standard_normal((B, T, n, m))
+    Hxe = 0.2 * rng.standard_normal((B, T, n, p))
+    Hue = 0.2 * rng.standard_normal((B, T, m, p))
+    hxx = np.stack([spd(n, 1.0) for _ in range(B)])
+    hxe = 0.2 * rng.standard_normal((B, n, p))
+    X0 = rng.standard_normal((B, n, p))
+    X, U, Lam, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0)
+    assert int(st.sum()) == 0
+    X, U, Lam = _to_np(X), _to_np(U), _to_np(Lam)
+    for b in range(min(B, 4)):
+        sol = po.lqr_solver(list(F[b]), list(G[b]), list(E[b]), list(Hxx[b]), list(Huu[b]), list(Hxu[b]), list(Hxe[b]), list(Hue[b]),
+                            [hxx[b]], [hxe[b]], X0[b], T)
+        assert _rel(X[b], np.stack(sol["state_traj_opt"])) < TOL
+        assert _rel(U[b], np.stack(sol["control_traj_opt"])) < TOL
+        assert _rel(Lam[b], np.stack(sol["costate_traj_opt"])) < TOL
+
+
+def test_lqr_optional_inputs_and_status():
+    """E/Hxu/Hxe/Hue/X0 omitted (zeros, PDP.py:496-555); a singular Huu + G'PG raises the pivot flag."""
+    from oracle import pdp_oracle as po
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(5)
+    n, m, p, T = 6, 2, 3, 9
+    F = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    G = rng.standard_normal((n, m))
+    Hxx, Huu = np.eye(n), 0.3 * np.eye(m)
+    hxx, hxe = np.eye(n), rng.standard_normal((n, p))
+    X, U, Lam, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, T=T)
+    Z = lambda r, c: T * [np.zeros((r, c))]
+    sol = po.lqr_solver(T * [F], T * [G], Z(n, p), T * [Hxx], T * [Huu], Z(n, m), Z(n, p), Z(m, p), [hxx], [hxe], np.zeros((n, p)), T)
+    assert int(st.sum()) == 0
+    assert _rel(_to_np(X)[0], np.stack(sol["state_traj_opt"])) < TOL
+    assert _rel(_to_np(U)[0], np.stack(sol["control_traj_opt"])) < TOL
+    X, U, Lam, st = rt.lqr_solve(F, np.zeros((n, m)), Hxx, np.zeros((m, m)), hxx, hxe, T=T)
+    assert int(st[0]) & 2
+
+
+def test_aux_integrators_match_numpy():
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(11)
+    B, T, n, m, p = 3, 7, 13, 4, 37
+    F = rng.standard_normal((B, T, n, n)) * 0.3
+    G = rng.standard_normal((B, T, n, m))
+    Ux = rng.standard_normal((B, T, m, n)) * 0.2
+    Ue = rng.standard_normal((B, T, m, p))
+    E = rng.standard_normal((B, T, n, p))
+    X0 = rng.standard_normal((B, n, p))
+    X, U = rt.cp_aux_integrate(F, G, Ux, Ue, X0)
+    Xs = rt.sysid_aux_integrate(F, E, None)
+    X, U, Xs = _to_np(X), _to_np(U), _to_np(Xs)
+    for b in range(B):
+        x = X0[b]
+        xs = np.zeros((n, p))
+        for t in range(T):
+            u = Ux[b, t] @ x + Ue[b, t]
+            x = F[b, t] @ x + G[b, t] @ u
+            xs = F[b, t] @ xs + E[b, t]
+            assert _rel(U[b, t], u) < 1e-12 and _rel(X[b, t + 1], x) < 1e-12 and _rel(Xs[b, t + 1], xs) < 1e-12
