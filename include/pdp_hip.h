@@ -84,6 +84,11 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
 int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double* F, const double* G, const double* Ux,
                                  const double* Ue, const double* X0, double* X, double* U, void* stream);
 
+/* Chain rule of ControlPlanning.step (PDP/PDP.py:869-876): grad[b][j] = sum_t dcx[b][t][:] X[b][t][:][j] + dcu[b][t][:] U[b][t][:][j]
+ * + dhx[b][:] X[b][T][:][j].  dcx [B][T][n], dcu [B][T][m], dhx [B][n], X [B][T+1][n][p], U [B][T][m][p] -> grad [B][p]. */
+int pdp_cp_grad_contract_batched(int B, int T, int n, int m, int p, const double* dcx, const double* dcu, const double* dhx,
+                                 const double* X, const double* U, double* grad, void* stream);
+
 /* Batched SysID.integrateAuxSys (PDP/PDP.py:1241-1259): X_{t+1} = F_t X_t + E_t.
  * F [B][T][n][n], E [B][T][n][p], X0 [B][n][p] (NULL = 0) -> X [B][T+1][n][p]. */
 int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0,
@@ -168,12 +173,16 @@ typedef struct pdp_policy {
 int pdp_cp_integrate_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta,
                              int theta_bstride, double* x, double* u, double* cost, void* stream);
 
-/* ControlPlanning.getAuxSys (PDP.py:788-811): dynF [B][T][n][n], dynG [B][T][n][m], dUx [B][T][m][n], dUe [B][T][m][p]. */
+/* ControlPlanning.getAuxSys (PDP.py:788-811): dynF [B][T][n][n], dynG [B][T][n][m], dUx [B][T][m][n], dUe [B][T][m][p];
+ * plus, optionally (NULL = skipped), the cost gradients that ControlPlanning.step evaluates along the trajectory
+ * (dcx_fn / dcu_fn / dhx_fn, PDP.py:871-876): dcx [B][T][n], dcu [B][T][m], dhx [B][n].  x is [B][T+1][n]. */
 int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const double* x, const double* u, const double* theta,
-                          int theta_bstride, double* dynF, double* dynG, double* dUx, double* dUe, void* stream);
+                          int theta_bstride, double* dynF, double* dynG, double* dUx, double* dUe, double* dcx, double* dcu,
+                          double* dhx, void* stream);
 
 /* ControlPlanning.step (PDP.py:850-878), fused: loss [B] = sum c + h, grad [B][p] = sum_t c_x X_t + c_u U_t + h_x X_T;
- * optional x [B][T+1][n], u [B][T][m] (NULL = not stored). */
+ * optional x [B][T+1][n], u [B][T][m] (NULL = not stored).  Provided for PDP_POLICY_POLY (p <= 64); for the MLP policy it
+ * returns PDP_E_MODE and the caller composes integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched. */
 int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int theta_bstride,
                         double* loss, double* grad, double* x, double* u, void* stream);
 

@@ -533,3 +533,52 @@ def solve_oc_homotopy(oc, ini_state, horizon, auxvar_value, start_theta, start_g
             if ds < min_step:
                 raise RuntimeError("homotopy stalled at s=%g" % s)
     return sol
+
+
+def lqr_solver_mp(dynF, dynG, dynE, Hxx, Huu, Hxu, Hxe, Hue, hxx, hxe, ini_state, horizon, dps=40):
+    """The SAME formulas as LQR.lqrSolver (PDP/PDP.py:557-608, with both explicit inverses) evaluated in
+    `dps`-digit arithmetic (mpmath): the reference algorithm without fp64 rounding.  On off-optimal
+    trajectories I + P R is ill-conditioned and the fp64 reference order itself loses up to ~7 digits
+    (measured: cart-pole 2e-7, robot arm 1e-9, quadrotor 3e-10 relative), so parity of the HIP kernels there
+    is judged against this evaluation; `lqr_solver` (fp64, reference order) is compared alongside."""
+    import mpmath as mp
+    old = mp.mp.dps
+    mp.mp.dps = dps
+    try:
+        cv = lambda A: mp.matrix(np.asarray(A, float).tolist())
+        T = int(horizon)
+        n = dynF[0].shape[0]
+        I = mp.eye(n)
+        F, G, E = [cv(a) for a in dynF], [cv(a) for a in dynG], [cv(a) for a in dynE]
+        Qxx, Quu, Qxu = [cv(a) for a in Hxx], [cv(a) for a in Huu], [cv(a) for a in Hxu]
+        Qxe, Que = [cv(a) for a in Hxe], [cv(a) for a in Hue]
+        PP, WW = T * [None], T * [None]
+        PP[-1], WW[-1] = cv(hxx[0]), cv(hxe[0])
+        for t in range(T - 1, 0, -1):
+            P, W = PP[t], WW[t]
+            iH = Quu[t] ** -1
+            GiH, XiH = G[t] * iH, Qxu[t] * iH
+            A = F[t] - GiH * Qxu[t].T
+            R = GiH * G[t].T
+            M = E[t] - GiH * Que[t]
+            Q = Qxx[t] - XiH * Qxu[t].T
+            N = Qxe[t] - XiH * Que[t]
+            tmp = A.T * (I + P * R) ** -1
+            PP[t - 1] = Q + tmp * (P * A)
+            WW[t - 1] = N + tmp * (W + P * M)
+        X = [cv(np.asarray(ini_state, float).reshape(n, -1))]
+        U = []
+        for t in range(T):
+            P, W = PP[t], WW[t]
+            iH = Quu[t] ** -1
+            GiH = G[t] * iH
+            A = F[t] - GiH * Qxu[t].T
+            M = E[t] - GiH * Que[t]
+            R = GiH * G[t].T
+            u = -iH * (Qxu[t].T * X[t] + Que[t]) - iH * G[t].T * ((I + P * R) ** -1) * (P * A * X[t] + P * M + W)
+            X.append(F[t] * X[t] + G[t] * u + E[t])
+            U.append(u)
+        tonp = lambda m_: np.array([[float(m_[r, c]) for c in range(m_.cols)] for r in range(m_.rows)])
+        return {"state_traj_opt": [tonp(x) for x in X], "control_traj_opt": [tonp(u) for u in U]}
+    finally:
+        mp.mp.dps = old

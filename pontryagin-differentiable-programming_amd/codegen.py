@@ -1,0 +1,297 @@
+"""One-time code generation: symbolic problem -> HIP device code (a `PdpModel` struct) -> libpdp_model_<name>.so.
+
+This replaces the reference's setup-time CasADi work: `OCSys.diffPMP` (PDP/PDP.py:222-270) builds 14
+casadi.Function objects that `getAuxSys` (272-314) then calls 9T+2 times per trajectory through SWIG; here the
+same derivatives are differentiated once (sx.py), emitted as straight-line device code with shared
+sub-expressions, and compiled by hipcc for gfx950 into the batched kernels of csrc/pdp_model_kernels.h.
+
+Generated interface (consumed by csrc/pdp_model_kernels.h):
+  struct PdpModel { KIND, NX, NU, NP, NAME, CHUNK;
+      dyn(x,u,th,out)  path_cost(x,u,th)  final_cost(x,th)  costate_step(x,u,lam,th,out)  dhx(x,th,out)
+      group <g> in {path, fwd, fin}:  <G>_NVAR, <G>_NCONST, <g>_const(c), eval_<g>(x,u,lam,th,sink),
+                                      <g>_code(mat, i), <G>_MAT[k], <G>_OFF[k], <G>_ROWS[mat], <G>_COLS[mat] }
+Matrix entries are classified at generation time: structural zero (code -1), constant (code -2-c, value in
+the constant pool) or variable (code k >= 0, written by eval_<g> through sink.put<k>(v)).  Only variable
+entries cost arithmetic and LDS space; the quadrotor's eight per-step matrices have ~200 of 728 entries non-zero.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+from . import sx
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+GEN_DIR = os.path.join(CSRC, "generated")
+LIB_DIR = os.path.join(HERE, "lib")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+
+KIND_OC, KIND_CP, KIND_SYSID = 0, 1, 2
+KIND_NAME = {0: "oc", 1: "cp", 2: "sysid"}
+
+# matrix order inside each group (indices used by the kernels)
+OC_PATH = ["F", "G", "E", "Hxx", "Hxu", "Hxe", "Huu", "Hue"]
+OC_FWD = ["F", "G", "E"]
+OC_FIN = ["hxx", "hxe"]
+CP_PATH = ["F", "G", "cx", "cu"]
+ID_PATH = ["F", "E"]
+
+
+def _col(v):
+    v = sx._lift(v)
+    return v.reshape((-1, 1))
+
+
+class Problem:
+    """Symbolic statement of one PDP problem (what the reference passes to setDyn/setPathCost/setFinalCost)."""
+
+    def __init__(self, kind, state, control, dyn, auxvar=None, path_cost=None, final_cost=None, label="model"):
+        self.kind = kind
+        self.x, self.u = _col(state), _col(control)
+        self.th = _col(auxvar) if auxvar is not None else sx.SX()
+        self.dyn = _col(dyn)
+        self.path_cost = sx._lift(path_cost) if path_cost is not None else None
+        self.final_cost = sx._lift(final_cost) if final_cost is not None else None
+        self.label = label
+        self.n, self.m, self.p = self.x.numel(), self.u.numel(), self.th.numel()
+        assert self.dyn.numel() == self.n, "dynamics must have as many rows as the state"
+        for s in list(self.x.data) + list(self.u.data) + list(self.th.data):
+            assert s.op == "sym", "state / control / auxvar must be purely symbolic"
+
+
+class _Group:
+    def __init__(self, gname, mats):
+        """mats: list of (name, rows, cols, SX).  Builds codes / pools."""
+        self.gname = gname
+        self.names = [m[0] for m in mats]
+        self.rows = [m[1] for m in mats]
+        self.cols = [m[2] for m in mats]
+        self.codes = []          # per matrix: list (row-major) of codes
+        self.var_nodes = []      # k -> node
+        self.var_mat, self.var_off = [], []
+        self.consts = []         # c -> value
+        cidx = {}
+        for mi, (name, r, c, M) in enumerate(mats):
+            M = sx._lift(M)
+            assert M.shape == (r, c), "%s: shape %s, expected %s" % (name, M.shape, (r, c))
+            codes = []
+            for i in range(r):
+                for j in range(c):
+                    nd = M.at(i, j)
+                    if nd.op == "const":
+                        if nd.val == 0.0:
+                            codes.append(-1)
+                        else:
+                            if nd.val not in cidx:
+                                cidx[nd.val] = len(self.consts)
+                                self.consts.append(nd.val)
+                            codes.append(-2 - cidx[nd.val])
+                    else:
+                        codes.append(len(self.var_nodes))
+                        self.var_nodes.append(nd)
+                        self.var_mat.append(mi)
+                        self.var_off.append(i * c + j)
+            self.codes.append(codes)
+
+    @property
+    def nvar(self):
+        return len(self.var_nodes)
+
+
+def _arr(vals, per_line=24):
+    vals = list(vals)
+    if not vals:
+        return "0"
+    out = []
+    for i in range(0, len(vals), per_line):
+        out.append(", ".join(str(v) for v in vals[i:i + per_line]))
+    return ",\n            ".join(out)
+
+
+def _emit_group(g, inputs, L):
+    G = g.gname.upper()
+    L.append("    // ---- group '%s': %s" % (g.gname, ", ".join("%s[%dx%d]" % (n, r, c) for n, r, c in zip(g.names, g.rows, g.cols))))
+    L.append("    static constexpr int %s_NMAT = %d, %s_NVAR = %d, %s_NCONST = %d;" % (G, len(g.names), G, g.nvar, G, len(g.consts)))
+    L.append("    static constexpr short %s_ROWS[%d] = {%s};" % (G, len(g.names), _arr(g.rows)))
+    L.append("    static constexpr short %s_COLS[%d] = {%s};" % (G, len(g.names), _arr(g.cols)))
+    L.append("    static constexpr short %s_MAT[%d] = {%s};" % (G, max(1, g.nvar), _arr(g.var_mat)))
+    L.append("    static constexpr short %s_OFF[%d] = {%s};" % (G, max(1, g.nvar), _arr(g.var_off)))
+    flat, base = [], []
+    for codes in g.codes:
+        base.append(len(flat))
+        flat.extend(codes)
+    L.append("    PDP_HD static int %s_code(int mat, int i) {" % g.gname)
+    L.append("        constexpr short tbl[] = {%s};" % _arr(flat))
+    L.append("        constexpr short base[] = {%s};" % _arr(base))
+    L.append("        return tbl[base[mat] + i];")
+    L.append("    }")
+    L.append("    PDP_HD static double %s_const(int c) {" % g.gname)
+    L.append("        constexpr double tbl[] = {%s};" % (_arr([sx._cnum(v) for v in g.consts], 8) if g.consts else "0.0"))
+    L.append("        return tbl[c];")
+    L.append("    }")
+    L.append("    template <class Sink>")
+    L.append("    PDP_HD static void eval_%s(const double* x, const double* u, const double* lam, const double* th, Sink& s) {" % g.gname)
+    L.append("        (void)x; (void)u; (void)lam; (void)th;")
+    L.extend(sx.emit(g.var_nodes, inputs, lang="c", result=lambda k, e: "s.template put<%d>(%s);" % (k, e), indent="        "))
+    L.append("    }")
+
+
+def _emit_vecfn(name, args, outputs, inputs, L, scalar=False):
+    if scalar:
+        L.append("    PDP_HD static double %s(%s) {" % (name, ", ".join("const double* %s" % a for a in args)))
+        L.append("        " + " ".join("(void)%s;" % a for a in args))
+        body = sx.emit(outputs, inputs, lang="c", result=lambda k, e: "return %s;" % e, indent="        ")
+        L.extend(body)
+        L.append("    }")
+    else:
+        L.append("    PDP_HD static void %s(%s, double* out) {" % (name, ", ".join("const double* %s" % a for a in args)))
+        L.append("        " + " ".join("(void)%s;" % a for a in args))
+        L.extend(sx.emit(outputs, inputs, lang="c", result=lambda k, e: "out[%d] = %s;" % (k, e), indent="        "))
+        L.append("    }")
+
+
+def _pick_chunk(nvar, extra):
+    """time steps per lane-parallel aux pass: LDS pool = chunk * (nvar+extra, odd) * 8 B, budget 34 KB so that
+    4 wavefronts (one per SIMD) fit a CU's 160 KB together with the Riccati scratch."""
+    stride = (nvar + extra) | 1
+    for c in (32, 16, 8, 4):
+        if c * stride * 8 <= 34 * 1024:
+            return c
+    return 2
+
+
+def generate(problem):
+    """Returns (header_source, info dict).  The model name embeds a hash of the generated code."""
+    pb = problem
+    n, m, p = pb.n, pb.m, pb.p
+    x, u, th = pb.x, pb.u, pb.th
+    lam = sx.SX.sym("lam", n)
+    inputs = {}
+    for nm, v in (("x", x), ("u", u), ("th", th), ("lam", lam)):
+        for k, nd in enumerate(v.data):
+            inputs[nd.id] = "%s[%d]" % (nm, k)
+    L = []
+    groups = {}
+    dyn = pb.dyn
+    fx, fu = sx.jacobian(dyn, x), sx.jacobian(dyn, u)
+    _emit_vecfn("dyn", ["x", "u", "th"], dyn.data, inputs, L)
+    if pb.kind == KIND_OC:
+        c, h = pb.path_cost, pb.final_cost
+        assert c is not None and h is not None and c.numel() == 1 and h.numel() == 1
+        fe = sx.jacobian(dyn, th)
+        H = c + sx.dot(dyn, lam)                                   # Hamiltonian, PDP.py:231
+        dHx, dHu = sx.jacobian(H, x).T, sx.jacobian(H, u).T        # PDP.py:243-246
+        dhx = sx.jacobian(h, x).T                                  # PDP.py:263
+        _emit_vecfn("path_cost", ["x", "u", "th"], c.data, inputs, L, scalar=True)
+        _emit_vecfn("final_cost", ["x", "th"], h.data, inputs, L, scalar=True)
+        _emit_vecfn("costate_step", ["x", "u", "lam", "th"], dHx.data, inputs, L)      # c_x + f_x' lam  (PDP.py:205-209)
+        _emit_vecfn("dhx", ["x", "th"], dhx.data, inputs, L)
+        mats = {"F": fx, "G": fu, "E": fe, "Hxx": sx.jacobian(dHx, x), "Hxu": sx.jacobian(dHx, u), "Hxe": sx.jacobian(dHx, th),
+                "Huu": sx.jacobian(dHu, u), "Hue": sx.jacobian(dHu, th), "hxx": sx.jacobian(dhx, x), "hxe": sx.jacobian(dhx, th)}
+        dims = {"F": (n, n), "G": (n, m), "E": (n, p), "Hxx": (n, n), "Hxu": (n, m), "Hxe": (n, p), "Huu": (m, m), "Hue": (m, p),
+                "hxx": (n, n), "hxe": (n, p)}
+        groups["path"] = _Group("path", [(k,) + dims[k] + (mats[k],) for k in OC_PATH])
+        groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD])
+        groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN])
+        chunk = _pick_chunk(groups["path"].nvar, 0)
+    elif pb.kind == KIND_CP:
+        c, h = pb.path_cost, pb.final_cost
+        assert p == 0, "ControlPlanning dynamics / costs carry no auxvar (PDP.py:672-697)"
+        _emit_vecfn("path_cost", ["x", "u", "th"], c.data, inputs, L, scalar=True)
+        _emit_vecfn("final_cost", ["x", "th"], h.data, inputs, L, scalar=True)
+        _emit_vecfn("dhx", ["x", "th"], sx.jacobian(h, x).T.data, inputs, L)
+        groups["path"] = _Group("path", [("F", n, n, fx), ("G", n, m, fu), ("cx", 1, n, sx.jacobian(c, x)), ("cu", 1, m, sx.jacobian(c, u))])
+        chunk = _pick_chunk(groups["path"].nvar, 0)
+    elif pb.kind == KIND_SYSID:
+        fe = sx.jacobian(dyn, th)
+        groups["path"] = _Group("path", [("F", n, n, fx), ("E", n, p, fe)])
+        chunk = _pick_chunk(groups["path"].nvar, n)
+    else:
+        raise ValueError("unknown problem kind")
+    for g in groups.values():
+        _emit_group(g, inputs, L)
+    body = "\n".join(L)
+    digest = hashlib.sha1(("%d|%d|%d|%d|" % (pb.kind, n, m, p) + body).encode()).hexdigest()[:10]
+    name = "%s_%s_%s" % (pb.label, KIND_NAME[pb.kind], digest)
+    head = [
+        "// AUTO-GENERATED by pdp_amd.codegen (symbolic problem -> HIP device code).  Do not edit.",
+        "// model %s : kind=%s n=%d m=%d p=%d ; scalar ops in path group: %d" % (name, KIND_NAME[pb.kind], n, m, p, sx.count_ops(groups["path"].var_nodes)),
+        "#pragma once",
+        "#ifndef PDP_HD",
+        "#define PDP_HD __host__ __device__ inline",
+        "#endif",
+        "struct PdpModel {",
+        "    static constexpr int KIND = %d, NX = %d, NU = %d, NP = %d, CHUNK = %d;" % (pb.kind, n, m, p, chunk),
+        "    static constexpr const char* NAME = \"%s\";" % name,
+    ]
+    src = "\n".join(head) + "\n" + body + "\n};\n"
+    info = dict(name=name, kind=pb.kind, n=n, m=m, p=p, chunk=chunk, nvar={k: g.nvar for k, g in groups.items()},
+                nconst={k: len(g.consts) for k, g in groups.items()}, ops_path=sx.count_ops(groups["path"].var_nodes))
+    return src, info
+
+
+# ------------------------------------------------------------------------------------------------------
+# build
+# ------------------------------------------------------------------------------------------------------
+def header_path(name):
+    return os.path.join(GEN_DIR, name + ".h")
+
+
+def lib_path(name):
+    return os.path.join(LIB_DIR, "libpdp_model_%s.so" % name)
+
+
+def write_header(problem):
+    src, info = generate(problem)
+    os.makedirs(GEN_DIR, exist_ok=True)
+    path = header_path(info["name"])
+    if not os.path.exists(path) or open(path).read() != src:
+        with open(path, "w") as f:
+            f.write(src)
+    return path, info
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout[-4000:]))
+    return r.stdout
+
+
+def compile_model(name, force=False):
+    """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr, out = header_path(name), lib_path(name)
+    deps = [hdr] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return out
+    if not os.path.exists(HIPCC):
+        raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
+    _run([HIPCC] + HIP_FLAGS + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip"), "-o", out])
+    return out
+
+
+def compile_core(force=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    out = os.path.join(LIB_DIR, "libpdp_hip.so")
+    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_riccati.h", "pdp_tile.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    _run([HIPCC] + HIP_FLAGS + ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip"), "-o", out])
+    return out
+
+
+def build_problem(problem, force=False):
+    """generate + compile (cached by content hash).  Returns (lib path, info)."""
+    _, info = write_header(problem)
+    return compile_model(info["name"], force=force), info
+
+
+def build_many(problems, force=False, workers=None):
+    infos = [write_header(pb)[1] for pb in problems]
+    with ThreadPoolExecutor(max_workers=workers or min(8, os.cpu_count() or 1)) as ex:
+        libs = list(ex.map(lambda i: compile_model(i["name"], force=force), infos))
+    return list(zip(libs, infos))

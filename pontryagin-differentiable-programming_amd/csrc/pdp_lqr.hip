@@ -5,6 +5,7 @@
 // One wavefront (= one 64-thread workgroup) per trajectory; matrices are read from HBM straight into the
 // register tile layout, every product is a chain of v_mfma_f64_16x16x4_f64 (pdp_tile.h / pdp_riccati.h).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include "../../include/pdp_hip.h"
 #include "pdp_riccati.h"
 
@@ -12,7 +13,15 @@ using namespace pdp;
 
 namespace {
 
-constexpr int MAX_NT = 4;   // parameter tiles: p <= (16 - m) + 16 * (MAX_NT - 1)
+constexpr int MAX_NT = 4;
+
+inline int launched() {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    fprintf(stderr, "[pdp_hip] kernel launch failed: %s\n", hipGetErrorString(e));
+    return PDP_E_LAUNCH;
+}
+#define PDP_CLEAR() (void)hipGetLastError()   // parameter tiles: p <= (16 - m) + 16 * (MAX_NT - 1)
 
 PDP_DEV const double* mat_at(const pdp_mat& M, int b, int t) {
     return M.ptr ? M.ptr + (int64_t)b * M.bstride + (int64_t)t * M.tstride : nullptr;
@@ -165,16 +174,37 @@ __global__ void __launch_bounds__(64) sysid_aux_kernel(int B, int T, int n, int 
     }
 }
 
+// grad[b][j] = sum_t dcx.X + dcu.U + dhx.X_T : one thread per (b, j), coalesced over j
+__global__ void cp_grad_contract_kernel(int B, int T, int n, int m, int p, const double* __restrict__ dcx, const double* __restrict__ dcu,
+                                        const double* __restrict__ dhx, const double* __restrict__ X, const double* __restrict__ U,
+                                        double* __restrict__ grad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j >= p) return;
+    double acc = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double* cx = dcx + ((int64_t)b * T + t) * n;
+        const double* cu = dcu + ((int64_t)b * T + t) * m;
+        const double* Xt = X + ((int64_t)b * (T + 1) + t) * n * p;
+        const double* Ut = U + ((int64_t)b * T + t) * m * p;
+        for (int i = 0; i < n; ++i) acc += cx[i] * Xt[i * p + j];
+        for (int i = 0; i < m; ++i) acc += cu[i] * Ut[i * p + j];
+    }
+    const double* XT = X + ((int64_t)b * (T + 1) + T) * n * p;
+    for (int i = 0; i < n; ++i) acc += dhx[(int64_t)b * n + i] * XT[i * p + j];
+    grad[(int64_t)b * p + j] = acc;
+}
+
 template <int M>
 int launch_lqr(const pdp_lqr_problem& pr, int nt, double* X, double* U, double* Lam, int32_t* status, double* wg, double* wpw, hipStream_t s) {
     dim3 grid(pr.B), block(64);
+    PDP_CLEAR();
     switch (nt) {
         case 1: hipLaunchKernelGGL((lqr_solve_kernel<M, 1>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
         case 2: hipLaunchKernelGGL((lqr_solve_kernel<M, 2>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
         case 3: hipLaunchKernelGGL((lqr_solve_kernel<M, 3>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
         default: hipLaunchKernelGGL((lqr_solve_kernel<M, 4>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
     }
-    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+    return launched();
 }
 
 }  // namespace
@@ -214,15 +244,25 @@ int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double
                                  const double* X0, double* X, double* U, void* stream) {
     if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !F || !G || !Ux || !Ue || !X || !U) return PDP_E_ARG;
     if (n > 16 || m > 16) return PDP_E_SIZE;
+    PDP_CLEAR();
     hipLaunchKernelGGL(cp_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
-    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+    return launched();
+}
+
+int pdp_cp_grad_contract_batched(int B, int T, int n, int m, int p, const double* dcx, const double* dcu, const double* dhx, const double* X,
+                                 const double* U, double* grad, void* stream) {
+    if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !dcx || !dcu || !dhx || !X || !U || !grad) return PDP_E_ARG;
+    PDP_CLEAR();
+    hipLaunchKernelGGL(cp_grad_contract_kernel, dim3((p + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, dcx, dcu, dhx, X, U, grad);
+    return launched();
 }
 
 int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0, double* X, void* stream) {
     if (B <= 0 || T <= 0 || n <= 0 || p <= 0 || !F || !E || !X) return PDP_E_ARG;
     if (n > 16) return PDP_E_SIZE;
+    PDP_CLEAR();
     hipLaunchKernelGGL(sysid_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, p, F, E, X0, X);
-    return hipGetLastError() == hipSuccess ? 0 : PDP_E_LAUNCH;
+    return launched();
 }
 
 }  // extern "C"

@@ -1,0 +1,216 @@
+// pdp_model.hip - C-ABI entry points of one generated model library (libpdp_model_<name>.so), section B of
+// include/pdp_hip.h.  Compiled once per model with -DPDP_MODEL_HEADER="generated/<name>.h" (codegen.py).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include "../../include/pdp_hip.h"
+#ifndef PDP_MODEL_HEADER
+#error "compile with -DPDP_MODEL_HEADER=\"generated/<model>.h\""
+#endif
+#define PDP_HD __host__ __device__ inline
+#include PDP_MODEL_HEADER
+#include "pdp_model_kernels.h"
+
+using namespace pdp;
+
+namespace {
+
+// launch-error protocol: stale errors of other libraries in the process are cleared on entry (PDP_CLEAR), the error
+// of our own launch is reported on stderr and mapped to PDP_E_LAUNCH
+inline int launched() {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    fprintf(stderr, "[pdp_hip] kernel launch failed: %s\n", hipGetErrorString(e));
+    return PDP_E_LAUNCH;
+}
+#define PDP_CLEAR() (void)hipGetLastError()
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+template <class Mdl> constexpr bool fused_oc_ok() { return Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4 && Mdl::NU + Mdl::NP <= 16; }
+
+template <class Mdl>
+int64_t oc_ws_bytes(int B, int T) {
+    return (int64_t)B * T * (Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP) * (int64_t)sizeof(double);
+}
+
+template <class Mdl>
+int oc_rollout(int B, int T, const double* x0, const double* u, const double* th, int tb, double* x, double* cost, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        if (B <= 0 || T <= 0 || !x0 || !u || !th || !x) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_rollout_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x0, u, th, tb, x, cost);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int oc_costate(int B, int T, const double* x, const double* u, const double* th, int tb, double* lam, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        if (B <= 0 || T <= 0 || !x || !u || !th || !lam) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_costate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x, u, th, tb, lam);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int oc_auxsys(int B, int T, const double* x, const double* u, const double* lam, const double* th, int tb, const pdp_oc_auxsys* o, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        if (B <= 0 || T <= 0 || !x || !u || !lam || !th || !o) return PDP_E_ARG;
+        const int64_t n = (int64_t)B * (T + 1);
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, x, u, lam, th, tb, *o);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const double* th, int tb, const double* dx, const double* du, double* x,
+           double* lam, double* loss, double* grad, double* dxdp, double* dudp, int32_t* status, void* ws, int64_t wsb, void* st) {
+    if constexpr (fused_oc_ok<Mdl>()) {
+        if (B <= 0 || T <= 0 || !u || !th || !dx || !du || !x || !lam || !loss || !grad || !ws) return PDP_E_ARG;
+        if (!(flags & PDP_OC_GIVEN_TRAJ) && !x0) return PDP_E_ARG;
+        if (wsb < oc_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
+        constexpr size_t lds = FusedLayout<Mdl>::LDS_DOUBLES * sizeof(double);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
+                           dudp, status, (double*)ws);
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl>
+int cp_integrate(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* x, double* u, double* cost, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_CP) {
+        if (B <= 0 || T <= 0 || !pol || !x0 || !th) return PDP_E_ARG;
+        if (pol->kind == PDP_POLICY_MLP) for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return PDP_E_SIZE;
+        if (Mdl::NX > MLP_MAX_WIDTH) return PDP_E_SIZE;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((cp_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, *pol, p, x0, th, tb, x, u, cost);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int cp_auxsys(int B, int T, const pdp_policy* pol, int p, const double* x, const double* u, const double* th, int tb, double* F, double* G,
+              double* Ux, double* Ue, double* cx, double* cu, double* hx, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_CP) {
+        if (B <= 0 || T <= 0 || !pol || !x || !u || !th) return PDP_E_ARG;
+        if (pol->kind == PDP_POLICY_MLP) for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return PDP_E_SIZE;
+        const int64_t n = (int64_t)B * (T + 1);
+        PDP_CLEAR();
+        hipLaunchKernelGGL((cp_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, *pol, p, x, u, th, tb, F, G, Ux, Ue, cx, cu, hx);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl, int NT>
+int cp_step_launch(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,
+                   double* u, void* st) {
+    const size_t lds = sizeof(double) * (1 + Mdl::PATH_NCONST + Mdl::CHUNK * (Mdl::PATH_NVAR | 1) + (size_t)(T + 1) * Mdl::NX + (size_t)T * Mdl::NU +
+                                         (size_t)T * pol->n_pivots + Mdl::NX + 8);
+    if (lds > 150 * 1024) return PDP_E_SIZE;
+    (void)hipFuncSetAttribute((const void*)cp_step_poly_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PDP_CLEAR();
+    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
+    return launched();
+}
+template <class Mdl>
+int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
+            void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_CP && Mdl::NX <= 16 && Mdl::NU <= 4) {
+        if (B <= 0 || T <= 0 || !pol || !x0 || !th || !loss || !grad) return PDP_E_ARG;
+        if (pol->kind != PDP_POLICY_POLY) return PDP_E_MODE;
+        if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
+        const int nt = (p + 15) / 16;
+        switch (nt) {
+            case 1: return cp_step_launch<Mdl, 1>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            case 2: return cp_step_launch<Mdl, 2>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            case 3: return cp_step_launch<Mdl, 3>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            case 4: return cp_step_launch<Mdl, 4>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            default: return PDP_E_SIZE;
+        }
+    } else { return Mdl::KIND == PDP_KIND_CP ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl>
+int sysid_integrate(int B, int T, const double* x0, const double* u, const double* th, int tb, double* x, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_SYSID) {
+        if (B <= 0 || T <= 0 || !x0 || !u || !th || !x) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((sysid_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x0, u, th, tb, x);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int sysid_auxsys(int B, int T, const double* x, const double* u, const double* th, int tb, double* F, double* E, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_SYSID) {
+        if (B <= 0 || T <= 0 || !x || !u || !th) return PDP_E_ARG;
+        const int64_t n = (int64_t)B * T;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((sysid_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, x, u, th, tb, F, E);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
+int sysid_step(int B, int T, const double* u, const double* xobs, const double* th, int tb, double* loss, double* grad, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_SYSID && Mdl::NX <= 16 && Mdl::NP <= 64) {
+        if (B <= 0 || T <= 0 || !u || !xobs || !th || !loss || !grad) return PDP_E_ARG;
+        constexpr int NT = (Mdl::NP + 15) / 16;
+        const size_t lds = sizeof(double) * (1 + Mdl::PATH_NCONST + Mdl::CHUNK * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (size_t)(T + 1) * Mdl::NX + Mdl::NX + 8);
+        if (lds > 150 * 1024) return PDP_E_SIZE;
+        (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PDP_CLEAR();
+        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad);
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_SYSID ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl> int nnz_path() { return Mdl::PATH_NVAR; }
+
+}  // namespace
+
+extern "C" {
+
+void pdp_model_get_info(pdp_model_info* info) {
+    if (!info) return;
+    info->kind = PdpModel::KIND; info->n = PdpModel::NX; info->m = PdpModel::NU; info->p = PdpModel::NP;
+    info->nnz_path = nnz_path<PdpModel>(); info->chunk = PdpModel::CHUNK; info->name = PdpModel::NAME;
+}
+int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, const double* theta, int tb, double* x, double* cost, void* stream) {
+    return oc_rollout<PdpModel>(B, T, x0, u, theta, tb, x, cost, stream);
+}
+int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const double* theta, int tb, double* lam, void* stream) {
+    return oc_costate<PdpModel>(B, T, x, u, theta, tb, lam, stream);
+}
+int pdp_oc_auxsys_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta, int tb, const pdp_oc_auxsys* out,
+                          void* stream) {
+    return oc_auxsys<PdpModel>(B, T, x, u, lam, theta, tb, out, stream);
+}
+int64_t pdp_oc_pdp_workspace_bytes(int B, int T) {
+    if constexpr (PdpModel::KIND == PDP_KIND_OC) return oc_ws_bytes<PdpModel>(B, T); else return 0;
+}
+int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta, int tb, const double* demo_x,
+                            const double* demo_u, double* x, double* lam, double* loss, double* grad, double* dxdp, double* dudp, int32_t* status,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
+    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, status, workspace, workspace_bytes, stream);
+}
+int pdp_cp_integrate_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int tb, double* x, double* u,
+                             double* cost, void* stream) {
+    return cp_integrate<PdpModel>(B, T, pol, p, x0, theta, tb, x, u, cost, stream);
+}
+int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const double* x, const double* u, const double* theta, int tb, double* dynF,
+                          double* dynG, double* dUx, double* dUe, double* dcx, double* dcu, double* dhx, void* stream) {
+    return cp_auxsys<PdpModel>(B, T, pol, p, x, u, theta, tb, dynF, dynG, dUx, dUe, dcx, dcu, dhx, stream);
+}
+int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int tb, double* loss, double* grad,
+                        double* x, double* u, void* stream) {
+    return cp_step<PdpModel>(B, T, pol, p, x0, theta, tb, loss, grad, x, u, stream);
+}
+int pdp_sysid_integrate_batched(int B, int T, const double* x0, const double* u, const double* theta, int tb, double* x, void* stream) {
+    return sysid_integrate<PdpModel>(B, T, x0, u, theta, tb, x, stream);
+}
+int pdp_sysid_auxsys_batched(int B, int T, const double* x, const double* u, const double* theta, int tb, double* dynF, double* dynE, void* stream) {
+    return sysid_auxsys<PdpModel>(B, T, x, u, theta, tb, dynF, dynE, stream);
+}
+int pdp_sysid_step_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int tb, double* loss, double* grad, void* stream) {
+    return sysid_step<PdpModel>(B, T, u, x_obs, theta, tb, loss, grad, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,731 @@
+// pdp_model_kernels.h - batched kernels instantiated once per generated model (struct PdpModel, see
+// codegen.py).  Section B of include/pdp_hip.h.
+//
+// Work decomposition
+//   * serial-in-time scalar recursions (rollout, costates) : one LANE per trajectory (materialised API), or
+//     executed uniformly by the wavefront that owns the trajectory (fused kernel);
+//   * model derivative evaluation (the aux system of OCSys.getAuxSys, reference PDP/PDP.py:287-301) is
+//     independent across time steps -> one LANE per time step; in the fused kernel a chunk of CHUNK steps is
+//     evaluated at once and only the structurally non-zero entries are written, packed, to an LDS pool;
+//   * the Riccati / sensitivity recursions run on MFMA register tiles (pdp_riccati.h), which gather their
+//     operands from the LDS pool through per-lane offsets computed once per kernel.
+// The per-step Jacobians/Hessians therefore never touch HBM in the fused path; HBM sees x0, u, theta, the demo,
+// the state/costate trajectories (API outputs), the feedback gains (scratch) and loss/gradient.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/pdp_hip.h"
+#include "pdp_riccati.h"
+#include "pdp_policy.h"
+
+namespace pdp {
+
+// ------------------------------------------------------------------------------------------------------
+// sinks for the generated eval_<group>() functions
+// ------------------------------------------------------------------------------------------------------
+struct PackedSink {            // variable entry k -> base[k]   (LDS pool row of this lane's time step)
+    double* base;
+    template <int K> PDP_DEV void put(double v) { base[K] = v; }
+};
+
+template <class Mdl> struct OcPathDense {   // scatter into the dense API layout; Hux written as Hxu^T
+    double* p[9];               // F G E Hxx Hxu Hxe Huu Hue, [8] = Hux
+    template <int K> PDP_DEV void put(double v) {
+        constexpr int mat = Mdl::PATH_MAT[K], off = Mdl::PATH_OFF[K];
+        if (p[mat]) p[mat][off] = v;
+        if constexpr (mat == 4) { if (p[8]) p[8][(off % Mdl::NU) * Mdl::NX + off / Mdl::NU] = v; }
+    }
+};
+template <class Mdl> struct OcFinDense {
+    double* p[2];
+    template <int K> PDP_DEV void put(double v) {
+        constexpr int mat = Mdl::FIN_MAT[K], off = Mdl::FIN_OFF[K];
+        if (p[mat]) p[mat][off] = v;
+    }
+};
+template <class Mdl> struct PathDense {     // generic: group 'path' of CP / SYSID models
+    double* p[4];
+    template <int K> PDP_DEV void put(double v) {
+        constexpr int mat = Mdl::PATH_MAT[K], off = Mdl::PATH_OFF[K];
+        if (p[mat]) p[mat][off] = v;
+    }
+};
+
+template <class Mdl>
+PDP_DEV void load_theta(const double* __restrict__ theta, int b, int bstride, double* th) {
+#pragma unroll
+    for (int k = 0; k < (Mdl::NP > 0 ? Mdl::NP : 1); ++k) th[k] = (Mdl::NP > 0) ? theta[(int64_t)b * bstride + k] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OC: rollout / costate (lane per trajectory), aux system (lane per (b,t))
+// ------------------------------------------------------------------------------------------------------
+template <class Mdl>
+__global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
+                                  int tb, double* __restrict__ x, double* __restrict__ cost) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double xc[NX], xn[NX], uc[NU];
+    double* xb = x + (int64_t)b * (T + 1) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
+        Mdl::dyn(xc, uc, th, xn);
+        if (cost) J += Mdl::path_cost(xc, uc, th);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
+    }
+    if (cost) cost[b] = J + Mdl::final_cost(xc, th);
+}
+
+template <class Mdl>
+__global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
+                                  int tb, double* __restrict__ lam) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    const double* xb = x + (int64_t)b * (T + 1) * NX;
+    const double* ub = u + (int64_t)b * T * NU;
+    double* lb = lam + (int64_t)b * T * NX;
+    double xc[NX], uc[NU], lc[NX], ln[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = xb[T * NX + i];
+    Mdl::dhx(xc, th, lc);                                  // lam[T-1] = h_x(x_T)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lb[(T - 1) * NX + i] = lc[i];
+    for (int k = T - 1; k >= 1; --k) {                     // lam[k-1] = c_x(x_k,u_k) + f_x' lam[k]
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = xb[k * NX + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uc[i] = ub[k * NU + i];
+        Mdl::costate_step(xc, uc, lc, th, ln);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { lc[i] = ln[i]; lb[(k - 1) * NX + i] = ln[i]; }
+    }
+}
+
+template <class Mdl>
+PDP_DEV void fill_static(double* dst, int mat, int count, bool fin) {
+    if (!dst) return;
+    for (int i = 0; i < count; ++i) {
+        int code = fin ? Mdl::fin_code(mat, i) : Mdl::path_code(mat, i);
+        if (code < 0) dst[i] = (code == -1) ? 0.0 : (fin ? Mdl::fin_const(-2 - code) : Mdl::path_const(-2 - code));
+    }
+}
+
+template <class Mdl>
+__global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ lam,
+                                 const double* __restrict__ theta, int tb, pdp_oc_auxsys o) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)B * (T + 1)) return;
+    const int b = (int)(g / (T + 1)), t = (int)(g % (T + 1));
+    double th[NP > 0 ? NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double xc[NX], uc[NU], lc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
+    if (t == T) {                                          // terminal matrices hxx, hxe at x_T (PDP.py:300-301)
+        OcFinDense<Mdl> s;
+        s.p[0] = o.hxx ? o.hxx + (int64_t)b * NX * NX : nullptr;
+        s.p[1] = o.hxe ? o.hxe + (int64_t)b * NX * NP : nullptr;
+        fill_static<Mdl>(s.p[0], 0, NX * NX, true);
+        fill_static<Mdl>(s.p[1], 1, NX * NP, true);
+        Mdl::eval_fin(xc, nullptr, nullptr, th, s);
+        return;
+    }
+    const int64_t bt = (int64_t)b * T + t;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uc[i] = u[bt * NU + i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lc[i] = lam[bt * NX + i];
+    OcPathDense<Mdl> s;
+    s.p[0] = o.dynF ? o.dynF + bt * NX * NX : nullptr;
+    s.p[1] = o.dynG ? o.dynG + bt * NX * NU : nullptr;
+    s.p[2] = o.dynE ? o.dynE + bt * NX * NP : nullptr;
+    s.p[3] = o.Hxx ? o.Hxx + bt * NX * NX : nullptr;
+    s.p[4] = o.Hxu ? o.Hxu + bt * NX * NU : nullptr;
+    s.p[5] = o.Hxe ? o.Hxe + bt * NX * NP : nullptr;
+    s.p[6] = o.Huu ? o.Huu + bt * NU * NU : nullptr;
+    s.p[7] = o.Hue ? o.Hue + bt * NU * NP : nullptr;
+    s.p[8] = o.Hux ? o.Hux + bt * NU * NX : nullptr;
+    for (int mat = 0; mat < 8; ++mat) fill_static<Mdl>(s.p[mat], mat, Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat], false);
+    if (s.p[8]) {
+        for (int i = 0; i < NX * NU; ++i) {
+            int code = Mdl::path_code(4, i);
+            if (code < 0) s.p[8][(i % NU) * NX + i / NU] = (code == -1) ? 0.0 : Mdl::path_const(-2 - code);
+        }
+    }
+    Mdl::eval_path(xc, uc, lc, th, s);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OC: fused forward + costates + aux system (LDS) + Riccati + PDP gradient, one wavefront per trajectory
+// ------------------------------------------------------------------------------------------------------
+struct Gather { int off[4]; int tmul[4]; };
+
+// offsets (in doubles, relative to the LDS block [cpool | pool]) of tile element (lane, r)
+template <class CodeFn>
+PDP_DEV void make_gather(Gather& g, int lane, int cpool_n, int stride, CodeFn code_of /* (row, col) -> code or -1 */) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int code = code_of(tile_row(lane, r), tile_col(lane));
+        if (code >= 0) { g.off[r] = cpool_n + code; g.tmul[r] = stride; }
+        else { g.off[r] = (code == -1) ? 0 : (1 + (-2 - code)); g.tmul[r] = 0; }
+    }
+}
+PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = lds[g.off[r] + tl * g.tmul[r]];
+    return v;
+}
+PDP_DEV d4 gather_tile_r0(const double* lds, const Gather& g, int tl) {
+    d4 v = zero4();
+    v[0] = lds[g.off[0] + tl * g.tmul[0]];
+    return v;
+}
+
+template <class Mdl>
+struct FusedLayout {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+    static constexpr int NC = 1 + (Mdl::PATH_NCONST > Mdl::FWD_NCONST ? (Mdl::PATH_NCONST > Mdl::FIN_NCONST ? Mdl::PATH_NCONST : Mdl::FIN_NCONST)
+                                                                      : (Mdl::FWD_NCONST > Mdl::FIN_NCONST ? Mdl::FWD_NCONST : Mdl::FIN_NCONST));
+    static constexpr int BSTRIDE = Mdl::PATH_NVAR | 1;                         // backward pool row (odd -> conflict-free)
+    static constexpr int FEXTRA = NX + NU;                                      // x - x_demo, u - u_demo per step
+    static constexpr int FSTRIDE = (Mdl::FWD_NVAR + FEXTRA) | 1;
+    static constexpr int POOL = CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) > Mdl::FIN_NVAR + 1 ? CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) : Mdl::FIN_NVAR + 1;
+    static constexpr int LDS_DOUBLES = RICCATI_SCRATCH + NC + POOL + NX + 8;
+};
+
+template <class Mdl>
+__global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
+                                                           const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
+                                                           const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
+                                                           double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
+                                                           double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
+    using L = FusedLayout<Mdl>;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK, M = NU;
+    constexpr int GSZ = NX * NU + NU * NP;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* scratch = lds;                              // RICCATI_SCRATCH
+    double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
+    double* pool = blk + L::NC;
+    double* dlT = pool + L::POOL;                       // x_T - xdemo_T (NX)
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const d4 z = zero4();
+    double th[NP];
+    load_theta<Mdl>(theta, b, tb, th);
+    double* xb = x + (int64_t)b * (T + 1) * NX;
+    double* lb = lam + (int64_t)b * T * NX;
+    const double* ub = u + (int64_t)b * T * NU;
+    double* gw = ws_gain + (int64_t)b * T * GSZ;
+
+    // ---------------- phase R/C: trajectory and costates (executed uniformly by all lanes) ------------
+    if (!(flags & PDP_OC_GIVEN_TRAJ)) {
+        double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xb[i] = xc[i];
+        }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+            Mdl::dyn(xc, uc, th, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
+            }
+        }
+        double lc[NX], ln[NX];
+        Mdl::dhx(xc, th, lc);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lb[(T - 1) * NX + i] = lc[i];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int k = T - 1; k >= 1; --k) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xb[k * NX + i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uc[i] = ub[k * NU + i];
+            Mdl::costate_step(xc, uc, lc, th, ln);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lc[i] = ln[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lb[(k - 1) * NX + i] = ln[i];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    // ---------------- terminal condition: P = hxx(x_T), W = hxe(x_T) ----------------------------------
+    bool ok = true, finite = true;
+    d4 P, W2;
+    {
+        if (lane == 0) blk[0] = 0.0;
+        if (lane < Mdl::FIN_NCONST) blk[1 + lane] = Mdl::fin_const(lane);
+        if (lane == 0) {
+            double xT[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
+            PackedSink s{pool};
+            Mdl::eval_fin(xT, nullptr, nullptr, th, s);
+        }
+        __syncthreads();
+        Gather gP, gW;
+        make_gather(gP, lane, L::NC, 0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1; });
+        make_gather(gW, lane, L::NC, 0, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fin_code(1, r * NP + (c - M)) : -1; });
+        P = gather_tile(blk, gP, 0);
+        W2 = gather_tile(blk, gW, 0);
+        __syncthreads();
+    }
+
+    // ---------------- backward sweep: chunks of CH time steps ------------------------------------------
+    {
+        if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+        Gather gF, gY, gHxx, gHX, gHU;
+        make_gather(gF, lane, L::NC, L::BSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, r * NX + c) : -1; });
+        make_gather(gY, lane, L::NC, L::BSTRIDE, [](int r, int c) {
+            return r >= NX ? -1 : (c < M ? Mdl::path_code(1, r * NU + c) : (c < M + NP ? Mdl::path_code(2, r * NP + (c - M)) : -1)); });
+        make_gather(gHxx, lane, L::NC, L::BSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(3, r * NX + c) : -1; });
+        make_gather(gHX, lane, L::NC, L::BSTRIDE, [](int r, int c) {
+            return r >= NX ? -1 : (c < M ? Mdl::path_code(4, r * NU + c) : (c < M + NP ? Mdl::path_code(5, r * NP + (c - M)) : -1)); });
+        make_gather(gHU, lane, L::NC, L::BSTRIDE, [](int r, int c) {
+            return r >= M ? -1 : (c < M ? Mdl::path_code(6, r * NU + c) : (c < M + NP ? Mdl::path_code(7, r * NP + (c - M)) : -1)); });
+        const int nchunk = (T + CH - 1) / CH;
+        for (int c = nchunk - 1; c >= 0; --c) {
+            const int t0 = c * CH, cnt = min(CH, T - t0);
+            __syncthreads();
+            if (lane < cnt) {                       // lane = time step: evaluate all path matrices at (x_t, u_t, lambda_{t+1})
+                const int t = t0 + lane;
+                double xc[NX], uc[NU], lc[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; lc[i] = lb[t * NX + i]; }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+                PackedSink s{pool + lane * L::BSTRIDE};
+                Mdl::eval_path(xc, uc, lc, th, s);
+            }
+            __syncthreads();
+            for (int tl = cnt - 1; tl >= 0; --tl) {
+                const int t = t0 + tl;
+                d4 Ft = gather_tile(blk, gF, tl);
+                d4 Y2 = gather_tile(blk, gY, tl);
+                d4 Hxx = gather_tile(blk, gHxx, tl);
+                d4 HX2 = gather_tile(blk, gHX, tl);
+                d4 HU2 = gather_tile_r0(blk, gHU, tl);
+                RiccatiGains g;
+                d4 P_old;
+                ok = riccati_backward<M>(P, W2, Ft, Y2, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
+                store_dense(gw + t * GSZ, NX, NU, NU, 0, 0, lane, g.KT);
+                store_dense(gw + t * GSZ + NX * NU, NU, NP, NP, 0, M, lane, g.IK);
+                finite = finite && tile_finite(P) && tile_finite(W2);
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---------------- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, loss and gradient -----------
+    double acc = 0.0, lsum = 0.0;
+    {
+        if (lane < Mdl::FWD_NCONST) blk[1 + lane] = Mdl::fwd_const(lane);
+        constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
+        Gather gFT, gGT, gE, gDX, gDU;
+        make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
+        make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1; });
+        make_gather(gE, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fwd_code(2, r * NP + (c - M)) : -1; });
+        make_gather(gDX, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
+        make_gather(gDU, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M) ? DLU + r : -1; });
+        const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
+        const double* dub = demo_u + (int64_t)b * T * NU;
+        d4 X2 = z;
+        const int nchunk = (T + CH - 1) / CH;
+        for (int c = 0; c < nchunk; ++c) {
+            const int t0 = c * CH, cnt = min(CH, T - t0);
+            __syncthreads();
+            if (lane < cnt) {
+                const int t = t0 + lane;
+                double xc[NX], uc[NU];
+                double* row = pool + lane * L::FSTRIDE;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; double d = xc[i] - dxb[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; double d = uc[i] - dub[t * NU + i]; row[DLU + i] = d; lsum += d * d; }
+                PackedSink s{row};
+                Mdl::eval_fwd(xc, uc, nullptr, th, s);
+            }
+            __syncthreads();
+            for (int tl = 0; tl < cnt; ++tl) {
+                const int t = t0 + tl;
+                d4 FT = gather_tile(blk, gFT, tl);
+                d4 GT = gather_tile_r0(blk, gGT, tl);
+                d4 E2 = gather_tile(blk, gE, tl);
+                d4 DX = gather_tile(blk, gDX, tl);          // (x_t - xd_t)[row] broadcast over columns
+                d4 DU = gather_tile_r0(blk, gDU, tl);
+                d4 KTn = -load_dense<false>(gw + t * GSZ, NX, NU, NU, 0, 0, lane);
+                d4 kn = -load_dense<false>(gw + t * GSZ + NX * NU, NU, NP, NP, 0, M, lane);
+                d4 U2, Xn;
+                riccati_forward(KTn, kn, FT, GT, E2, X2, U2, Xn);
+                acc += DX[0] * X2[0] + DX[1] * X2[1] + DX[2] * X2[2] + DX[3] * X2[3] + DU[0] * U2[0];
+                if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+                if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+                X2 = Xn;
+                finite = finite && tile_finite(Xn);
+            }
+        }
+        // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
+        __syncthreads();
+        if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
+        if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + T) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+    }
+    acc = sum_over_rowgroups(acc);
+    lsum = wave_sum(lsum);
+    if (lane >= M && lane < M + NP) grad[(int64_t)b * NP + (lane - M)] = acc;
+    if (lane == 0) loss[b] = lsum;
+    int st = 0;
+    if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
+    if (!ok) st |= PDP_STATUS_PIVOT;
+    if (lane == 0 && status) status[b] = st;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// ControlPlanning (PDP_KIND_CP)
+// ------------------------------------------------------------------------------------------------------
+template <class Mdl>
+__global__ void cp_integrate_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta, int tb,
+                                    double* __restrict__ x, double* __restrict__ u, double* __restrict__ cost) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* th = theta + (int64_t)b * tb;
+    double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; if (x) x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        policy_eval<NX, NU>(pol, t, xc, th, uc);
+        Mdl::dyn(xc, uc, nullptr, xn);
+        J += Mdl::path_cost(xc, uc, nullptr);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) if (u) u[((int64_t)b * T + t) * NU + i] = uc[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; if (x) x[((int64_t)b * (T + 1) + t + 1) * NX + i] = xn[i]; }
+    }
+    if (cost) cost[b] = J + Mdl::final_cost(xc, nullptr);
+}
+
+template <class Mdl>
+PDP_DEV void fill_static_path(double* dst, int mat, int count) {
+    if (!dst) return;
+    for (int i = 0; i < count; ++i) {
+        int code = Mdl::path_code(mat, i);
+        if (code < 0) dst[i] = (code == -1) ? 0.0 : Mdl::path_const(-2 - code);
+    }
+}
+
+template <class Mdl>
+__global__ void cp_auxsys_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x, const double* __restrict__ u,
+                                 const double* __restrict__ theta, int tb, double* __restrict__ dynF, double* __restrict__ dynG,
+                                 double* __restrict__ dUx, double* __restrict__ dUe, double* __restrict__ dcx, double* __restrict__ dcu,
+                                 double* __restrict__ dhx) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)B * (T + 1)) return;
+    const int b = (int)(g / (T + 1)), t = (int)(g % (T + 1));
+    double xc[NX], uc[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
+    if (t == T) {
+        if (dhx) { double h[NX]; Mdl::dhx(xc, nullptr, h);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dhx[(int64_t)b * NX + i] = h[i]; }
+        return;
+    }
+    const int64_t bt = (int64_t)b * T + t;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uc[i] = u[bt * NU + i];
+    PathDense<Mdl> s;
+    s.p[0] = dynF ? dynF + bt * NX * NX : nullptr;
+    s.p[1] = dynG ? dynG + bt * NX * NU : nullptr;
+    s.p[2] = dcx ? dcx + bt * NX : nullptr;
+    s.p[3] = dcu ? dcu + bt * NU : nullptr;
+    for (int mat = 0; mat < 4; ++mat) fill_static_path<Mdl>(s.p[mat], mat, Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat]);
+    Mdl::eval_path(xc, uc, nullptr, nullptr, s);
+    if (dUx && dUe) policy_jacobians<NX, NU>(pol, p, t, xc, theta + (int64_t)b * tb, dUx + bt * NU * NX, dUe + bt * NU * p);
+}
+
+// Fused ControlPlanning.step for the Lagrange-polynomial policy: rollout (uniform), then forward sensitivities
+// X_{t+1} = F X_t + G Ue_t on MFMA tiles with the per-step matrices staged in LDS; NT tiles of 16 parameters.
+template <class Mdl, int NT>
+__global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0,
+                                                           const double* __restrict__ theta, int tb, double* __restrict__ loss,
+                                                           double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = Mdl::CHUNK, M = NU;
+    constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* blk = lds;                       // [cpool | pool]
+    double* pool = blk + NC;
+    double* xs = pool + CH * STRIDE;         // (T+1) x NX
+    double* us = xs + (T + 1) * NX;          // T x NU
+    double* basis = us + T * NU;             // T x n_pivots
+    double* hx = basis + T * pol.n_pivots;   // NX
+    const int b = blockIdx.x, lane = threadIdx.x, np = pol.n_pivots;
+    const double* th = theta + (int64_t)b * tb;
+    const d4 z = zero4();
+    for (int t = lane; t < T; t += 64)
+        for (int i = 0; i < np; ++i) basis[t * np + i] = lagrange_basis(pol, i, (double)t);
+    if (lane == 0) blk[0] = 0.0;
+    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    __syncthreads();
+    // ---- rollout (uniform)
+    double J = 0.0;
+    {
+        double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+        }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uc[j] = 0.0;
+            for (int i = 0; i < np; ++i) {
+                double bi = basis[t * np + i];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) uc[j] += bi * th[i * NU + j];
+            }
+            Mdl::dyn(xc, uc, nullptr, xn);
+            J += Mdl::path_cost(xc, uc, nullptr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) us[t * NU + j] = uc[j];
+            }
+        }
+        J += Mdl::final_cost(xc, nullptr);
+        double h[NX];
+        Mdl::dhx(xc, nullptr, h);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) hx[i] = h[i];
+        }
+    }
+    __syncthreads();
+    if (xo) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
+    if (uo) for (int i = lane; i < T * NU; i += 64) uo[(int64_t)b * T * NU + i] = us[i];
+    // ---- forward sensitivities
+    Gather gFT, gGT, gCX, gCU;
+    make_gather(gFT, lane, NC, STRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, c * NX + r) : -1; });
+    make_gather(gGT, lane, NC, STRIDE, [](int r, int c) { return (r < M && c < NX) ? Mdl::path_code(1, c * NU + r) : -1; });
+    make_gather(gCX, lane, NC, STRIDE, [](int r, int c) { return (r < NX) ? Mdl::path_code(2, r) : -1; });
+    make_gather(gCU, lane, NC, STRIDE, [](int r, int c) { return (r < M) ? Mdl::path_code(3, r) : -1; });
+    d4 X[NT];
+    double acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { X[j] = z; acc[j] = 0.0; }
+    const int row0 = lane >> 4, col = lane & 15;
+    const int nchunk = (T + CH - 1) / CH;
+    for (int c = 0; c < nchunk; ++c) {
+        const int t0 = c * CH, cnt = min(CH, T - t0);
+        __syncthreads();
+        if (lane < cnt) {
+            const int t = t0 + lane;
+            double xc[NX], uc[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xs[t * NX + i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
+            PackedSink s{pool + lane * STRIDE};
+            Mdl::eval_path(xc, uc, nullptr, nullptr, s);
+        }
+        __syncthreads();
+        for (int tl = 0; tl < cnt; ++tl) {
+            const int t = t0 + tl;
+            d4 FT = gather_tile(blk, gFT, tl);
+            d4 GT = gather_tile_r0(blk, gGT, tl);
+            d4 CX = gather_tile(blk, gCX, tl);
+            d4 CU = gather_tile_r0(blk, gCU, tl);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int cidx = 16 * j + col;                 // parameter index of this lane's column
+                d4 Ue = z;                                      // d pi/d theta = [b_0 I_m ... b_N I_m]   (rows < m live in register 0)
+                if (cidx < p && row0 < M && (cidx % NU) == row0) Ue[0] = basis[t * np + cidx / NU];
+                acc[j] += CX[0] * X[j][0] + CX[1] * X[j][1] + CX[2] * X[j][2] + CX[3] * X[j][3] + CU[0] * Ue[0];
+                d4 Xn = mma_tn(FT, X[j], z);
+                X[j] = mma_tn_r0(GT, Ue, Xn);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc[j] += hx[row] * X[j][r]; }
+        double a = sum_over_rowgroups(acc[j]);
+        if (lane < 16 && 16 * j + lane < p) grad[(int64_t)b * p + 16 * j + lane] = a;
+    }
+    if (lane == 0) loss[b] = J;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SysID (PDP_KIND_SYSID)
+// ------------------------------------------------------------------------------------------------------
+template <class Mdl>
+__global__ void sysid_integrate_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
+                                       int tb, double* __restrict__ x) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
+        Mdl::dyn(xc, uc, th, xn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; x[((int64_t)b * (T + 1) + t + 1) * NX + i] = xn[i]; }
+    }
+}
+
+template <class Mdl>
+__global__ void sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
+                                    int tb, double* __restrict__ dynF, double* __restrict__ dynE) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)B * T) return;
+    const int b = (int)(g / T);
+    double th[NP > 0 ? NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    const int t = (int)(g % T);
+    double xc[NX], uc[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uc[i] = u[g * NU + i];
+    PathDense<Mdl> s;
+    s.p[0] = dynF ? dynF + g * NX * NX : nullptr;
+    s.p[1] = dynE ? dynE + g * NX * NP : nullptr;
+    s.p[2] = s.p[3] = nullptr;
+    fill_static_path<Mdl>(s.p[0], 0, NX * NX);
+    fill_static_path<Mdl>(s.p[1], 1, NX * NP);
+    Mdl::eval_path(xc, uc, nullptr, th, s);
+}
+
+// Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
+template <class Mdl, int NT>
+__global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const double* __restrict__ u, const double* __restrict__ xobs,
+                                                         const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+    constexpr int NC = 1 + Mdl::PATH_NCONST, DLX = Mdl::PATH_NVAR, STRIDE = (Mdl::PATH_NVAR + NX) | 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* blk = lds;
+    double* pool = blk + NC;
+    double* xs = pool + CH * STRIDE;         // (T+1) x NX
+    double* dlT = xs + (T + 1) * NX;         // NX
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const d4 z = zero4();
+    double th[NP];
+    load_theta<Mdl>(theta, b, tb, th);
+    const double* ub = u + (int64_t)b * T * NU;
+    const double* ob = xobs + (int64_t)b * (T + 1) * NX;
+    if (lane == 0) blk[0] = 0.0;
+    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    {
+        double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = ob[i];                       // ini_state = batch_states[i][0] (PDP.py:1269)
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+        }
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+            Mdl::dyn(xc, uc, th, xn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+            }
+        }
+    }
+    __syncthreads();
+    Gather gFT, gDX, gE[NT];
+    make_gather(gFT, lane, NC, STRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, c * NX + r) : -1; });
+    make_gather(gDX, lane, NC, STRIDE, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        make_gather(gE[j], lane, NC, STRIDE, [j](int r, int c) { return (r < NX && 16 * j + c < NP) ? Mdl::path_code(1, r * NP + 16 * j + c) : -1; });
+    d4 X[NT];
+    double acc[NT], lsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { X[j] = z; acc[j] = 0.0; }
+    const int nchunk = (T + CH - 1) / CH;
+    for (int c = 0; c < nchunk; ++c) {
+        const int t0 = c * CH, cnt = min(CH, T - t0);
+        __syncthreads();
+        if (lane < cnt) {
+            const int t = t0 + lane;
+            double xc[NX], uc[NU];
+            double* row = pool + lane * STRIDE;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xc[i] = xs[t * NX + i]; double d = xc[i] - ob[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+            PackedSink s{row};
+            Mdl::eval_path(xc, uc, nullptr, th, s);
+        }
+        __syncthreads();
+        for (int tl = 0; tl < cnt; ++tl) {
+            d4 FT = gather_tile(blk, gFT, tl);
+            d4 DX = gather_tile(blk, gDX, tl);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                d4 E = gather_tile(blk, gE[j], tl);
+                acc[j] += DX[0] * X[j][0] + DX[1] * X[j][1] + DX[2] * X[j][2] + DX[3] * X[j][3];
+                X[j] = mma_tn(FT, X[j], E);
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < NX) { double d = xs[T * NX + lane] - ob[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc[j] += dlT[row] * X[j][r]; }
+        double a = sum_over_rowgroups(acc[j]);
+        if (lane < 16 && 16 * j + lane < NP) grad[(int64_t)b * NP + 16 * j + lane] = a;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) loss[b] = lsum;
+}
+
+}  // namespace pdp

@@ -48,6 +48,13 @@ MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_costate
 _core = None
 
 
+def _dlopen(path):
+    """dlopen one of our libraries AFTER torch, so that its libamdhip64.so.7 dependency resolves to the HIP runtime
+    torch already loaded (one runtime per process; loading /opt/rocm's copy first leaves torch without a device)."""
+    import torch  # noqa: F401
+    return C.CDLL(path)
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed: %s" % (what, PDP_E.get(rc, rc)))
@@ -60,7 +67,7 @@ def load_core():
         if not os.path.exists(CORE_LIB):
             raise RuntimeError("libpdp_hip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                                "there is no CPU fallback" % CORE_LIB)
-        lib = C.CDLL(CORE_LIB)
+        lib = _dlopen(CORE_LIB)
         lib.pdp_hip_version.restype = C.c_char_p
         lib.pdp_lqr_workspace_bytes.restype = C.c_int64
         lib.pdp_lqr_workspace_bytes.argtypes = [C.c_int] * 6
@@ -182,3 +189,231 @@ def sysid_aux_integrate(F, E, X0=None):
     check(lib.pdp_sysid_aux_integrate_batched(B, T, n, p, ptr(F), ptr(E), ptr(X0), ptr(X), current_stream_ptr()),
           "pdp_sysid_aux_integrate_batched")
     return X
+
+
+# ------------------------------------------------------------------------------------------------------
+# per-model libraries (section B of include/pdp_hip.h)
+# ------------------------------------------------------------------------------------------------------
+_VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
+_MODEL_SIGS = {
+    "pdp_model_get_info": (None, [C.POINTER(PdpModelInfo)]),
+    "pdp_oc_rollout_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "pdp_oc_costate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
+    "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
+    "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "pdp_cp_auxsys_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pdp_cp_step_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "pdp_sysid_integrate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pdp_sysid_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "pdp_sysid_step_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+}
+_models = {}
+
+
+def make_policy(kind, pivots=None, layers=None):
+    pol = PdpPolicy()
+    if kind == "poly":
+        pol.kind = 0
+        pol.n_pivots = len(pivots)
+        assert pol.n_pivots <= 16, "at most 16 Lagrange pivots"
+        for i, v in enumerate(pivots):
+            pol.pivots[i] = float(v)
+    else:
+        pol.kind = 1
+        pol.n_layers = len(layers)
+        assert pol.n_layers <= 8, "at most 8 MLP layers"
+        for i, v in enumerate(layers):
+            pol.sizes[i] = int(v)
+    return pol
+
+
+class ModelLib:
+    """One generated model library; methods mirror the C entry points on torch tensors."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError("model library %s not built; there is no CPU fallback" % path)
+        self.path = path
+        self.lib = _dlopen(path)
+        for name, (res, args) in _MODEL_SIGS.items():
+            fn = getattr(self.lib, name)
+            fn.restype, fn.argtypes = res, args
+        info = PdpModelInfo()
+        self.lib.pdp_model_get_info(C.byref(info))
+        self.kind, self.n, self.m, self.p = info.kind, info.n, info.m, info.p
+        self.nnz_path, self.chunk, self.name = info.nnz_path, info.chunk, info.name.decode()
+
+    # -- helpers
+    def _theta(self, theta, B, p=None):
+        th = dev(theta)
+        p = self.p if p is None else p
+        th = th.reshape(-1, p)
+        assert th.shape[0] in (1, B), "theta must be [p] (shared) or [B,p]"
+        return th, (p if th.shape[0] == B and B > 1 else 0)
+
+    # -- OC
+    def oc_rollout(self, x0, u, theta, want_cost=True):
+        torch = torch_cuda()
+        x0, u = dev(x0).reshape(-1, self.n), dev(u)
+        B, T = x0.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda")
+        cost = torch.empty((B,), dtype=torch.float64, device="cuda") if want_cost else None
+        check(self.lib.pdp_oc_rollout_batched(B, T, ptr(x0), ptr(u), ptr(th), tb, ptr(x), ptr(cost), current_stream_ptr()), "pdp_oc_rollout_batched")
+        return x, cost
+
+    def oc_costate(self, x, u, theta):
+        torch = torch_cuda()
+        x, u = dev(x), dev(u)
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        lam = torch.empty((B, T, self.n), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_oc_costate_batched(B, T, ptr(x), ptr(u), ptr(th), tb, ptr(lam), current_stream_ptr()), "pdp_oc_costate_batched")
+        return lam
+
+    def oc_auxsys(self, x, u, lam, theta):
+        torch = torch_cuda()
+        x, u, lam = dev(x), dev(u), dev(lam)
+        B, T = u.shape[0], u.shape[1]
+        n, m, p = self.n, self.m, self.p
+        th, tb = self._theta(theta, B)
+        shp = dict(dynF=(B, T, n, n), dynG=(B, T, n, m), dynE=(B, T, n, p), Hxx=(B, T, n, n), Hxu=(B, T, n, m), Hxe=(B, T, n, p),
+                   Hux=(B, T, m, n), Huu=(B, T, m, m), Hue=(B, T, m, p), hxx=(B, n, n), hxe=(B, n, p))
+        out = {k: torch.empty(s, dtype=torch.float64, device="cuda") for k, s in shp.items()}
+        o = PdpOcAuxsys(**{k: v.data_ptr() for k, v in out.items()})
+        check(self.lib.pdp_oc_auxsys_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, C.byref(o), current_stream_ptr()), "pdp_oc_auxsys_batched")
+        return out
+
+    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None):
+        """Fused forward + Riccati + PDP gradient.  Give (x, lam) to use an optimal trajectory (PDP_OC_GIVEN_TRAJ),
+        else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp])."""
+        torch = torch_cuda()
+        u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
+        B, T = u.shape[0], u.shape[1]
+        n, m, p = self.n, self.m, self.p
+        th, tb = self._theta(theta, B)
+        flags = 0
+        if x is not None:
+            assert lam is not None
+            x, lam, flags = dev(x), dev(lam), 1
+            x0 = None
+        else:
+            x0 = dev(x0).reshape(B, n)
+        bufs = buffers if buffers is not None else {}
+
+        def buf(key, shape, dtype=torch.float64):
+            t = bufs.get(key)
+            if t is None or tuple(t.shape) != tuple(shape):
+                t = torch.empty(shape, dtype=dtype, device="cuda")
+                bufs[key] = t
+            return t
+        if x is None:
+            x, lam = buf("x", (B, T + 1, n)), buf("lam", (B, T, n))
+        loss, grad = buf("loss", (B,)), buf("grad", (B, p))
+        status = buf("status", (B,), torch.int32)
+        dxdp = buf("dxdp", (B, T + 1, n, p)) if want_sens else None
+        dudp = buf("dudp", (B, T, m, p)) if want_sens else None
+        nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
+        ws = buf("ws", (max(nbytes, 8) // 8,))
+        rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
+                                              ptr(grad), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+        check(rc, "pdp_oc_pdp_grad_batched")
+        out = dict(loss=loss, grad=grad, x=x, lam=lam, status=status)
+        if want_sens:
+            out.update(dxdp=dxdp, dudp=dudp)
+        return out
+
+    # -- ControlPlanning
+    def cp_integrate(self, pol, p, x0, theta):
+        torch = torch_cuda()
+        x0 = dev(x0).reshape(-1, self.n)
+        B = x0.shape[0]
+        th, tb = self._theta(theta, B, p)
+        T = self._T
+        x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda")
+        u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda")
+        cost = torch.empty((B,), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_cp_integrate_batched(B, T, C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(cost), current_stream_ptr()),
+              "pdp_cp_integrate_batched")
+        return x, u, cost
+
+    def cp_integrate_T(self, pol, p, x0, theta, T):
+        self._T = int(T)
+        return self.cp_integrate(pol, p, x0, theta)
+
+    def cp_auxsys(self, pol, p, x, u, theta, want_cost_grads=True):
+        torch = torch_cuda()
+        x, u = dev(x), dev(u)
+        B, T = u.shape[0], u.shape[1]
+        n, m = self.n, self.m
+        th, tb = self._theta(theta, B, p)
+        e = lambda *s: torch.empty(s, dtype=torch.float64, device="cuda")
+        out = dict(dynF=e(B, T, n, n), dynG=e(B, T, n, m), dUx=e(B, T, m, n), dUe=e(B, T, m, p))
+        if want_cost_grads:
+            out.update(dcx=e(B, T, n), dcu=e(B, T, m), dhx=e(B, n))
+        check(self.lib.pdp_cp_auxsys_batched(B, T, C.byref(pol), p, ptr(x), ptr(u), ptr(th), tb, ptr(out["dynF"]), ptr(out["dynG"]), ptr(out["dUx"]),
+                                             ptr(out["dUe"]), ptr(out.get("dcx")), ptr(out.get("dcu")), ptr(out.get("dhx")), current_stream_ptr()),
+              "pdp_cp_auxsys_batched")
+        return out
+
+    def cp_step(self, pol, p, x0, theta, T, want_traj=False):
+        """ControlPlanning.step: fused kernel for the Lagrange policy; composed from the modular kernels for the MLP policy."""
+        torch = torch_cuda()
+        x0 = dev(x0).reshape(-1, self.n)
+        B = x0.shape[0]
+        th, tb = self._theta(theta, B, p)
+        loss = torch.empty((B,), dtype=torch.float64, device="cuda")
+        grad = torch.empty((B, p), dtype=torch.float64, device="cuda")
+        x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda") if want_traj else None
+        u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda") if want_traj else None
+        rc = self.lib.pdp_cp_step_batched(B, int(T), C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(loss), ptr(grad), ptr(x), ptr(u), current_stream_ptr())
+        if rc == -4 and pol.kind == 1:          # MLP: integrate -> auxsys -> aux integrate (MFMA) -> chain rule
+            x, u, loss = self.cp_integrate_T(pol, p, x0, th, T)
+            aux = self.cp_auxsys(pol, p, x, u, th)
+            X, U = cp_aux_integrate(aux["dynF"], aux["dynG"], aux["dUx"], aux["dUe"])
+            lib = load_core()
+            lib.pdp_cp_grad_contract_batched.restype = C.c_int
+            lib.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
+            check(lib.pdp_cp_grad_contract_batched(B, int(T), self.n, self.m, p, ptr(aux["dcx"]), ptr(aux["dcu"]), ptr(aux["dhx"]), ptr(X), ptr(U),
+                                                   ptr(grad), current_stream_ptr()), "pdp_cp_grad_contract_batched")
+            return (loss, grad, x, u) if want_traj else (loss, grad)
+        check(rc, "pdp_cp_step_batched")
+        return (loss, grad, x, u) if want_traj else (loss, grad)
+
+    # -- SysID
+    def sysid_integrate(self, x0, u, theta):
+        torch = torch_cuda()
+        x0, u = dev(x0).reshape(-1, self.n), dev(u)
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_sysid_integrate_batched(B, T, ptr(x0), ptr(u), ptr(th), tb, ptr(x), current_stream_ptr()), "pdp_sysid_integrate_batched")
+        return x
+
+    def sysid_auxsys(self, x, u, theta):
+        torch = torch_cuda()
+        x, u = dev(x), dev(u)
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        F = torch.empty((B, T, self.n, self.n), dtype=torch.float64, device="cuda")
+        E = torch.empty((B, T, self.n, self.p), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_sysid_auxsys_batched(B, T, ptr(x), ptr(u), ptr(th), tb, ptr(F), ptr(E), current_stream_ptr()), "pdp_sysid_auxsys_batched")
+        return F, E
+
+    def sysid_step(self, u, xobs, theta):
+        torch = torch_cuda()
+        u, xobs = dev(u), dev(xobs)
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        loss = torch.empty((B,), dtype=torch.float64, device="cuda")
+        grad = torch.empty((B, self.p), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_sysid_step_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), current_stream_ptr()), "pdp_sysid_step_batched")
+        return loss, grad
+
+
+def load_model(path):
+    if path not in _models:
+        _models[path] = ModelLib(path)
+    return _models[path]

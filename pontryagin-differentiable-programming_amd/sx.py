@@ -13,6 +13,8 @@ Element order is column-major like CasADi (PDP.py:740 relies on it for the MLP w
 """
 import math
 import numbers
+import struct
+import zlib
 
 import numpy as np
 
@@ -24,7 +26,7 @@ _BINARY = ("add", "sub", "mul", "div", "pow")
 
 
 class Node:
-    __slots__ = ("op", "a", "b", "val", "name", "id")
+    __slots__ = ("op", "a", "b", "val", "name", "id", "h")
 
     def __repr__(self):
         if self.op == "const":
@@ -38,6 +40,7 @@ class Node:
 
 _table = {}
 _next_id = [0]
+_OPCODE = {k: i + 3 for i, k in enumerate(_UNARY + _BINARY)}
 
 
 def _mk(op, a=None, b=None, val=None, name=None):
@@ -53,6 +56,13 @@ def _mk(op, a=None, b=None, val=None, name=None):
             return n
     n = Node()
     n.op, n.a, n.b, n.val, n.name = op, a, b, val, name
+    # structural hash (deterministic across processes and creation orders): canonical operand order for + and *
+    if op == "const":
+        n.h = zlib.crc32(struct.pack("<d", val)) | (1 << 40)
+    elif op == "sym":
+        n.h = zlib.crc32(name.encode()) | (2 << 40)
+    else:
+        n.h = ((a.h * 1000003) ^ ((b.h if b is not None else 7) * 998244353) ^ (_OPCODE[op] << 50)) & 0xFFFFFFFFFFFFFFF
     n.id = _next_id[0]
     _next_id[0] += 1
     if key is not None:
@@ -83,7 +93,7 @@ def add(a, b):
         return sub(a, b.a)
     if a.op == "neg":
         return sub(b, a.a)
-    if a.id > b.id:
+    if (a.h, a.id) > (b.h, b.id):
         a, b = b, a
     return _mk("add", a, b)
 
@@ -131,7 +141,7 @@ def mul(a, b):
         return neg(mul(a.a, b))
     if b.op == "neg":
         return neg(mul(a, b.a))
-    if a.id > b.id:
+    if (a.h, a.id) > (b.h, b.id):
         a, b = b, a
     return _mk("mul", a, b)
 
