@@ -67,9 +67,10 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         if (B <= 0 || T <= 0 || !u || !th || !dx || !du || !x || !lam || !loss || !grad || !ws) return PDP_E_ARG;
         if (!(flags & PDP_OC_GIVEN_TRAJ) && !x0) return PDP_E_ARG;
         if (wsb < oc_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
-        constexpr size_t lds = FusedLayout<Mdl>::LDS_DOUBLES * sizeof(double);
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        const size_t lds = fused_lds_bytes<Mdl>(T);
+        if (lds > 160 * 1024) return PDP_E_SIZE;
+        static size_t attr = 0;
+        if (lds > attr) { (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
         PDP_CLEAR();
         hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
                            dudp, status, (double*)ws);

@@ -67,6 +67,8 @@ __global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, c
     if (b >= B) return;
     double th[Mdl::NP > 0 ? Mdl::NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     double xc[NX], xn[NX], uc[NU];
     double* xb = x + (int64_t)b * (T + 1) * NX;
 #pragma unroll
@@ -75,12 +77,12 @@ __global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, c
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
-        Mdl::dyn(xc, uc, th, xn);
-        if (cost) J += Mdl::path_cost(xc, uc, th);
+        Mdl::dyn(xc, uc, th, pc, xn);
+        if (cost) J += Mdl::path_cost(xc, uc, th, pc);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
     }
-    if (cost) cost[b] = J + Mdl::final_cost(xc, th);
+    if (cost) cost[b] = J + Mdl::final_cost(xc, th, pc);
 }
 
 template <class Mdl>
@@ -91,13 +93,15 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
     if (b >= B) return;
     double th[Mdl::NP > 0 ? Mdl::NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     const double* xb = x + (int64_t)b * (T + 1) * NX;
     const double* ub = u + (int64_t)b * T * NU;
     double* lb = lam + (int64_t)b * T * NX;
     double xc[NX], uc[NU], lc[NX], ln[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xc[i] = xb[T * NX + i];
-    Mdl::dhx(xc, th, lc);                                  // lam[T-1] = h_x(x_T)
+    Mdl::dhx(xc, th, pc, lc);                                  // lam[T-1] = h_x(x_T)
 #pragma unroll
     for (int i = 0; i < NX; ++i) lb[(T - 1) * NX + i] = lc[i];
     for (int k = T - 1; k >= 1; --k) {                     // lam[k-1] = c_x(x_k,u_k) + f_x' lam[k]
@@ -105,7 +109,7 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
         for (int i = 0; i < NX; ++i) xc[i] = xb[k * NX + i];
 #pragma unroll
         for (int i = 0; i < NU; ++i) uc[i] = ub[k * NU + i];
-        Mdl::costate_step(xc, uc, lc, th, ln);
+        Mdl::costate_step(xc, uc, lc, th, pc, ln);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { lc[i] = ln[i]; lb[(k - 1) * NX + i] = ln[i]; }
     }
@@ -129,6 +133,8 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
     const int b = (int)(g / (T + 1)), t = (int)(g % (T + 1));
     double th[NP > 0 ? NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     double xc[NX], uc[NU], lc[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
@@ -138,7 +144,7 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
         s.p[1] = o.hxe ? o.hxe + (int64_t)b * NX * NP : nullptr;
         fill_static<Mdl>(s.p[0], 0, NX * NX, true);
         fill_static<Mdl>(s.p[1], 1, NX * NP, true);
-        Mdl::eval_fin(xc, nullptr, nullptr, th, s);
+        Mdl::eval_fin(xc, nullptr, nullptr, th, pc, s);
         return;
     }
     const int64_t bt = (int64_t)b * T + t;
@@ -163,7 +169,7 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
             if (code < 0) s.p[8][(i % NU) * NX + i / NU] = (code == -1) ? 0.0 : Mdl::path_const(-2 - code);
         }
     }
-    Mdl::eval_path(xc, uc, lc, th, s);
+    Mdl::eval_path(xc, uc, lc, th, pc, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -202,8 +208,18 @@ struct FusedLayout {
     static constexpr int FEXTRA = NX + NU;                                      // x - x_demo, u - u_demo per step
     static constexpr int FSTRIDE = (Mdl::FWD_NVAR + FEXTRA) | 1;
     static constexpr int POOL = CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) > Mdl::FIN_NVAR + 1 ? CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) : Mdl::FIN_NVAR + 1;
-    static constexpr int LDS_DOUBLES = RICCATI_SCRATCH + NC + POOL + NX + 8;
 };
+
+// pool size in doubles: the aux-matrix pool, or the x/u/lambda staging of the rollout phase, whichever is larger
+template <class Mdl>
+__host__ __device__ inline int fused_pool_doubles(int T) {
+    const int stage = (2 * T + 1) * Mdl::NX + T * Mdl::NU;
+    return FusedLayout<Mdl>::POOL > stage ? FusedLayout<Mdl>::POOL : stage;
+}
+template <class Mdl>
+__host__ __device__ inline size_t fused_lds_bytes(int T) {
+    return sizeof(double) * (size_t)(RICCATI_SCRATCH + FusedLayout<Mdl>::NC + fused_pool_doubles<Mdl>(T) + Mdl::NX + 8);
+}
 
 template <class Mdl>
 __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
@@ -218,63 +234,84 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
     double* pool = blk + L::NC;
-    double* dlT = pool + L::POOL;                       // x_T - xdemo_T (NX)
+    double* dlT = pool + fused_pool_doubles<Mdl>(T);    // x_T - xdemo_T (NX)
     const int b = blockIdx.x, lane = threadIdx.x;
     const d4 z = zero4();
     double th[NP];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     double* xb = x + (int64_t)b * (T + 1) * NX;
     double* lb = lam + (int64_t)b * T * NX;
     const double* ub = u + (int64_t)b * T * NU;
     double* gw = ws_gain + (int64_t)b * T * GSZ;
+#ifdef PDP_PHASE_TIMING
+    long long tstamp[8]; int nst = 0;
+#define PDP_STAMP() tstamp[nst++] = __builtin_readcyclecounter()
+    long long fine[16]; for (int i = 0; i < 16; ++i) fine[i] = 0;
+#define PDP_FINE(i, cond) if (cond) fine[i] = __builtin_readcyclecounter()
+#else
+#define PDP_STAMP()
+#define PDP_FINE(i, cond)
+#endif
+    PDP_STAMP();
 
-    // ---------------- phase R/C: trajectory and costates (executed uniformly by all lanes) ------------
+    // ---------------- phase R/C: trajectory and costates (scalar recursions, executed uniformly by all lanes) --------
+    // x and u are staged in the (still unused) LDS pool so that the serial costate loop never waits on HBM/L2.
     if (!(flags & PDP_OC_GIVEN_TRAJ)) {
+        double* xs = pool;                                   // (T+1) x NX
+        double* us = pool + (T + 1) * NX;                    // T x NU
+        double* ls = us + T * NU;                            // T x NX
+        for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
         double xc[NX], xn[NX], uc[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xb[i] = xc[i];
+            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
         }
+        wave_lds_sync();
         for (int t = 0; t < T; ++t) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
-            Mdl::dyn(xc, uc, th, xn);
+            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
+            Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
+                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
             }
         }
         double lc[NX], ln[NX];
-        Mdl::dhx(xc, th, lc);
+        Mdl::dhx(xc, th, pc, lc);                               // lam[T-1] = h_x(x_T)
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) lb[(T - 1) * NX + i] = lc[i];
+            for (int i = 0; i < NX; ++i) ls[(T - 1) * NX + i] = lc[i];
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int k = T - 1; k >= 1; --k) {
+        wave_lds_sync();
+        for (int k = T - 1; k >= 1; --k) {                  // lam[k-1] = c_x(x_k,u_k) + f_x' lam[k]
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xb[k * NX + i];
+            for (int i = 0; i < NX; ++i) xc[i] = xs[k * NX + i];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = ub[k * NU + i];
-            Mdl::costate_step(xc, uc, lc, th, ln);
+            for (int i = 0; i < NU; ++i) uc[i] = us[k * NU + i];
+            Mdl::costate_step(xc, uc, lc, th, pc, ln);
 #pragma unroll
             for (int i = 0; i < NX; ++i) lc[i] = ln[i];
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) lb[(k - 1) * NX + i] = ln[i];
+                for (int i = 0; i < NX; ++i) ls[(k - 1) * NX + i] = ln[i];
             }
         }
-        __threadfence_block();
-        __syncthreads();
+        wave_lds_sync();
+        for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API outputs
+        for (int i = lane; i < T * NX; i += 64) lb[i] = ls[i];
+        __threadfence_block();                               // x / lam are re-read below by other lanes of this wave
+        wave_lds_sync();
     }
+    PDP_STAMP();
 
     // ---------------- terminal condition: P = hxx(x_T), W = hxe(x_T) ----------------------------------
-    bool ok = true, finite = true;
+    bool ok = true;
     d4 P, W2;
     {
         if (lane == 0) blk[0] = 0.0;
@@ -284,16 +321,17 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
 #pragma unroll
             for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
             PackedSink s{pool};
-            Mdl::eval_fin(xT, nullptr, nullptr, th, s);
+            Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
         }
-        __syncthreads();
+        wave_lds_sync();
         Gather gP, gW;
         make_gather(gP, lane, L::NC, 0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1; });
         make_gather(gW, lane, L::NC, 0, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fin_code(1, r * NP + (c - M)) : -1; });
         P = gather_tile(blk, gP, 0);
         W2 = gather_tile(blk, gW, 0);
-        __syncthreads();
+        wave_lds_sync();
     }
+    PDP_STAMP();
 
     // ---------------- backward sweep: chunks of CH time steps ------------------------------------------
     {
@@ -310,7 +348,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const int nchunk = (T + CH - 1) / CH;
         for (int c = nchunk - 1; c >= 0; --c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
-            __syncthreads();
+            wave_lds_sync();
             if (lane < cnt) {                       // lane = time step: evaluate all path matrices at (x_t, u_t, lambda_{t+1})
                 const int t = t0 + lane;
                 double xc[NX], uc[NU], lc[NX];
@@ -319,31 +357,37 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
 #pragma unroll
                 for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
                 PackedSink s{pool + lane * L::BSTRIDE};
-                Mdl::eval_path(xc, uc, lc, th, s);
+                Mdl::eval_path(xc, uc, lc, th, pc, s);
             }
-            __syncthreads();
+            wave_lds_sync();
+            // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk)
+            d4 Ft = gather_tile(blk, gF, cnt - 1), Y2 = gather_tile(blk, gY, cnt - 1), Hxx = gather_tile(blk, gHxx, cnt - 1),
+               HX2 = gather_tile(blk, gHX, cnt - 1), HU2 = gather_tile_r0(blk, gHU, cnt - 1);
             for (int tl = cnt - 1; tl >= 0; --tl) {
-                const int t = t0 + tl;
-                d4 Ft = gather_tile(blk, gF, tl);
-                d4 Y2 = gather_tile(blk, gY, tl);
-                d4 Hxx = gather_tile(blk, gHxx, tl);
-                d4 HX2 = gather_tile(blk, gHX, tl);
-                d4 HU2 = gather_tile_r0(blk, gHU, tl);
+                const int t = t0 + tl, tn = tl > 0 ? tl - 1 : 0;
+                PDP_FINE(0, t == 20);
+                d4 Ft_n = gather_tile(blk, gF, tn), Y2_n = gather_tile(blk, gY, tn), Hxx_n = gather_tile(blk, gHxx, tn),
+                   HX2_n = gather_tile(blk, gHX, tn), HU2_n = gather_tile_r0(blk, gHU, tn);
                 RiccatiGains g;
                 d4 P_old;
+                PDP_FINE(1, t == 20);
                 ok = riccati_backward<M>(P, W2, Ft, Y2, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
+                PDP_FINE(2, t == 20);
                 store_dense(gw + t * GSZ, NX, NU, NU, 0, 0, lane, g.KT);
                 store_dense(gw + t * GSZ + NX * NU, NU, NP, NP, 0, M, lane, g.IK);
-                finite = finite && tile_finite(P) && tile_finite(W2);
+                Ft = Ft_n; Y2 = Y2_n; Hxx = Hxx_n; HX2 = HX2_n; HU2 = HU2_n;
+                PDP_FINE(3, t == 20);
+                PDP_FINE(4, t == 19);
             }
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    bool finite = tile_finite(P) && tile_finite(W2);
+    PDP_STAMP();
 
     // ---------------- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, loss and gradient -----------
     double acc = 0.0, lsum = 0.0;
     {
+        wave_lds_sync();
         if (lane < Mdl::FWD_NCONST) blk[1 + lane] = Mdl::fwd_const(lane);
         constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
         Gather gFT, gGT, gE, gDX, gDU;
@@ -355,10 +399,13 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
+        // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
+        d4 KTn = -load_dense<false>(gw, NX, NU, NU, 0, 0, lane);
+        d4 kn = -load_dense<false>(gw + NX * NU, NU, NP, NP, 0, M, lane);
         const int nchunk = (T + CH - 1) / CH;
         for (int c = 0; c < nchunk; ++c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
-            __syncthreads();
+            wave_lds_sync();
             if (lane < cnt) {
                 const int t = t0 + lane;
                 double xc[NX], uc[NU];
@@ -368,34 +415,40 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
 #pragma unroll
                 for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; double d = uc[i] - dub[t * NU + i]; row[DLU + i] = d; lsum += d * d; }
                 PackedSink s{row};
-                Mdl::eval_fwd(xc, uc, nullptr, th, s);
+                Mdl::eval_fwd(xc, uc, nullptr, th, pc, s);
             }
-            __syncthreads();
+            wave_lds_sync();
             for (int tl = 0; tl < cnt; ++tl) {
-                const int t = t0 + tl;
+                const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
+                PDP_FINE(8, t == 20);
+                d4 KTn_n = -load_dense<false>(gw + tnx * GSZ, NX, NU, NU, 0, 0, lane);
+                d4 kn_n = -load_dense<false>(gw + tnx * GSZ + NX * NU, NU, NP, NP, 0, M, lane);
                 d4 FT = gather_tile(blk, gFT, tl);
                 d4 GT = gather_tile_r0(blk, gGT, tl);
                 d4 E2 = gather_tile(blk, gE, tl);
                 d4 DX = gather_tile(blk, gDX, tl);          // (x_t - xd_t)[row] broadcast over columns
                 d4 DU = gather_tile_r0(blk, gDU, tl);
-                d4 KTn = -load_dense<false>(gw + t * GSZ, NX, NU, NU, 0, 0, lane);
-                d4 kn = -load_dense<false>(gw + t * GSZ + NX * NU, NU, NP, NP, 0, M, lane);
                 d4 U2, Xn;
+                PDP_FINE(9, t == 20);
                 riccati_forward(KTn, kn, FT, GT, E2, X2, U2, Xn);
+                PDP_FINE(10, t == 20);
                 acc += DX[0] * X2[0] + DX[1] * X2[1] + DX[2] * X2[2] + DX[3] * X2[3] + DU[0] * U2[0];
                 if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, X2);
                 if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
                 X2 = Xn;
-                finite = finite && tile_finite(Xn);
+                KTn = KTn_n; kn = kn_n;
+                PDP_FINE(11, t == 20);
+                PDP_FINE(12, t == 21);
             }
         }
         // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
-        __syncthreads();
+        wave_lds_sync();
         if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
         if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + T) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+        finite = finite && tile_finite(X2);
     }
     acc = sum_over_rowgroups(acc);
     lsum = wave_sum(lsum);
@@ -405,8 +458,12 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
     if (!ok) st |= PDP_STATUS_PIVOT;
     if (lane == 0 && status) status[b] = st;
+#ifdef PDP_PHASE_TIMING   // debug builds (probes/phase_timing.py): cycle stamps of blocks 0 and 700 behind loss[B]
+    PDP_STAMP();
+    if (lane == 0 && (b == 0 || b == 700)) { long long* o = (long long*)(loss + B) + (b ? 8 : 0); for (int i = 0; i < nst; ++i) o[i] = tstamp[i]; }
+    if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 16; for (int i = 0; i < 16; ++i) o[i] = fine[i]; }
+#endif
 }
-
 
 // ------------------------------------------------------------------------------------------------------
 // ControlPlanning (PDP_KIND_CP)
@@ -418,20 +475,22 @@ __global__ void cp_integrate_kernel(int B, int T, pdp_policy pol, int p, const d
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* th = theta + (int64_t)b * tb;
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
     double xc[NX], xn[NX], uc[NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; if (x) x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
     double J = 0.0;
     for (int t = 0; t < T; ++t) {
         policy_eval<NX, NU>(pol, t, xc, th, uc);
-        Mdl::dyn(xc, uc, nullptr, xn);
-        J += Mdl::path_cost(xc, uc, nullptr);
+        Mdl::dyn(xc, uc, nullptr, pc, xn);
+        J += Mdl::path_cost(xc, uc, nullptr, pc);
 #pragma unroll
         for (int i = 0; i < NU; ++i) if (u) u[((int64_t)b * T + t) * NU + i] = uc[i];
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; if (x) x[((int64_t)b * (T + 1) + t + 1) * NX + i] = xn[i]; }
     }
-    if (cost) cost[b] = J + Mdl::final_cost(xc, nullptr);
+    if (cost) cost[b] = J + Mdl::final_cost(xc, nullptr, pc);
 }
 
 template <class Mdl>
@@ -452,11 +511,13 @@ __global__ void cp_auxsys_kernel(int B, int T, pdp_policy pol, int p, const doub
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (int64_t)B * (T + 1)) return;
     const int b = (int)(g / (T + 1)), t = (int)(g % (T + 1));
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
     double xc[NX], uc[NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
     if (t == T) {
-        if (dhx) { double h[NX]; Mdl::dhx(xc, nullptr, h);
+        if (dhx) { double h[NX]; Mdl::dhx(xc, nullptr, pc, h);
 #pragma unroll
             for (int i = 0; i < NX; ++i) dhx[(int64_t)b * NX + i] = h[i]; }
         return;
@@ -470,7 +531,7 @@ __global__ void cp_auxsys_kernel(int B, int T, pdp_policy pol, int p, const doub
     s.p[2] = dcx ? dcx + bt * NX : nullptr;
     s.p[3] = dcu ? dcu + bt * NU : nullptr;
     for (int mat = 0; mat < 4; ++mat) fill_static_path<Mdl>(s.p[mat], mat, Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat]);
-    Mdl::eval_path(xc, uc, nullptr, nullptr, s);
+    Mdl::eval_path(xc, uc, nullptr, nullptr, pc, s);
     if (dUx && dUe) policy_jacobians<NX, NU>(pol, p, t, xc, theta + (int64_t)b * tb, dUx + bt * NU * NX, dUe + bt * NU * p);
 }
 
@@ -491,6 +552,8 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     double* hx = basis + T * pol.n_pivots;   // NX
     const int b = blockIdx.x, lane = threadIdx.x, np = pol.n_pivots;
     const double* th = theta + (int64_t)b * tb;
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
     const d4 z = zero4();
     for (int t = lane; t < T; t += 64)
         for (int i = 0; i < np; ++i) basis[t * np + i] = lagrange_basis(pol, i, (double)t);
@@ -515,8 +578,8 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 #pragma unroll
                 for (int j = 0; j < NU; ++j) uc[j] += bi * th[i * NU + j];
             }
-            Mdl::dyn(xc, uc, nullptr, xn);
-            J += Mdl::path_cost(xc, uc, nullptr);
+            Mdl::dyn(xc, uc, nullptr, pc, xn);
+            J += Mdl::path_cost(xc, uc, nullptr, pc);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
             if (lane == 0) {
@@ -526,9 +589,9 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
                 for (int j = 0; j < NU; ++j) us[t * NU + j] = uc[j];
             }
         }
-        J += Mdl::final_cost(xc, nullptr);
+        J += Mdl::final_cost(xc, nullptr, pc);
         double h[NX];
-        Mdl::dhx(xc, nullptr, h);
+        Mdl::dhx(xc, nullptr, pc, h);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) hx[i] = h[i];
@@ -560,7 +623,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 #pragma unroll
             for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
             PackedSink s{pool + lane * STRIDE};
-            Mdl::eval_path(xc, uc, nullptr, nullptr, s);
+            Mdl::eval_path(xc, uc, nullptr, nullptr, pc, s);
         }
         __syncthreads();
         for (int tl = 0; tl < cnt; ++tl) {
@@ -601,13 +664,15 @@ __global__ void sysid_integrate_kernel(int B, int T, const double* __restrict__ 
     if (b >= B) return;
     double th[Mdl::NP > 0 ? Mdl::NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     double xc[NX], xn[NX], uc[NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
-        Mdl::dyn(xc, uc, th, xn);
+        Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; x[((int64_t)b * (T + 1) + t + 1) * NX + i] = xn[i]; }
     }
@@ -622,6 +687,8 @@ __global__ void sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, 
     const int b = (int)(g / T);
     double th[NP > 0 ? NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     const int t = (int)(g % T);
     double xc[NX], uc[NU];
 #pragma unroll
@@ -634,7 +701,7 @@ __global__ void sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, 
     s.p[2] = s.p[3] = nullptr;
     fill_static_path<Mdl>(s.p[0], 0, NX * NX);
     fill_static_path<Mdl>(s.p[1], 1, NX * NP);
-    Mdl::eval_path(xc, uc, nullptr, th, s);
+    Mdl::eval_path(xc, uc, nullptr, th, pc, s);
 }
 
 // Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
@@ -652,6 +719,8 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     const d4 z = zero4();
     double th[NP];
     load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
     const double* ub = u + (int64_t)b * T * NU;
     const double* ob = xobs + (int64_t)b * (T + 1) * NX;
     if (lane == 0) blk[0] = 0.0;
@@ -667,7 +736,7 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
         for (int t = 0; t < T; ++t) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
-            Mdl::dyn(xc, uc, th, xn);
+            Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
             if (lane == 0) {
@@ -700,7 +769,7 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
 #pragma unroll
             for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
             PackedSink s{row};
-            Mdl::eval_path(xc, uc, nullptr, th, s);
+            Mdl::eval_path(xc, uc, nullptr, th, pc, s);
         }
         __syncthreads();
         for (int tl = 0; tl < cnt; ++tl) {

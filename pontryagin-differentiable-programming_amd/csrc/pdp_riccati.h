@@ -22,7 +22,7 @@
 
 namespace pdp {
 
-constexpr int RICCATI_SCRATCH = 256 + 272 + 272;   // Q2 / Z | FY (stride 17) | P (stride 17)
+constexpr int RICCATI_SCRATCH = 272 + 272;   // FY (stride 17) | P (stride 17)
 
 PDP_DEV void tile_to_lds17(double* s, const d4 v, int lane) {
 #pragma unroll
@@ -47,58 +47,52 @@ struct RiccatiGains {
 // reference's quadrotor demo, T=50: 3.4e-10 relative error in X vs a 50-digit solution, against 1e-15 once P
 // is re-symmetrised each step), so every step ends with P <- (P + P^T)/2 through a padded LDS transpose.
 //
-// scratch: LDS, RICCATI_SCRATCH doubles, private to the wave.  Returns false when the m x m pivot test fails.
+// scratch: LDS, RICCATI_SCRATCH doubles, private to the wave (one wave per workgroup).  Returns false when the
+// m x m solve meets a vanishing / non-finite pivot.  No barrier and no global-memory wait inside.
 template <int M>
 PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Hxx, const d4 HX2, const d4 HU2,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
     d4 PF = mma_tn(P, Ft, z);        // P F        (P symmetric)
     d4 PY2 = mma_tn(P, Y2, W0);      // [P G | P E + W]
-    d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
     d4 FY = mma_tn(Ft, PY2, HX2);    // [Hxu + F'PG | Hxe + F'(PE+W)] = [Qux' | Wn]
     d4 Q2 = mma_tn(Y2, PY2, HU2);    // rows<m: [Quu | Que]
+    d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
     P_old_out = P;
-    // ---- m x m inverse: broadcast Quu through LDS, every lane inverts it (uniform, registers)
-    __syncthreads();
-    tile_to_lds(scratch, Q2, lane);
-    tile_to_lds17(scratch + 256, FY, lane);
-    __syncthreads();
+    // ---- Qux (m x n) = transpose of the first m columns of FY, through LDS (padded stride)
+    tile_to_lds17(scratch, FY, lane);
+    // ---- m x m system: Quu broadcast with v_readlane (element (i,j) lives in lane 16 i + j, register 0), inverted uniformly
     double a[M * M], ai[M * M];
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) a[i * M + j] = scratch[i * 16 + j];
-    bool ok = inverse_small<M>(a, ai);
-    // Qux tile (m x n): transpose of the first m columns of FY
-    d4 Qux = z, Z = z;
+        for (int j = 0; j < M; ++j) a[i * M + j] = readlane_f64(Q2[0], 16 * i + j);
+    bool ok = inverse_small_fast<M>(a, ai);
+    const int row = lane >> 4, col = lane & 15;
+    d4 Z = z;                                   // Z = Quu^-T in the top-left corner
     {
-        int row = lane >> 4, col = lane & 15;          // register 0 holds rows 0..3
-        if (row < M) Qux[0] = scratch[256 + col * 17 + row];
-    }
-    __syncthreads();
-    if (lane == 0) {
+        double zz = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int j = 0; j < M; ++j) scratch[i * 16 + j] = ai[j * M + i];   // Z = Quu^-T
+            for (int j = 0; j < M; ++j) zz = (row == i && col == j) ? ai[j * M + i] : zz;
+        Z[0] = zz;
     }
-    __syncthreads();
-    {
-        int row = lane >> 4, col = lane & 15;
-        if (row < M && col < M) Z[0] = scratch[row * 16 + col];
-    }
+    wave_lds_sync();
+    d4 Qux = z;
+    if (row < M) Qux[0] = scratch[col * 17 + row];
     d4 K = mma_tn_r0(Z, Qux, z);          // Quu^-1 Qux            (m x n)
     g.IK = mma_tn_r0(Z, Q2, z);           // Quu^-1 [Quu | Que] = [I | k]
     g.KT = mma_tn_r0(Qux, Z, z);          // Qux' Quu^-T = K'      (n x m)
     g.Z = Z;
     g.Qux = Qux;
     P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
-    tile_to_lds17(scratch + 528, P, lane);
-    __syncthreads();
-    P = 0.5 * (P + tile_from_lds17_transposed(scratch + 528, lane));
+    tile_to_lds17(scratch + 272, P, lane);
     d4 Wn = mms_tn_r0(Qux, g.IK, FY);     // [Qux' - Qux' I | Wn - Qux' k]
     W0 = keep_cols(Wn, M, M + p0, lane);
     g.IK = keep_cols(g.IK, M, M + p0, lane);
+    wave_lds_sync();
+    P = 0.5 * (P + tile_from_lds17_transposed(scratch + 272, lane));
     return ok;
 }
 

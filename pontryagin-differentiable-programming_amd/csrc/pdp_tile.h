@@ -83,6 +83,19 @@ PDP_DEV bool tile_finite(const d4 v) {
     return ok;
 }
 
+// Cross-lane hand-off through LDS inside ONE wavefront (all kernels here run one wave per workgroup): the LDS unit
+// executes a wave's DS instructions in issue order, so a later ds_read sees an earlier ds_write of any lane; what is
+// needed is (a) the compiler must not reorder the accesses (it reasons per thread) and (b) outstanding DS results are
+// waited for.  No s_barrier, and - unlike __syncthreads() - no vmcnt(0): pending global stores keep draining.
+PDP_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// broadcast lane `src`'s value to the whole wave (2 x v_readlane_b32, no LDS)
+PDP_DEV double readlane_f64(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // tile <-> 16x16 row-major LDS scratch (conflict-free: consecutive lanes, consecutive addresses)
 PDP_DEV void tile_to_lds(double* s, const d4 v, int lane) {
 #pragma unroll
@@ -131,6 +144,51 @@ PDP_DEV bool inverse_small(const double* a_in, double* inv) {
 #pragma unroll
         for (int j = 0; j < M; ++j) inv[i * M + j] = b[i][j];
     return ok;
+}
+
+// Inverse of an M x M matrix (M <= 4), uniform over the wave.  Fast path: cofactor (adjugate) formulas with ONE
+// division (fp64 division costs ~74 cycles on gfx950; Gauss-Jordan needs M of them in sequence); guarded by the
+// determinant test |det| > 1e-10 * max|a|^M, otherwise the pivoted Gauss-Jordan above takes over (uniform branch).
+template <int M>
+PDP_DEV bool inverse_small_fast(const double* a, double* inv) {
+    double amax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) amax = fmax(amax, fabs(a[i]));
+    double det, c[M * M];
+    if constexpr (M == 1) {
+        det = a[0]; c[0] = 1.0;
+    } else if constexpr (M == 2) {
+        det = a[0] * a[3] - a[1] * a[2];
+        c[0] = a[3]; c[1] = -a[1]; c[2] = -a[2]; c[3] = a[0];
+    } else if constexpr (M == 3) {
+        c[0] = a[4] * a[8] - a[5] * a[7]; c[1] = a[2] * a[7] - a[1] * a[8]; c[2] = a[1] * a[5] - a[2] * a[4];
+        c[3] = a[5] * a[6] - a[3] * a[8]; c[4] = a[0] * a[8] - a[2] * a[6]; c[5] = a[2] * a[3] - a[0] * a[5];
+        c[6] = a[3] * a[7] - a[4] * a[6]; c[7] = a[1] * a[6] - a[0] * a[7]; c[8] = a[0] * a[4] - a[1] * a[3];
+        det = a[0] * c[0] + a[1] * c[3] + a[2] * c[6];
+    } else {
+        // 2x2 minors of rows (0,1) and rows (2,3)
+        const double s0 = a[0] * a[5] - a[4] * a[1], s1 = a[0] * a[6] - a[4] * a[2], s2 = a[0] * a[7] - a[4] * a[3];
+        const double s3 = a[1] * a[6] - a[5] * a[2], s4 = a[1] * a[7] - a[5] * a[3], s5 = a[2] * a[7] - a[6] * a[3];
+        const double c5 = a[10] * a[15] - a[14] * a[11], c4 = a[9] * a[15] - a[13] * a[11], c3 = a[9] * a[14] - a[13] * a[10];
+        const double c2 = a[8] * a[15] - a[12] * a[11], c1 = a[8] * a[14] - a[12] * a[10], c0 = a[8] * a[13] - a[12] * a[9];
+        det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+        c[0] = a[5] * c5 - a[6] * c4 + a[7] * c3;   c[1] = -a[1] * c5 + a[2] * c4 - a[3] * c3;
+        c[2] = a[13] * s5 - a[14] * s4 + a[15] * s3; c[3] = -a[9] * s5 + a[10] * s4 - a[11] * s3;
+        c[4] = -a[4] * c5 + a[6] * c2 - a[7] * c1;  c[5] = a[0] * c5 - a[2] * c2 + a[3] * c1;
+        c[6] = -a[12] * s5 + a[14] * s2 - a[15] * s1; c[7] = a[8] * s5 - a[10] * s2 + a[11] * s1;
+        c[8] = a[4] * c4 - a[5] * c2 + a[7] * c0;   c[9] = -a[0] * c4 + a[1] * c2 - a[3] * c0;
+        c[10] = a[12] * s4 - a[13] * s2 + a[15] * s0; c[11] = -a[8] * s4 + a[9] * s2 - a[11] * s0;
+        c[12] = -a[4] * c3 + a[5] * c1 - a[6] * c0; c[13] = a[0] * c3 - a[1] * c1 + a[2] * c0;
+        c[14] = -a[12] * s3 + a[13] * s1 - a[14] * s0; c[15] = a[8] * s3 - a[9] * s1 + a[10] * s0;
+    }
+    double lim = 1e-10;
+#pragma unroll
+    for (int i = 0; i < M; ++i) lim *= amax;
+    if (!(fabs(det) > lim) || !(fabs(det) <= 1.7e308)) return inverse_small<M>(a, inv);   // ill-conditioned / singular: pivoted path
+    const double id = 1.0 / det;
+#pragma unroll
+    for (int i = 0; i < M * M; ++i) inv[i] = c[i] * id;
+    return true;
 }
 
 // wave-level sum over the 4 lane groups that share a column (lanes l, l+16, l+32, l+48)

@@ -218,9 +218,11 @@ def as_node(v):
 # ------------------------------------------------------------------------------------------------
 # graph utilities
 # ------------------------------------------------------------------------------------------------
-def topo_order(outputs):
-    """Nodes reachable from `outputs` in dependency order (iterative DFS)."""
+def topo_order(outputs, stop=None):
+    """Nodes reachable from `outputs` in dependency order (iterative DFS); nodes whose id is in `stop` are listed
+    but not descended into."""
     seen, order = set(), []
+    stop = stop or ()
     for root in outputs:
         if root.id in seen:
             continue
@@ -232,6 +234,8 @@ def topo_order(outputs):
                     continue
                 seen.add(n.id)
                 stack.append((n, 1))
+                if n.id in stop:
+                    continue
                 if n.b is not None and n.b.id not in seen:
                     stack.append((n.b, 0))
                 if n.a is not None and n.a.id not in seen:
@@ -642,19 +646,24 @@ def _cnum(v):
     return r
 
 
-def emit(outputs, inputs, lang="c", tmp="w", result=lambda k, e: "out[%d] = %s;" % (k, e), skip_zero=False, indent="    "):
+def emit(outputs, inputs, lang="c", tmp="w", result=lambda k, e: "out[%d] = %s;" % (k, e), skip_zero=False, indent="    ", replace=None):
     """Straight-line code computing `outputs` (list of Nodes) from `inputs` ({sym node id: source string}).
     lang: 'c' (C / HIP device code, doubles) or 'py' (Python; functions prefixed by `_m.`).
+    replace: {node id: source string} - sub-expressions available precomputed (not re-emitted, not descended into).
     Returns list of source lines."""
     lines, name = [], {}
     use = {}
-    order = topo_order(outputs)
+    replace = replace or {}
+    order = topo_order(outputs, stop=replace)
     for n in order:
         for ch in (n.a, n.b):
             if ch is not None:
                 use[ch.id] = use.get(ch.id, 0) + 1
     k = 0
     for n in order:
+        if n.id in replace:
+            name[n.id] = replace[n.id]
+            continue
         if n.op == "const":
             name[n.id] = _cnum(n.val) if n.val >= 0 else "(%s)" % _cnum(n.val)
             continue
