@@ -1,0 +1,108 @@
+"""CPU (no GPU needed): the C-ABI libraries load and export every symbol include/pdp_hip.h declares; code generation is
+deterministic; the symbolic engine's derivatives agree with sympy; argument validation happens before any launch."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pdp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdp_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from pdp_amd import codegen, zoo
+    return codegen, zoo
+
+
+def test_every_declared_symbol_is_exported(built):
+    codegen, zoo = built
+    from pdp_amd import runtime
+    syms = _declared_symbols()
+    assert set(runtime.CORE_SYMBOLS + runtime.MODEL_SYMBOLS + ["pdp_cp_grad_contract_batched"]) == set(syms)
+    core = ctypes.CDLL(os.path.join(ROOT, "pontryagin-differentiable-programming_amd", "lib", "libpdp_hip.so"))
+    core_syms = [s for s in syms if s in runtime.CORE_SYMBOLS or s == "pdp_cp_grad_contract_batched"]
+    for s in core_syms:
+        assert hasattr(core, s), s
+    core.pdp_hip_version.restype = ctypes.c_char_p
+    assert b"gfx950" in core.pdp_hip_version()
+    lib_path, info = codegen.build_problem(zoo.make_problem("cartpole", "irl"))
+    mdl = ctypes.CDLL(lib_path)
+    for s in runtime.MODEL_SYMBOLS:
+        assert hasattr(mdl, s), s
+
+
+def test_model_info_and_argument_validation_without_gpu(built):
+    codegen, zoo = built
+    from pdp_amd import runtime
+    m = runtime.load_model(codegen.build_problem(zoo.make_problem("quadrotor", "irl"))[0])
+    assert (m.kind, m.n, m.m, m.p) == (0, 13, 4, 9) and m.name.startswith("quadrotor_oc_")
+    # bad arguments are rejected by the C entry points before anything is launched (no GPU needed)
+    assert m.lib.pdp_oc_rollout_batched(0, 10, None, None, None, 0, None, None, None) == -1
+    assert m.lib.pdp_oc_pdp_grad_batched(4, 10, 0, None, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert m.lib.pdp_sysid_step_batched(4, 10, None, None, None, 0, None, None, None) == -4        # wrong model kind
+    core = runtime.load_core()
+    assert core.pdp_lqr_workspace_bytes(2, 5, 3, 1, 4, 1) == 2 * 5 * (3 * 1 + 1 * 4 + 3 * 3 + 3 * 4) * 8
+    pr = runtime.PdpLqrProblem()
+    pr.B, pr.T, pr.n, pr.m, pr.p = 1, 5, 20, 1, 1
+    assert core.pdp_lqr_solve_batched(ctypes.byref(pr), None, None, None, None, None, 0, None) == -1
+
+
+def test_codegen_is_deterministic_and_cached(built):
+    codegen, zoo = built
+    a = codegen.generate(zoo.make_problem("rocket", "irl"))
+    b = codegen.generate(zoo.make_problem("rocket", "irl"))
+    assert a[0] == b[0] and a[1]["name"] == b[1]["name"]
+    assert os.path.exists(codegen.lib_path(a[1]["name"]))
+
+
+@pytest.mark.parametrize("system", ["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
+def test_symbolic_engine_derivatives_match_sympy(system):
+    """the product's SX engine (used for code generation) against the independent sympy models of the oracle"""
+    from oracle import models, pdp_oracle as po
+    from pdp_amd import sx, zoo
+    env, dt = zoo.make_env(system, "irl")
+    th = sx.vertcat(env.dyn_auxvar, env.cost_auxvar)
+    dyn = env.X + dt * env.f
+    lam = sx.SX.sym("lam", env.X.numel())
+    H = env.path_cost + sx.dot(dyn, lam)
+    dHx = sx.jacobian(H, env.X).T
+    fns = sx.Function("f", [env.X, env.U, lam, th], [dyn, sx.jacobian(dyn, env.X), sx.jacobian(dyn, th), sx.jacobian(dHx, env.X), sx.jacobian(dHx, th),
+                                                      sx.jacobian(sx.jacobian(H, env.U).T, th), sx.jacobian(sx.jacobian(env.final_cost, env.X).T, th)])
+    st = models.IRL_SETUP[system]
+    oc = po.make_oc(models.REGISTRY[system](**st["kwargs"]), st["dt"])
+    rng = np.random.default_rng(4)
+    x, u, l = rng.standard_normal(oc.n), rng.standard_normal(oc.m), rng.standard_normal(oc.n)
+    e = np.abs(rng.standard_normal(oc.p)) + 0.5
+    got = [g.full() for g in fns(x, u, l, e)]
+    ref = [np.asarray(oc.dyn_fn(x, u, e)).reshape(-1, 1), oc._m(oc.dfx_fn(x, u, e), oc.n, oc.n), oc._m(oc.dfe_fn(x, u, e), oc.n, oc.p),
+           oc._m(oc.ddHxx_fn(x, u, l, e), oc.n, oc.n), oc._m(oc.ddHxe_fn(x, u, l, e), oc.n, oc.p), oc._m(oc.ddHue_fn(x, u, l, e), oc.m, oc.p),
+           oc._m(oc.ddhxe_fn(x, e), oc.n, oc.p)]
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+
+
+def test_sx_casadi_semantics():
+    from pdp_amd import sx
+    A = sx.SX.sym("A", 2, 3)
+    v = A.reshape((-1, 1))
+    assert v.shape == (6, 1) and v[1].data[0] is A[1, 0].data[0]          # column-major vec (PDP.py:740 relies on it)
+    x = sx.SX.sym("x", 3)
+    y = np.array([1.0, 2.0, 3.0]) - x                                        # numpy on the left defers to SX
+    assert isinstance(y, sx.SX) and y.shape == (3, 1)
+    f = sx.Function("f", [x], [sx.mtimes(A.T, sx.SX.sym("z", 2)) if False else sx.dot(x, x) * x])
+    out = f([1.0, 2.0, 2.0]).full()
+    assert np.allclose(out.flatten(), 9.0 * np.array([1.0, 2.0, 2.0]))
+    J = sx.jacobian(sx.tanh(x[0] * x[1]) + x[2] ** 2, x)
+    Jf = sx.Function("J", [x], [J])
+    assert np.allclose(Jf([0.3, -0.2, 1.5]).full(), [[-0.2 * (1 - np.tanh(-0.06) ** 2), 0.3 * (1 - np.tanh(-0.06) ** 2), 3.0]])
+    assert float(sx.inv(sx.SX(np.array([[2.0, 0.0], [0.0, 4.0]])))[1, 1]) == 0.25
