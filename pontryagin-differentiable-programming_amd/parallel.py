@@ -1,0 +1,61 @@
+"""Multi-GPU data parallelism of the PDP iteration: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over
+xGMI on ROCm, "gloo" on CPU for tests).  Trajectories are independent: the batch is cut into
+contiguous shards, every rank runs the same kernels on its shard with a replicated theta, and ONE all-gather of the
+per-sample gradients and losses `[B/G, p+1]` per iteration gives every rank the full `[B, p+1]`; the batch mean the
+reference takes (PDP/PDP.py:1293-1294, cartpole_PDP.py:77-78) is then a local reduction.  Message size at C3: 1024 x 10 x 8 B
+= 80 KB per rank - latency-bound over xGMI, so it is issued as a single collective, never per parameter."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_total, world, rank):
+    """contiguous block partition; the first (n_total % world) ranks get one extra trajectory"""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard(x, world=None, rank=None, dim=0):
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    lo, hi = shard_bounds(x.shape[dim], world, rank)
+    return x.narrow(dim, lo, hi - lo) if hasattr(x, "narrow") else x[lo:hi]
+
+
+def gather_loss_grad(loss, grad, n_total=None):
+    """all-gather per-sample (loss [b], grad [b,p]) of every rank -> (loss [B], grad [B,p]) on every rank.
+    Shards may differ by one trajectory (ragged): they are padded to the largest shard for the collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return loss, grad
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b, p = grad.shape
+    if n_total is None:
+        sizes = torch.tensor([b], device=grad.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        counts = [int(s.item()) for s in all_sizes]
+    else:
+        counts = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
+    bmax = max(counts)
+    packed = torch.zeros((bmax, p + 1), dtype=grad.dtype, device=grad.device)
+    packed[:b, :p] = grad
+    packed[:b, p] = loss
+    out = torch.empty((world * bmax, p + 1), dtype=grad.dtype, device=grad.device)
+    dist.all_gather_into_tensor(out, packed)
+    out = out.view(world, bmax, p + 1)
+    rows = torch.cat([out[r, :counts[r]] for r in range(world)], dim=0)
+    return rows[:, p].contiguous(), rows[:, :p].contiguous()
+
+
+def mean_loss_grad(loss, grad, n_total=None):
+    """the reference's batch mean of (loss, gradient) over ALL trajectories of all ranks"""
+    L, G = gather_loss_grad(loss, grad, n_total)
+    return L.mean(), G.mean(dim=0)
+
+
+def pdp_iteration(unit, shard_inputs, n_total=None):
+    """One data-parallel PDP iteration: `unit(**shard_inputs)` must return a dict with per-sample 'loss' [b] and 'grad' [b,p]
+    computed on this rank's shard (e.g. OCSys.pdp_grad_batch, or (loss, grad) from ControlPlanning.step_batch / SysID.step_batch)."""
+    out = unit(**shard_inputs)
+    loss, grad = (out["loss"], out["grad"]) if isinstance(out, dict) else out
+    return mean_loss_grad(loss, grad, n_total)
