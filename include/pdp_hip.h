@@ -124,6 +124,14 @@ void pdp_model_get_info(pdp_model_info* info);
 int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, const double* theta, int theta_bstride,
                            double* x, double* cost, void* stream);
 
+/* Closed-loop rollout used by the batched OC solver that stands where OCSys.ocSolver calls IPOPT (PDP.py:121-220):
+ *   u_t = ubar_t - alpha_b k_t - K_t (x_t - xbar_t),  x_{t+1} = f(x_t,u_t,theta),  cost = sum c + h
+ * with the feedback gains in the layout pdp_lqr_solve_batched leaves in its workspace for p = 1:
+ * gains[b][t] = { K^T [n][m], k [m] }.  x0 [B][n], ubar [B][T][m], xbar [B][T+1][n], alpha [B] -> x [B][T+1][n], u [B][T][m], cost [B]. */
+int pdp_oc_rollout_feedback_batched(int B, int T, const double* x0, const double* ubar, const double* xbar, const double* gains,
+                                    const double* alpha, const double* theta, int theta_bstride, double* x, double* u, double* cost,
+                                    void* stream);
+
 /* PMP costate recursion, ocSolver costate_option=1 (PDP.py:199-209): lam[T-1] = h_x(x_T),
  * lam[k-1] = c_x(x_k,u_k) + f_x(x_k,u_k)^T lam[k].  lam [B][T][n] with lam[t] = lambda_{t+1}. */
 int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const double* theta, int theta_bstride,
@@ -134,6 +142,8 @@ int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const
  * Any output pointer may be NULL (skipped). */
 typedef struct pdp_oc_auxsys {
     double *dynF, *dynG, *dynE, *Hxx, *Hxu, *Hxe, *Hux, *Huu, *Hue, *hxx, *hxe;
+    double* dHu; /* optional extra (not part of the reference dict): dH/du [B][T][m] = c_u + f_u' lambda_{t+1}, the PMP
+                    stationarity residual (dHu_fn, PDP.py:245-246) used by the batched OC solver */
 } pdp_oc_auxsys;
 int pdp_oc_auxsys_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta,
                           int theta_bstride, const pdp_oc_auxsys* out, void* stream);

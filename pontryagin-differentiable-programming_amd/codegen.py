@@ -272,6 +272,7 @@ def generate(problem):
         funcs.append(("final_cost", ["x", "th"], R(h).data, True))
         funcs.append(("costate_step", ["x", "u", "lam", "th"], R(dHx).data, False))     # c_x + f_x' lam  (PDP.py:205-209)
         funcs.append(("dhx", ["x", "th"], R(dhx).data, False))
+        funcs.append(("dHu", ["x", "u", "lam", "th"], R(dHu).data, False))               # c_u + f_u' lam  (PMP stationarity residual)
         mats = {"F": fx, "G": fu, "E": fe, "Hxx": sx.jacobian(dHx, x), "Hxu": sx.jacobian(dHx, u), "Hxe": sx.jacobian(dHx, th),
                 "Huu": sx.jacobian(dHu, u), "Hue": sx.jacobian(dHu, th), "hxx": sx.jacobian(dhx, x), "hxe": sx.jacobian(dhx, th)}
         mats = {k: R(v) for k, v in mats.items()}

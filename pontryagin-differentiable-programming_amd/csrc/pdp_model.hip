@@ -42,6 +42,16 @@ int oc_rollout(int B, int T, const double* x0, const double* u, const double* th
     } else { return PDP_E_MODE; }
 }
 template <class Mdl>
+int oc_rollout_fb(int B, int T, const double* x0, const double* ubar, const double* xbar, const double* gains, const double* alpha, const double* th,
+                  int tb, double* x, double* u, double* cost, void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        if (B <= 0 || T <= 0 || !x0 || !ubar || !xbar || !gains || !alpha || !th || !x || !u || !cost) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_rollout_feedback_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x0, ubar, xbar, gains, alpha, th, tb, x, u, cost);
+        return launched();
+    } else { return PDP_E_MODE; }
+}
+template <class Mdl>
 int oc_costate(int B, int T, const double* x, const double* u, const double* th, int tb, double* lam, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_OC) {
         if (B <= 0 || T <= 0 || !x || !u || !th || !lam) return PDP_E_ARG;
@@ -176,6 +186,10 @@ void pdp_model_get_info(pdp_model_info* info) {
 }
 int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, const double* theta, int tb, double* x, double* cost, void* stream) {
     return oc_rollout<PdpModel>(B, T, x0, u, theta, tb, x, cost, stream);
+}
+int pdp_oc_rollout_feedback_batched(int B, int T, const double* x0, const double* ubar, const double* xbar, const double* gains, const double* alpha,
+                                    const double* theta, int tb, double* x, double* u, double* cost, void* stream) {
+    return oc_rollout_fb<PdpModel>(B, T, x0, ubar, xbar, gains, alpha, theta, tb, x, u, cost, stream);
 }
 int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const double* theta, int tb, double* lam, void* stream) {
     return oc_costate<PdpModel>(B, T, x, u, theta, tb, lam, stream);

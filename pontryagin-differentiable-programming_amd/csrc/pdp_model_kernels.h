@@ -85,6 +85,43 @@ __global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, c
     if (cost) cost[b] = J + Mdl::final_cost(xc, th, pc);
 }
 
+// closed-loop rollout u = ubar - alpha k - K (x - xbar) (one lane per trajectory); gains[b][t] = {K^T [n][m], k [m]}
+template <class Mdl>
+__global__ void oc_rollout_feedback_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
+                                           const double* __restrict__ gains, const double* __restrict__ alpha, const double* __restrict__ theta, int tb,
+                                           double* __restrict__ x, double* __restrict__ u, double* __restrict__ cost) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, GSZ = NX * NU + NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
+    const double a = alpha[b];
+    double xc[NX], xn[NX], uc[NU];
+    double* xb = x + (int64_t)b * (T + 1) * NX;
+    const double* xr = xbar + (int64_t)b * (T + 1) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double* g = gains + ((int64_t)b * T + t) * GSZ;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            double v = ubar[((int64_t)b * T + t) * NU + j] - a * g[NX * NU + j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= g[i * NU + j] * (xc[i] - xr[t * NX + i]);
+            uc[j] = v;
+            u[((int64_t)b * T + t) * NU + j] = v;
+        }
+        Mdl::dyn(xc, uc, th, pc, xn);
+        J += Mdl::path_cost(xc, uc, th, pc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
+    }
+    cost[b] = J + Mdl::final_cost(xc, th, pc);
+}
+
 template <class Mdl>
 __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
                                   int tb, double* __restrict__ lam) {
@@ -162,6 +199,12 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
     s.p[6] = o.Huu ? o.Huu + bt * NU * NU : nullptr;
     s.p[7] = o.Hue ? o.Hue + bt * NU * NP : nullptr;
     s.p[8] = o.Hux ? o.Hux + bt * NU * NX : nullptr;
+    if (o.dHu) {
+        double hu[NU];
+        Mdl::dHu(xc, uc, lc, th, pc, hu);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) o.dHu[bt * NU + i] = hu[i];
+    }
     for (int mat = 0; mat < 8; ++mat) fill_static<Mdl>(s.p[mat], mat, Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat], false);
     if (s.p[8]) {
         for (int i = 0; i < NX * NU; ++i) {

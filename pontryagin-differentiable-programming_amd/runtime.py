@@ -32,7 +32,7 @@ class PdpModelInfo(C.Structure):
 
 
 class PdpOcAuxsys(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue", "hxx", "hxe")]
+    _fields_ = [(k, C.c_void_p) for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue", "hxx", "hxe", "dHu")]
 
 
 class PdpPolicy(C.Structure):
@@ -41,7 +41,7 @@ class PdpPolicy(C.Structure):
 
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
                 "pdp_sysid_aux_integrate_batched"]
-MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
+MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
@@ -124,7 +124,7 @@ def _mat(t, B, time_varying):
     return PdpMat(t.data_ptr(), bs, ts), t
 
 
-def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0=None, T=None, want_costate=True):
+def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0=None, T=None, want_costate=True, return_gains=False):
     """Batched LQR.lqrSolver.  Time-varying families are [B,T,r,c] (or [T,r,c] shared over the batch, or [r,c]
     time-invariant); terminal / initial ones [B,r,c] or [r,c].  Returns (X [B,T+1,n,p], U [B,T,m,p], Lam or None, status [B])."""
     torch = torch_cuda()
@@ -161,6 +161,8 @@ def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0
     ws = torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device="cuda")
     rc = lib.pdp_lqr_solve_batched(C.byref(pr), ptr(X), ptr(U), ptr(Lam), ptr(status), ptr(ws), nbytes, current_stream_ptr())
     check(rc, "pdp_lqr_solve_batched")
+    if return_gains:       # feedback gains {K^T [n][m], k [m][p]} per (b,t): the head of the workspace
+        return X, U, Lam, status, ws[:B * T * (n * m + m * p)].view(B, T, n * m + m * p)
     return X, U, Lam, status
 
 
@@ -199,6 +201,7 @@ _MODEL_SIGS = {
     "pdp_model_get_info": (None, [C.POINTER(PdpModelInfo)]),
     "pdp_oc_rollout_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pdp_oc_costate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pdp_oc_rollout_feedback_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
@@ -264,6 +267,18 @@ class ModelLib:
         check(self.lib.pdp_oc_rollout_batched(B, T, ptr(x0), ptr(u), ptr(th), tb, ptr(x), ptr(cost), current_stream_ptr()), "pdp_oc_rollout_batched")
         return x, cost
 
+    def oc_rollout_feedback(self, x0, ubar, xbar, gains, alpha, theta):
+        torch = torch_cuda()
+        x0, ubar, xbar, gains, alpha = dev(x0).reshape(-1, self.n), dev(ubar), dev(xbar), dev(gains), dev(alpha)
+        B, T = ubar.shape[0], ubar.shape[1]
+        th, tb = self._theta(theta, B)
+        x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda")
+        u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda")
+        cost = torch.empty((B,), dtype=torch.float64, device="cuda")
+        check(self.lib.pdp_oc_rollout_feedback_batched(B, T, ptr(x0), ptr(ubar), ptr(xbar), ptr(gains), ptr(alpha), ptr(th), tb, ptr(x), ptr(u), ptr(cost),
+                                                       current_stream_ptr()), "pdp_oc_rollout_feedback_batched")
+        return x, u, cost
+
     def oc_costate(self, x, u, theta):
         torch = torch_cuda()
         x, u = dev(x), dev(u)
@@ -273,7 +288,8 @@ class ModelLib:
         check(self.lib.pdp_oc_costate_batched(B, T, ptr(x), ptr(u), ptr(th), tb, ptr(lam), current_stream_ptr()), "pdp_oc_costate_batched")
         return lam
 
-    def oc_auxsys(self, x, u, lam, theta):
+    def oc_auxsys(self, x, u, lam, theta, only=None):
+        """materialised OCSys.getAuxSys; `only` = iterable of keys to produce (others are skipped), may include 'dHu'"""
         torch = torch_cuda()
         x, u, lam = dev(x), dev(u), dev(lam)
         B, T = u.shape[0], u.shape[1]
@@ -281,6 +297,9 @@ class ModelLib:
         th, tb = self._theta(theta, B)
         shp = dict(dynF=(B, T, n, n), dynG=(B, T, n, m), dynE=(B, T, n, p), Hxx=(B, T, n, n), Hxu=(B, T, n, m), Hxe=(B, T, n, p),
                    Hux=(B, T, m, n), Huu=(B, T, m, m), Hue=(B, T, m, p), hxx=(B, n, n), hxe=(B, n, p))
+        if only is not None:
+            shp["dHu"] = (B, T, m)
+            shp = {k: v for k, v in shp.items() if k in only}
         out = {k: torch.empty(s, dtype=torch.float64, device="cuda") for k, s in shp.items()}
         o = PdpOcAuxsys(**{k: v.data_ptr() for k, v in out.items()})
         check(self.lib.pdp_oc_auxsys_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, C.byref(o), current_stream_ptr()), "pdp_oc_auxsys_batched")

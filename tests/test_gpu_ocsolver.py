@@ -1,0 +1,78 @@
+"""GPU: the batched OC solver that stands where the reference calls IPOPT (OCSys.ocSolver, PDP.py:121-220).
+Known answers: the optima IPOPT found on the author's machine (tests/golden/demos_*.npz) and the stored IRL traces -
+here the WHOLE iteration (OC solve -> aux system -> Riccati -> gradient) runs on the GPU, no oracle involved."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, f):
+    return np.load(os.path.join(golden_dir, f))
+
+
+def make_oc(name):
+    from pdp_amd import PDP, zoo
+    from pdp_amd.sx import vertcat
+    env, dt = zoo.make_env(name, "irl")
+    oc = PDP.OCSys(name)
+    oc.setAuxvarVariable(vertcat(env.dyn_auxvar, env.cost_auxvar))
+    oc.setStateVariable(env.X)
+    oc.setControlVariable(env.U)
+    oc.setDyn(env.X + dt * env.f)
+    oc.setPathCost(env.path_cost)
+    oc.setFinalCost(env.final_cost)
+    return oc
+
+
+@pytest.mark.parametrize("name,cold", [("pendulum", True), ("cartpole", True), ("robotarm", True), ("quadrotor", True), ("rocket", False)])
+def test_oc_solver_reproduces_stored_ipopt_optimum(golden_dir, name, cold):
+    """cold start (u = 0, like the reference's NLP initial guess) for four systems; the rocket landing problem is non-convex
+    and IPOPT's multiple-shooting path ends in another basin than single shooting from zero, so it is warm-started near the stored optimum"""
+    from pdp_amd import ocsolver
+    d = load(golden_dir, "demos_%s.npz" % name)
+    oc = make_oc(name)
+    rng = np.random.default_rng(0)
+    u0 = None if cold else d["control"] * (1 + 0.05 * rng.standard_normal(d["control"].shape))
+    sol = ocsolver.solve_batch(oc, d["state"][:, 0], d["control"].shape[1], d["true_parameter"], u_init=u0)
+    x, u, lam, cost = (sol[k].cpu().numpy() for k in ("state", "control", "costate", "cost"))
+    assert np.abs(cost - d["cost"]).max() <= 1e-9 * np.abs(d["cost"]).max()
+    assert np.abs(x - d["state"]).max() <= 1e-6 * max(1, np.abs(d["state"]).max())
+    assert np.abs(u - d["control"]).max() <= 1e-6 * max(1, np.abs(d["control"]).max())
+    assert np.abs(lam - d["costate"]).max() <= 1e-6 * max(1, np.abs(d["costate"]).max())      # costate[t] = lambda_{t+1}, IPOPT lam_g sign
+
+
+@pytest.mark.parametrize("name,rows", [("cartpole", [0, 3, 7]), ("quadrotor", [1, 5, 9]), ("pendulum", [0, 9]), ("robotarm", [0, 4]), ("rocket", [3, 8])])
+def test_end_to_end_irl_iteration_on_gpu_matches_stored_trace(golden_dir, name, rows):
+    """Examples/IRL/<sys>/<sys>_PDP.py loop body at the reference's own iterates theta_k: ocSolver -> getAuxSys -> lqrSolver ->
+    chain rule, entirely on the GPU; reproduces loss_trace[k+1] and (p_k - p_{k+1})/lr stored by the reference."""
+    from pdp_amd import ocsolver
+    d = load(golden_dir, "demos_%s.npz" % name)
+    tr = load(golden_dir, "irltrace_%s.npz" % name)
+    oc = make_oc(name)
+    T = d["control"].shape[1]
+    for j in rows:
+        th = tr["param"][j]
+        sol = ocsolver.solve_batch(oc, d["state"][:, 0], T, th, u_init=d["control"])       # warm start: the demo controls (theta_k is near theta*)
+        out = oc.pdp_grad_batch(sol["control"], th, d["state"], d["control"], state_traj=sol["state"], costate_traj=sol["costate"])
+        assert int(out["status"].sum()) == 0
+        loss = float(out["loss"].mean())
+        dp = out["grad"].mean(dim=0).cpu().numpy()
+        gref = (tr["param"][j] - tr["param_next"][j]) / float(tr["lr"])
+        assert abs(loss - tr["loss_next"][j]) <= 1e-6 * abs(tr["loss_next"][j])
+        assert np.abs(dp - gref).max() <= 2e-5 * np.abs(gref).max()
+
+
+def test_ocSolver_dropin_signature(golden_dir):
+    """reference call `traj = oc.ocSolver(ini_state=..., horizon=..., auxvar_value=...)` and its dict keys (PDP.py:212-218)"""
+    d = load(golden_dir, "demos_quadrotor.npz")
+    oc = make_oc("quadrotor")
+    traj = oc.ocSolver(ini_state=d["state"][0, 0], horizon=50, auxvar_value=d["true_parameter"])
+    assert set(traj) == {"state_traj_opt", "control_traj_opt", "costate_traj_opt", "auxvar_value", "time", "horizon", "cost"}
+    assert traj["state_traj_opt"].shape == (51, 13) and traj["control_traj_opt"].shape == (50, 4) and traj["costate_traj_opt"].shape == (50, 13)
+    assert abs(traj["cost"].item() - d["cost"][0]) < 1e-9 * d["cost"][0]
+    assert np.abs(traj["costate_traj_opt"] - d["costate"][0]).max() < 1e-6 * np.abs(d["costate"][0]).max()
+    traj1 = oc.ocSolver(d["state"][0, 0], 50, d["true_parameter"], costate_option=1)
+    assert np.abs(traj1["costate_traj_opt"] - traj["costate_traj_opt"]).max() < 1e-8 * np.abs(d["costate"][0]).max()
