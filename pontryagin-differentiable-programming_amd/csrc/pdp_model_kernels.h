@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             return r >= NX ? -1 : (c < M ? Mdl::path_code(4, r * NU + c) : (c < M + NP ? Mdl::path_code(5, r * NP + (c - M)) : -1)); });
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [](int r, int c) {
             return r >= M ? -1 : (c < M ? Mdl::path_code(6, r * NU + c) : (c < M + NP ? Mdl::path_code(7, r * NP + (c - M)) : -1)); });
+        const TileMap mKT = make_tile_map(NX, NU, NU, 0, 0, lane), mIK = make_tile_map(NU, NP, NP, 0, M, lane);
         const int nchunk = (T + CH - 1) / CH;
         for (int c = nchunk - 1; c >= 0; --c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
@@ -416,9 +417,16 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 PDP_FINE(1, t == 20);
                 ok = riccati_backward<M>(P, W2, Ft, Y2, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
-                store_dense(gw + t * GSZ, NX, NU, NU, 0, 0, lane, g.KT);
-                store_dense(gw + t * GSZ + NX * NU, NU, NP, NP, 0, M, lane, g.IK);
+                store_mapped<4>(gw + t * GSZ, mKT, g.KT);
+                store_mapped<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
                 Ft = Ft_n; Y2 = Y2_n; Hxx = Hxx_n; HX2 = HX2_n; HU2 = HU2_n;
+#ifdef PDP_SCHED_PIPELINE
+#pragma unroll
+                for (int q = 0; q < 25; ++q) {               // 1 MFMA, then up to PDP_SCHED_PIPELINE VALU/SALU/DS/VMEM instructions
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x096, PDP_SCHED_PIPELINE, 0);
+                }
+#endif
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
             }
@@ -443,8 +451,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
-        d4 KTn = -load_dense<false>(gw, NX, NU, NU, 0, 0, lane);
-        d4 kn = -load_dense<false>(gw + NX * NU, NU, NP, NP, 0, M, lane);
+        const TileMap mKT = make_tile_map(NX, NU, NU, 0, 0, lane), mIK = make_tile_map(NU, NP, NP, 0, M, lane);
+        d4 KTn = -load_mapped<4>(gw, mKT);
+        d4 kn = -load_mapped<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;
         for (int c = 0; c < nchunk; ++c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
@@ -464,8 +473,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             for (int tl = 0; tl < cnt; ++tl) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
-                d4 KTn_n = -load_dense<false>(gw + tnx * GSZ, NX, NU, NU, 0, 0, lane);
-                d4 kn_n = -load_dense<false>(gw + tnx * GSZ + NX * NU, NU, NP, NP, 0, M, lane);
+                d4 KTn_n = -load_mapped<4>(gw + tnx * GSZ, mKT);
+                d4 kn_n = -load_mapped<1>(gw + tnx * GSZ + NX * NU, mIK);
                 d4 FT = gather_tile(blk, gFT, tl);
                 d4 GT = gather_tile_r0(blk, gGT, tl);
                 d4 E2 = gather_tile(blk, gE, tl);

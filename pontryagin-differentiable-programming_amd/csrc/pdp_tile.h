@@ -71,6 +71,33 @@ PDP_DEV void store_dense(double* __restrict__ M, int R, int C, int ld, int roff,
         if (row >= 0 && row < R && col >= 0 && col < C) M[row * ld + col] = v[r];
     }
 }
+// Loop-invariant map between a tile and a dense R x C block (leading dimension ld) placed at (roff, coff) in the tile:
+// built once per kernel, so that per-step loads/stores cost one address add each.
+struct TileMap {
+    int off[4];       // element offset in the dense block, or -1
+};
+PDP_DEV TileMap make_tile_map(int R, int C, int ld, int roff, int coff, int lane) {
+    TileMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = tile_row(lane, r) - roff, col = tile_col(lane) - coff;
+        m.off[r] = (row >= 0 && row < R && col >= 0 && col < C) ? row * ld + col : -1;
+    }
+    return m;
+}
+template <int NR = 4>
+PDP_DEV void store_mapped(double* __restrict__ base, const TileMap& m, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) base[m.off[r]] = v[r];
+}
+template <int NR = 4>
+PDP_DEV d4 load_mapped(const double* __restrict__ base, const TileMap& m) {
+    d4 v = zero4();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) v[r] = base[m.off[r]];
+    return v;
+}
+
 // zero every column outside [c0, c1)
 PDP_DEV d4 keep_cols(const d4 v, int c0, int c1, int lane) {
     int col = tile_col(lane);
@@ -148,12 +175,12 @@ PDP_DEV bool inverse_small(const double* a_in, double* inv) {
 
 // Inverse of an M x M matrix (M <= 4), uniform over the wave.  Fast path: cofactor (adjugate) formulas with ONE
 // division (fp64 division costs ~74 cycles on gfx950; Gauss-Jordan needs M of them in sequence); guarded by the
-// determinant test |det| > 1e-10 * max|a|^M, otherwise the pivoted Gauss-Jordan above takes over (uniform branch).
+// determinant test |det| > 1e-10 * |prod diag|, otherwise the pivoted Gauss-Jordan above takes over (uniform branch).
 template <int M>
 PDP_DEV bool inverse_small_fast(const double* a, double* inv) {
-    double amax = 0.0;
+    double dprod = 1.0;                        // |det| <= prod diag for SPD matrices (Hadamard): det / dprod measures conditioning
 #pragma unroll
-    for (int i = 0; i < M * M; ++i) amax = fmax(amax, fabs(a[i]));
+    for (int i = 0; i < M; ++i) dprod *= a[i * M + i];
     double det, c[M * M];
     if constexpr (M == 1) {
         det = a[0]; c[0] = 1.0;
@@ -181,10 +208,7 @@ PDP_DEV bool inverse_small_fast(const double* a, double* inv) {
         c[12] = -a[4] * c3 + a[5] * c1 - a[6] * c0; c[13] = a[0] * c3 - a[1] * c1 + a[2] * c0;
         c[14] = -a[12] * s3 + a[13] * s1 - a[14] * s0; c[15] = a[8] * s3 - a[9] * s1 + a[10] * s0;
     }
-    double lim = 1e-10;
-#pragma unroll
-    for (int i = 0; i < M; ++i) lim *= amax;
-    if (!(fabs(det) > lim) || !(fabs(det) <= 1.7e308)) return inverse_small<M>(a, inv);   // ill-conditioned / singular: pivoted path
+    if (!(fabs(det) > 1e-10 * fabs(dprod)) || !(fabs(det) <= 1.7e308)) return inverse_small<M>(a, inv);   // ill-conditioned / singular: pivoted path
     const double id = 1.0 / det;
 #pragma unroll
     for (int i = 0; i < M * M; ++i) inv[i] = c[i] * id;
