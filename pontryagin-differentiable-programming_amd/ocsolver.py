@@ -17,7 +17,7 @@ import numpy as np
 from . import runtime
 
 
-def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0):
+def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, force_init=False, want_gains=False):
     """oc: PDP.OCSys.  ini_state [B,n]; auxvar_value [p] or [B,p]; returns dict of CUDA tensors
     state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], iterations (int), converged [B] (bool).
     u_init (optional warm start) is used per sample only where its rollout is finite and cheaper than u = 0."""
@@ -32,7 +32,7 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     if u_init is not None:
         uw = runtime.dev(u_init).reshape(B, T, m)
         xw, Jw = mdl.oc_rollout(x0, uw, th)
-        better = torch.isfinite(Jw) & torch.isfinite(xw).all(dim=(1, 2)) & ((Jw < J) | ~torch.isfinite(J))
+        better = torch.isfinite(Jw) & torch.isfinite(xw).all(dim=(1, 2)) & ((Jw < J) | ~torch.isfinite(J) | force_init)
         u, x, J = torch.where(better.view(B, 1, 1), uw, u), torch.where(better.view(B, 1, 1), xw, x), torch.where(better, Jw, J)
     zeros_lam = torch.zeros((B, T, n), dtype=torch.float64, device="cuda")
     hxe0 = torch.zeros((B, n, 1), dtype=torch.float64, device="cuda")
@@ -87,4 +87,72 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
         mu = torch.where(mu < 1e-8, torch.zeros_like(mu), mu)
         newton = newton & ~failed
     lam = mdl.oc_costate(x, u, th)
-    return {"state": x, "control": u, "costate": lam, "cost": J, "grad_norm": gnorm, "iterations": it, "converged": converged}
+    out = {"state": x, "control": u, "costate": lam, "cost": J, "grad_norm": gnorm, "iterations": it, "converged": converged}
+    if want_gains:      # time-varying LQR feedback around the final trajectory (closed-loop warm starts of neighbouring problems)
+        aux = mdl.oc_auxsys(x, u, lam, th, only=keys)
+        _, _, _, _, gains = runtime.lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], hxe0, Hxu=aux["Hxu"],
+                                              Hue=aux["dHu"].unsqueeze(-1), want_costate=False, return_gains=True)
+        out["gains"] = gains.clone()
+    return out
+
+
+def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,
+                warm_start=None, want_gains=False):
+    """Batched OC solve (see _solve) plus a batch-level globalisation: samples that did not converge (non-convex problems such
+    as the cart-pole swing-up can trap single shooting in a poor basin) are re-solved from a CLOSED-LOOP warm start: the optimal
+    trajectory and LQR feedback gains of the nearest converged sample (distance in initial state and parameter) are rolled out
+    from the stuck sample's own initial state (open-loop warm starts diverge on unstable systems), up to `neighbor_retries` times."""
+    torch = runtime.torch_cuda()
+    mdl = oc.model()
+    force = False
+    if warm_start is not None:
+        # closed-loop warm start from a previous solution of the SAME batch (dict with state, control, gains - e.g. the previous
+        # iterate of an IRL loop, or the solution at a neighbouring parameter): u = ubar - K (x - xbar) rolled out at the new theta
+        x0w = runtime.dev(ini_state).reshape(-1, mdl.n)
+        _, u_init, _ = mdl.oc_rollout_feedback(x0w, warm_start["control"], warm_start["state"], warm_start["gains"],
+                                               torch.zeros((x0w.shape[0],), dtype=torch.float64, device="cuda"), oc._theta(auxvar_value, x0w.shape[0]))
+        force = True
+    sol = _solve(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level, force_init=force,
+                 want_gains=want_gains)
+    B = sol["state"].shape[0]
+    if B == 1 or neighbor_retries <= 0:
+        return sol
+    x0 = runtime.dev(ini_state).reshape(B, -1)
+    th_np = np.asarray(oc._theta(auxvar_value, B), dtype=np.float64).reshape(-1, oc.n_auxvar)
+    th = runtime.dev(th_np)
+    feat = torch.cat([x0, th.expand(B, -1)], dim=1)
+    feat = feat / (feat.abs().amax(dim=0, keepdim=True) + 1e-12)
+    for _ in range(neighbor_retries):
+        conv = sol["converged"]
+        if not bool(conv.any()):
+            break
+        # candidates for a retry: not converged, or converged into a basin markedly worse than a nearby sample's
+        # (cost > 1.25 x the cheapest of the 8 nearest converged neighbours) - single shooting on non-convex problems
+        gi = torch.nonzero(conv).flatten()
+        dist = torch.cdist(feat, feat[gi])
+        k = min(8, gi.numel())
+        nn = dist.topk(k, dim=1, largest=False).indices                       # [B,k] indices into gi
+        nn_cost = sol["cost"][gi][nn]
+        best = nn_cost.argmin(dim=1)
+        donor_all = gi[nn.gather(1, best.view(-1, 1)).flatten()]
+        worse = conv & (sol["cost"] > 1.25 * nn_cost.min(dim=1).values)
+        bad = ~conv | worse
+        if not bool(bad.any()):
+            break
+        bi = torch.nonzero(bad).flatten()
+        donors = donor_all[bi]
+        thb = th_np[bi.cpu().numpy()] if th_np.shape[0] == B else th_np[0]
+        thd = th_np[donors.cpu().numpy()] if th_np.shape[0] == B else th_np[0]
+        don = _solve(oc, x0[donors], horizon, thd, u_init=sol["control"][donors], tol=tol, max_iter=3, force_init=True, want_gains=True)
+        _, u_cl, _ = mdl.oc_rollout_feedback(x0[bi], don["control"], don["state"], don["gains"], torch.zeros_like(sol["cost"][bi]), thb)
+        sub = _solve(oc, x0[bi], horizon, thb, u_init=u_cl, tol=tol, max_iter=max_iter, print_level=print_level, force_init=True)
+        better = (sub["converged"] & ~sol["converged"][bi]) | (sub["converged"] & (sub["cost"] < sol["cost"][bi])) | \
+                 (~sol["converged"][bi] & (sub["cost"] < sol["cost"][bi]))
+        idx = bi[better]
+        if want_gains:
+            sub2 = _solve(oc, x0[bi], horizon, thb, u_init=sub["control"], tol=tol, max_iter=1, force_init=True, want_gains=True)
+            sub["gains"] = sub2["gains"]
+        for k in ("state", "control", "costate", "cost", "grad_norm", "converged") + (("gains",) if want_gains else ()):
+            sol[k][idx] = sub[k][better]
+        sol["iterations"] = max(sol["iterations"], sub["iterations"])
+    return sol

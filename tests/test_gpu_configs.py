@@ -1,0 +1,166 @@
+"""GPU: the BASELINE.json configurations at (or near) full size, checked through size-independent properties the domain
+offers: zero loss / zero gradient at the generating parameter, PDP gradient == finite differences of the re-solved
+problem, per-sample results independent of batch composition, linearity of the sensitivity recursion."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def make_oc(name):
+    from test_gpu_ocsolver import make_oc as mk
+    return mk(name)
+
+
+def test_C2_cartpole_irl_batch256_pdp_gradient_is_derivative_through_the_oc_solution():
+    """C2: cart-pole IRL, n=4 m=1 T=50, 256 cost/dynamics parameter samples.  Demo = optimum at theta*; for every sample
+    theta_b the OC problem is solved on the GPU and differentiated by PDP.  Properties: (i) at theta* loss = 0 and gradient = 0;
+    (ii) PDP's gradient equals the central finite difference of loss(theta) obtained by RE-SOLVING the OC problem
+    (the reference's dp is half the gradient of its loss, cartpole_PDP.py:63-74)."""
+    from pdp_amd import ocsolver
+    import torch
+    oc = make_oc("cartpole")
+    rng = np.random.default_rng(0)
+    B, T = 256, 50
+    th_star = np.array([0.5, 0.5, 1, 1, 6, 1, 1.0])
+    x0 = np.zeros((B, 4))
+    x0[:, 1] = rng.uniform(-0.5, 0.5, B)
+    demo = ocsolver.solve_batch(oc, x0, T, th_star, want_gains=True)
+    assert bool(demo["converged"].all())
+    out = oc.pdp_grad_batch(demo["control"], th_star, demo["state"], demo["control"], state_traj=demo["state"], costate_traj=demo["costate"])
+    assert float(out["loss"].abs().max()) == 0.0 and float(out["grad"].abs().max()) == 0.0
+    theta = th_star[None, :] + rng.uniform(-0.1, 0.1, (B, 7))
+    sol = ocsolver.solve_batch(oc, x0, T, theta, warm_start=demo, want_gains=True)      # closed-loop warm start from the theta* solution
+    assert bool(sol["converged"].all())
+    out = oc.pdp_grad_batch(sol["control"], theta, demo["state"], demo["control"], state_traj=sol["state"], costate_traj=sol["costate"])
+    assert int(out["status"].sum()) == 0
+    g = npy(out["grad"])
+    # finite differences through the solver, 8 samples x 7 parameters solved as one batch of 112 problems
+    idx = np.arange(8)
+    eps = 1e-5
+    thp = np.repeat(theta[idx], 14, axis=0)
+    for k in range(7):
+        thp[k::14][:, k] += eps                     # rows 0..6: +eps on parameter k
+        thp[7 + k::14][:, k] -= eps                 # rows 7..13: -eps
+    rep = lambda a: torch.repeat_interleave(a[:8], 14, dim=0)
+    s2 = ocsolver.solve_batch(oc, np.repeat(x0[idx], 14, axis=0), T, thp, tol=1e-11,
+                              warm_start={k: rep(sol[k]) for k in ("state", "control", "gains")})
+    dx = s2["state"] - rep(demo["state"])
+    du = s2["control"] - rep(demo["control"])
+    L = npy((dx ** 2).sum(dim=(1, 2)) + (du ** 2).sum(dim=(1, 2))).reshape(8, 14)
+    fd = (L[:, :7] - L[:, 7:]) / (2 * eps)
+    assert np.abs(2 * g[idx] - fd).max() <= 2e-4 * np.abs(fd).max()
+
+
+def test_C4_rocket_planning_T100_batch512():
+    """C4 per-GPU shard: rocket n=13 m=3 T=100, Lagrange policy p=18, 512 random initial states.  ControlPlanning.step returns
+    the exact gradient of the rollout cost: checked by finite differences; per-sample results do not depend on the batch."""
+    from pdp_amd import runtime as rt, zoo
+    from pdp_amd import JinEnv
+    mdl = zoo.get("rocket", "oc")
+    rng = np.random.default_rng(1)
+    B, T, p = 512, 100, 18
+    x0 = np.zeros((B, 13))
+    x0[:, 0:3] = np.array([10, -8, 5.0]) + rng.standard_normal((B, 3))
+    x0[:, 3] = -0.1
+    x0[:, 6:10] = JinEnv.toQuaternion(1.5, [0, 0, 1])
+    theta = 0.5 * rng.standard_normal(p)
+    pol = rt.make_policy("poly", pivots=np.linspace(0, T, 6))
+    loss, grad = mdl.cp_step(pol, p, x0, theta, T)
+    loss, grad = npy(loss), npy(grad)
+    assert np.all(np.isfinite(loss)) and np.all(np.isfinite(grad))
+    l2, g2 = mdl.cp_step(pol, p, x0[100:103], np.tile(theta, (3, 1)), T)
+    assert np.array_equal(npy(l2), loss[100:103]) and np.array_equal(npy(g2), grad[100:103])
+    eps = 1e-6
+    for k in (0, 7, 17):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        lp, _ = mdl.cp_step(pol, p, x0[:4], tp, T)
+        lm, _ = mdl.cp_step(pol, p, x0[:4], tm, T)
+        fd = (npy(lp) - npy(lm)) / (2 * eps)
+        assert np.abs(fd - grad[:4, k]).max() <= 1e-6 * np.abs(grad[:4, k]).max()
+
+
+def test_C5_quadrotor_sysid_T100_batch1024():
+    """C5a per-GPU shard: quadrotor SysID T=100 p=5, 1024 trajectories generated at theta* with inputs U(-10,10):
+    loss = 0 and gradient = 0 at theta*; away from it the (half-)gradient matches finite differences."""
+    from pdp_amd import zoo
+    from pdp_amd import JinEnv
+    mdl = zoo.get("quadrotor", "sysid")
+    rng = np.random.default_rng(2)
+    B, T = 1024, 100
+    th_star = np.array([1, 1, 1, 1, 0.4])
+    u = rng.uniform(-1, 1, (B, T, 4)) + 2.5
+    x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (B, 1))
+    xobs = mdl.sysid_integrate(x0, u, th_star)
+    loss, grad = mdl.sysid_step(u, xobs, th_star)
+    assert float(loss.abs().max()) == 0.0 and float(grad.abs().max()) == 0.0
+    theta = th_star + np.array([0.1, -0.05, 0.08, 0.03, -0.02])
+    loss, grad = mdl.sysid_step(u, xobs, theta)
+    g = npy(grad)
+    eps = 1e-6
+    for k in range(5):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        lp, _ = mdl.sysid_step(u[:8], xobs[:8], tp)
+        lm, _ = mdl.sysid_step(u[:8], xobs[:8], tm)
+        fd = (npy(lp) - npy(lm)) / (2 * eps)
+        assert np.abs(fd - 2 * g[:8, k]).max() <= 1e-5 * max(np.abs(fd).max(), 1e-12)
+
+
+def test_C5_quadrotor_neural_policy_T100_p420():
+    """C5b: tanh-MLP policy hidden [13,13] (p = 420), T = 100: gradient of ControlPlanning.step vs finite differences on
+    a few of the 420 weights (column-major layout), batch of 16."""
+    from pdp_amd import runtime as rt, zoo
+    from pdp_amd import JinEnv
+    mdl = zoo.get("quadrotor", "oc")
+    rng = np.random.default_rng(3)
+    B, T, p = 16, 100, 420
+    theta = 0.1 * rng.standard_normal(p)
+    x0 = np.zeros((B, 13))
+    x0[:, :3] = rng.uniform(-2, 2, (B, 3))
+    x0[:, 6] = 1.0
+    pol = rt.make_policy("mlp", layers=[13, 13, 4])
+    loss, grad = mdl.cp_step(pol, p, x0, theta, T)
+    g = npy(grad)
+    assert g.shape == (B, p) and np.all(np.isfinite(g))
+    eps = 1e-6
+    for k in (0, 181, 200, 419):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        lp, _ = mdl.cp_step(pol, p, x0[:3], tp, T)
+        lm, _ = mdl.cp_step(pol, p, x0[:3], tm, T)
+        fd = (npy(lp) - npy(lm)) / (2 * eps)
+        assert np.abs(fd - g[:3, k]).max() <= 1e-5 * max(np.abs(g[:3, k]).max(), 1e-9)
+
+
+def test_lqr_sensitivity_is_linear_in_the_parameter_columns():
+    """size-independent property of the aux-system solve: the solution is linear in (E, Hxe, Hue, hxe, X0) - doubling those
+    columns doubles X, U, Lambda; a zero right-hand side gives a zero solution (B = 2048 random problems)."""
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(4)
+    B, T, n, m, p = 2048, 20, 13, 4, 9
+
+    def spd(k, s, cnt):
+        A = rng.standard_normal((cnt, k, k))
+        return s * (A @ A.transpose(0, 2, 1) / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.1 * rng.standard_normal((B, T, n, n))
+    G = 0.3 * rng.standard_normal((B, T, n, m))
+    Hxx, Huu, hxx = spd(n, 1.0, B * T).reshape(B, T, n, n), spd(m, 0.5, B * T).reshape(B, T, m, m), spd(n, 1.0, B)
+    Hxu = 0.05 * rng.standard_normal((B, T, n, m))
+    E, Hxe, Hue = 0.1 * rng.standard_normal((B, T, n, p)), 0.2 * rng.standard_normal((B, T, n, p)), 0.2 * rng.standard_normal((B, T, m, p))
+    hxe, X0 = 0.2 * rng.standard_normal((B, n, p)), rng.standard_normal((B, n, p))
+    X1, U1, L1, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0)
+    X2, U2, L2, _ = rt.lqr_solve(F, G, Hxx, Huu, hxx, 2 * hxe, E=2 * E, Hxu=Hxu, Hxe=2 * Hxe, Hue=2 * Hue, X0=2 * X0)
+    assert int(st.sum()) == 0
+    for a, b in ((X1, X2), (U1, U2), (L1, L2)):
+        assert float((2 * a - b).abs().max()) <= 1e-12 * float(b.abs().max())
+    X0_, U0_, L0_, _ = rt.lqr_solve(F, G, Hxx, Huu, hxx, 0 * hxe, Hxu=Hxu)
+    assert float(X0_.abs().max()) == 0.0 and float(U0_.abs().max()) == 0.0
