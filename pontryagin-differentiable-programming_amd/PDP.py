@@ -425,6 +425,103 @@ class ControlPlanning:
         return float(loss[0]), _np(grad)[0]
 
 
+    # ---- warped / recovery-matrix variants (reference PDP.py:882-1141) -----------------------------------------------
+    # The horizon is cut into <= 10 grid cells with one control per cell.  The reference composes the dynamics symbolically
+    # over every cell (warp_dynCost) and, for recmat, builds ONE symbolic expression of the whole-horizon gradient
+    # (recmat_recoveryMatrix).  That gradient is d cost / d (cell control) = sum over the cell of H_u(x_t, u_t, lambda_{t+1})
+    # with the PMP costates lambda - so here it is ONE adjoint sweep with kernels that already exist:
+    # rollout -> costates -> dH/du per step -> segment sums.  No symbolic composition, cost O(T n^2) instead of O(T n^2 p).
+    def _adjoint_model(self):
+        if getattr(self, "_adj", None) is None:
+            pb = codegen.Problem(codegen.KIND_OC, self.state, self.control, self.dyn, SX.sym("unused_auxvar"), self.path_cost, self.final_cost,
+                                 label=_label(self.project_name))
+            lib, _ = codegen.build_problem(pb)
+            self._adj = runtime.load_model(lib)
+        return self._adj
+
+    def _make_time_grid(self, horizon, time_grid, full_grid_points):
+        if time_grid is None:
+            time_grid = numpy.linspace(0, 1, numpy.amin([horizon + 1, 11]))
+        if type(time_grid) == list:
+            time_grid = numpy.array(time_grid)
+        if numpy.isscalar(time_grid) and time_grid == -1:
+            time_grid = full_grid_points
+        self.time_grid = numpy.rint(horizon * time_grid / time_grid[-1]).astype(int)
+        self.whorizon = len(self.time_grid) - 1
+        self._cell_of_t = numpy.repeat(numpy.arange(self.whorizon), numpy.diff(self.time_grid))
+
+    def warp_init_step(self, horizon, time_grid=None):                          # PDP.py:960-978
+        self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon - 1, horizon))
+        self.setPolyControl(numpy.linspace(0, self.whorizon, self.whorizon + 1))
+
+    def recmat_init_step(self, horizon, time_grid=None):                        # PDP.py:1081-1098
+        self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon, horizon + 1))
+        self.n_auxvar = self.whorizon * self.n_control
+        self.auxvar = SX.sym("U", self.n_auxvar)
+
+    def _cell_controls(self, theta, mode):
+        """[B, whorizon, m] control of every grid cell"""
+        th = np.atleast_2d(np.asarray(theta, float))
+        if mode == "recmat":
+            return th.reshape(th.shape[0], self.whorizon, self.n_control)
+        W = self.whorizon
+        piv = np.asarray(self.pivots)
+        basis = np.ones((W, W + 1))
+        for wt in range(W):
+            for i in range(W + 1):
+                for j in range(W + 1):
+                    if j != i:
+                        basis[wt, i] = basis[wt, i] * (wt - piv[j]) / (piv[i] - piv[j])
+        self._wbasis = basis
+        return np.einsum("wi,bim->bwm", basis, th.reshape(th.shape[0], W + 1, self.n_control))
+
+    def _warped_adjoint(self, ini_state, auxvar_value, mode):
+        """(cost [B], d cost / d cell-control [B, whorizon, m], state [B,T+1,n], control [B,T,m])"""
+        torch = runtime.torch_cuda()
+        mdl = self._adjoint_model()
+        x0 = np.atleast_2d(np.asarray(ini_state, float))
+        uc = self._cell_controls(auxvar_value, mode)
+        if uc.shape[0] == 1 and x0.shape[0] > 1:
+            uc = np.repeat(uc, x0.shape[0], axis=0)
+        u = runtime.dev(uc[:, self._cell_of_t, :])
+        dummy = np.zeros(1)
+        x, cost = mdl.oc_rollout(x0, u, dummy)
+        lam = mdl.oc_costate(x, u, dummy)
+        dHu = mdl.oc_auxsys(x, u, lam, dummy, only=("dHu",))["dHu"]                 # [B,T,m]
+        g = torch.zeros((u.shape[0], self.whorizon, self.n_control), dtype=torch.float64, device="cuda")
+        g.index_add_(1, torch.as_tensor(self._cell_of_t, device="cuda"), dHu)
+        return cost, g, x, u
+
+    def recmat_step(self, ini_state, horizon, auxvar_value):                    # PDP.py:1100-1114
+        cost, g, _, _ = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "recmat")
+        return float(cost[0]), _np(g)[0].reshape(-1)
+
+    def recmat_step_batch(self, ini_state, horizon, auxvar_value):
+        cost, g, _, _ = self._warped_adjoint(ini_state, auxvar_value, "recmat")
+        return cost, g.reshape(g.shape[0], -1)
+
+    def warp_step(self, ini_state, horizon, auxvar_value):                      # PDP.py:980-1008
+        assert hasattr(self, "time_grid"), "Run warp_init_step first!"
+        cost, g, _, _ = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "warp")
+        dtheta = np.einsum("wi,wm->im", self._wbasis, _np(g)[0])                 # chain rule through the Lagrange policy on the cell index
+        return float(cost[0]), dtheta.reshape(-1)
+
+    def warp_integrateSys(self, ini_state, whorizon, auxvar_value):             # PDP.py:917-938
+        cost, _, x, u = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "warp")
+        x, uc = _np(x)[0], self._cell_controls(_vec(auxvar_value), "warp")[0]
+        return {"wstate_traj": x[self.time_grid], "wcontrol_traj": uc, "wcost": float(cost[0])}
+
+    def _unwarp(self, ini_state, auxvar_value, mode):
+        cost, _, x, u = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), mode)
+        return {"state_traj": _np(x)[0], "control_traj": _np(u)[0], "cost": np.array([float(cost[0])])}
+
+    def warp_unwarp(self, ini_state, horizon, auxvar_value):                    # PDP.py:1010-1035
+        return self._unwarp(ini_state, auxvar_value, "warp")
+
+    def recmat_unwarp(self, ini_state, horizon, auxvar_value):                  # PDP.py:1116-1141
+        return self._unwarp(ini_state, auxvar_value, "recmat")
+
+
 # =============================================================================================================
 class SysID:
     """System identification (reference PDP/PDP.py:1157-1296)."""

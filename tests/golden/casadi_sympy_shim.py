@@ -177,6 +177,14 @@ class Function:
         self._f = [sp.lambdify(args, o.m, modules="numpy", cse=True) for o in self.outs]
 
     def __call__(self, *vals):
+        if any(isinstance(v, SX) for v in vals):                 # symbolic call: substitution (used by warp_dynCost / recmat)
+            sub = {}
+            for v, i in zip(vals, self.ins):
+                v = SX._lift(v)
+                for a, b in zip(i._colmajor(), v._colmajor()):
+                    sub[a] = b
+            res = [SX(o.m.xreplace(sub)) for o in self.outs]
+            return res[0] if len(res) == 1 else tuple(res)
         flat = []
         for v, i in zip(vals, self.ins):
             if isinstance(v, DM):

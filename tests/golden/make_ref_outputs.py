@@ -198,8 +198,48 @@ def sysid_cases():
         print("sysid", name, loss, grad)
 
 
+
+
+def warp_recmat_cases():
+    """ControlPlanning.warp_step / recmat_step (PDP.py:882-1141) of the reference on small problems (the symbolic
+    composition over grid cells is expensive in the sympy stand-in)."""
+    # (system, dt, T, x0, time_grid, modes): kept to what the sympy stand-in composes in about a minute; the recovery matrix of
+    # the cart-pole (a whole-horizon symbolic expression, PDP.py:1039-1079) does not finish in an hour there
+    specs = [("pendulum", 0.05, 20, [0.0, 0.0], None, ("warp", "recmat")), ("cartpole", 0.05, 25, [0.0, 0.0, 0.0, 0.0], None, ("warp",))]
+    for k, (name, dt, T, x0, grid, modes) in enumerate(specs):
+        env = make_env(name, "oc")
+        for mode in modes:
+            cp = PDP.ControlPlanning()
+            cp.setStateVariable(env.X)
+            cp.setControlVariable(env.U)
+            cp.setDyn(env.X + dt * env.f)
+            cp.setPathCost(env.path_cost)
+            cp.setFinalCost(env.final_cost)
+            if mode == "warp":
+                cp.warp_init_step(T) if grid is None else cp.warp_init_step(T, grid)
+                theta = rng.standard_normal(cp.n_auxvar)
+                loss, grad = cp.warp_step(np.array(x0, float), T, theta)
+                un = cp.warp_unwarp(np.array(x0, float), T, theta)
+            else:
+                cp.recmat_init_step(T) if grid is None else cp.recmat_init_step(T, grid)
+                theta = rng.standard_normal(cp.n_auxvar)
+                loss, grad = cp.recmat_step(np.array(x0, float), T, theta)
+                un = cp.recmat_unwarp(np.array(x0, float), T, theta)
+            np.savez_compressed(os.path.join(HERE, "ref_%s_%s_%d.npz" % (mode, name, k)), dt=dt, T=T, x0=np.array(x0, float), theta=theta,
+                                grid=(-2 if grid is None else grid), time_grid=cp.time_grid, loss=float(np.asarray(loss).squeeze()), grad=np.asarray(grad, float).flatten(),
+                                state=un["state_traj"], control=un["control_traj"], cost=float(np.asarray(un["cost"]).squeeze()))
+            print(mode, name, k, "p", cp.n_auxvar, "grid", cp.time_grid, "loss", float(np.asarray(loss).squeeze()))
+
+
 if __name__ == "__main__":
-    lqr_random_cases()
-    sysid_cases()
-    cp_cases()
-    irl_cases()
+    which = sys.argv[1:] or ["lqr", "sysid", "cp", "irl", "warp"]
+    if "lqr" in which:
+        lqr_random_cases()
+    if "sysid" in which:
+        sysid_cases()
+    if "cp" in which:
+        cp_cases()
+    if "irl" in which:
+        irl_cases()
+    if "warp" in which:
+        warp_recmat_cases()
