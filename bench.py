@@ -57,7 +57,8 @@ def synth_inputs(batch, seed):
 def cpu_baseline(budget_s=12.0):
     """The oracle's C restatement (oracle/libpdp_oracle.so, OpenMP) when built, else the numpy oracle, timed on a bounded
     sample of the same workload on this host's cores.  Reported beside the GPU number; never the thing measured above."""
-    x0, u, dx, du = synth_inputs(256, 12345)
+    cores = os.cpu_count() or 1
+    x0, u, dx, du = synth_inputs(int(min(8192, max(256, 16 * cores))), 12345)      # >= 16 trajectories per core for the OpenMP port
     th = np.array(THETA)
     try:
         from oracle import c_oracle
@@ -65,12 +66,11 @@ def cpu_baseline(budget_s=12.0):
     except Exception:
         lib = None
     if lib is not None:
-        cores = os.cpu_count() or 1
-        n = 64
+        n = min(len(x0), 4 * cores)
         t0 = time.perf_counter()
         c_oracle.quadrotor_oc_unit(lib, x0[:n], u[:n], th, dx[:n], du[:n], threads=cores)
         dt = time.perf_counter() - t0
-        n = int(min(len(x0), max(n, n * budget_s / max(dt, 1e-6) / 4)))
+        n = int(min(len(x0), max(n, n * budget_s / max(dt, 1e-6) / 8)))
         reps, t_tot, done = 0, 0.0, 0
         while t_tot < budget_s / 2:
             t0 = time.perf_counter()

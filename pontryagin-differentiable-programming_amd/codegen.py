@@ -279,9 +279,15 @@ def generate(problem):
         dims = {"F": (n, n), "G": (n, m), "E": (n, p), "Hxx": (n, n), "Hxu": (n, m), "Hxe": (n, p), "Huu": (m, m), "Hue": (m, p),
                 "hxx": (n, n), "hxe": (n, p)}
         groups["path"] = _Group("path", [(k,) + dims[k] + (mats[k],) for k in OC_PATH])
+        # the fused kernel evaluates the path matrices in two stages per chunk: lambda-independent (patha: F, G, E, c_x) first,
+        # then - once the costates of the chunk have been propagated with F and c_x - the lambda-weighted Hessians (pathb)
+        mats["cx"] = R(sx.jacobian(c, x).T)
+        dims["cx"] = (n, 1)
+        groups["patha"] = _Group("patha", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "E", "cx")])
+        groups["pathb"] = _Group("pathb", [(k,) + dims[k] + (mats[k],) for k in ("Hxx", "Hxu", "Hxe", "Huu", "Hue")])
         groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD])
         groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN])
-        chunk = _pick_chunk(groups["path"].nvar, 0)
+        chunk = _pick_chunk(groups["patha"].nvar + groups["pathb"].nvar, n)
     elif pb.kind == KIND_CP:
         c, h = pb.path_cost, pb.final_cost
         assert p == 0, "ControlPlanning dynamics / costs carry no auxvar (PDP.py:672-697)"

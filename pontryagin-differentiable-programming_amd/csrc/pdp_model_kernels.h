@@ -245,18 +245,21 @@ PDP_DEV d4 gather_tile_r0(const double* lds, const Gather& g, int tl) {
 template <class Mdl>
 struct FusedLayout {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
-    static constexpr int NC = 1 + (Mdl::PATH_NCONST > Mdl::FWD_NCONST ? (Mdl::PATH_NCONST > Mdl::FIN_NCONST ? Mdl::PATH_NCONST : Mdl::FIN_NCONST)
-                                                                      : (Mdl::FWD_NCONST > Mdl::FIN_NCONST ? Mdl::FWD_NCONST : Mdl::FIN_NCONST));
-    static constexpr int BSTRIDE = Mdl::PATH_NVAR | 1;                         // backward pool row (odd -> conflict-free)
+    static constexpr int NCB = Mdl::PATHA_NCONST + Mdl::PATHB_NCONST;          // constants of the two backward groups, A first
+    static constexpr int NC = 1 + (NCB > Mdl::FWD_NCONST ? (NCB > Mdl::FIN_NCONST ? NCB : Mdl::FIN_NCONST)
+                                                         : (Mdl::FWD_NCONST > Mdl::FIN_NCONST ? Mdl::FWD_NCONST : Mdl::FIN_NCONST));
+    static constexpr int NA = Mdl::PATHA_NVAR, NB = Mdl::PATHB_NVAR;           // backward pool row: [patha | pathb | lambda_{t+1} (NX)]
+    static constexpr int LAM = NA + NB;
+    static constexpr int BSTRIDE = (NA + NB + NX) | 1;                         // odd -> conflict-free
     static constexpr int FEXTRA = NX + NU;                                      // x - x_demo, u - u_demo per step
     static constexpr int FSTRIDE = (Mdl::FWD_NVAR + FEXTRA) | 1;
     static constexpr int POOL = CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) > Mdl::FIN_NVAR + 1 ? CH * (BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE) : Mdl::FIN_NVAR + 1;
 };
 
-// pool size in doubles: the aux-matrix pool, or the x/u/lambda staging of the rollout phase, whichever is larger
+// pool size in doubles: the aux-matrix pool, or the x/u staging of the rollout phase, whichever is larger
 template <class Mdl>
 __host__ __device__ inline int fused_pool_doubles(int T) {
-    const int stage = (2 * T + 1) * Mdl::NX + T * Mdl::NU;
+    const int stage = (T + 1) * Mdl::NX + T * Mdl::NU;
     return FusedLayout<Mdl>::POOL > stage ? FusedLayout<Mdl>::POOL : stage;
 }
 template <class Mdl>
@@ -299,12 +302,12 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
 #endif
     PDP_STAMP();
 
-    // ---------------- phase R/C: trajectory and costates (scalar recursions, executed uniformly by all lanes) --------
-    // x and u are staged in the (still unused) LDS pool so that the serial costate loop never waits on HBM/L2.
+    // ---------------- phase R: trajectory x+ = f(x,u,theta) (scalar recursion, executed uniformly by all lanes), staged in the
+    // (still unused) LDS pool and written out coalesced.  The costates are NOT computed here: they are propagated on MFMA
+    // inside the backward chunks (lambda_t = c_x + F_t' lambda_{t+1} with the F_t tiles the Riccati step gathers anyway).
     if (!(flags & PDP_OC_GIVEN_TRAJ)) {
         double* xs = pool;                                   // (T+1) x NX
         double* us = pool + (T + 1) * NX;                    // T x NU
-        double* ls = us + T * NU;                            // T x NX
         for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
         double xc[NX], xn[NX], uc[NU];
 #pragma unroll
@@ -325,30 +328,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
             }
         }
-        double lc[NX], ln[NX];
-        Mdl::dhx(xc, th, pc, lc);                               // lam[T-1] = h_x(x_T)
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) ls[(T - 1) * NX + i] = lc[i];
-        }
         wave_lds_sync();
-        for (int k = T - 1; k >= 1; --k) {                  // lam[k-1] = c_x(x_k,u_k) + f_x' lam[k]
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xs[k * NX + i];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = us[k * NU + i];
-            Mdl::costate_step(xc, uc, lc, th, pc, ln);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) lc[i] = ln[i];
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) ls[(k - 1) * NX + i] = ln[i];
-            }
-        }
-        wave_lds_sync();
-        for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API outputs
-        for (int i = lane; i < T * NX; i += 64) lb[i] = ls[i];
-        __threadfence_block();                               // x / lam are re-read below by other lanes of this wave
+        for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API output
+        __threadfence_block();                               // x is re-read below by other lanes of this wave
         wave_lds_sync();
     }
     PDP_STAMP();
@@ -377,31 +359,84 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     PDP_STAMP();
 
     // ---------------- backward sweep: chunks of CH time steps ------------------------------------------
+    // per chunk: (A) lane = time step evaluates F, G, E, c_x  ->  (C) costates through the chunk on MFMA: lambda_t = c_x + F_t' lambda_{t+1}
+    //            (B) lane = time step evaluates the lambda-weighted Hessians Hxx, Hxu, Hxe, Huu, Hue  ->  Riccati steps
     {
-        if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
-        Gather gF, gY, gHxx, gHX, gHU;
-        make_gather(gF, lane, L::NC, L::BSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, r * NX + c) : -1; });
-        make_gather(gY, lane, L::NC, L::BSTRIDE, [](int r, int c) {
-            return r >= NX ? -1 : (c < M ? Mdl::path_code(1, r * NU + c) : (c < M + NP ? Mdl::path_code(2, r * NP + (c - M)) : -1)); });
-        make_gather(gHxx, lane, L::NC, L::BSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(3, r * NX + c) : -1; });
-        make_gather(gHX, lane, L::NC, L::BSTRIDE, [](int r, int c) {
-            return r >= NX ? -1 : (c < M ? Mdl::path_code(4, r * NU + c) : (c < M + NP ? Mdl::path_code(5, r * NP + (c - M)) : -1)); });
-        make_gather(gHU, lane, L::NC, L::BSTRIDE, [](int r, int c) {
-            return r >= M ? -1 : (c < M ? Mdl::path_code(6, r * NU + c) : (c < M + NP ? Mdl::path_code(7, r * NP + (c - M)) : -1)); });
+        if (lane < Mdl::PATHA_NCONST) blk[1 + lane] = Mdl::patha_const(lane);
+        if (lane < Mdl::PATHB_NCONST) blk[1 + Mdl::PATHA_NCONST + lane] = Mdl::pathb_const(lane);
+        constexpr int NA = L::NA, NCA = Mdl::PATHA_NCONST;
+        auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
+        auto codeB = [](int mat, int i) { int c = Mdl::pathb_code(mat, i); return c >= 0 ? c + NA : (c == -1 ? -1 : c - NCA); };
+        Gather gF, gY, gHxx, gHX, gHU, gCX;
+        make_gather(gF, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+        make_gather(gY, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
+            return r >= NX ? -1 : (c < M ? codeA(1, r * NU + c) : (c < M + NP ? codeA(2, r * NP + (c - M)) : -1)); });
+        make_gather(gCX, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
+        make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
+        make_gather(gHX, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
+            return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
+        make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
+            return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
         const TileMap mKT = make_tile_map(NX, NU, NU, 0, 0, lane), mIK = make_tile_map(NU, NP, NP, 0, M, lane);
+        const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
+        // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
+        d4 Lam = z;
+        if (!given) {
+            double xT[NX], lT[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
+            Mdl::dhx(xT, th, pc, lT);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dlT[i] = lT[i];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX && tile_col(lane) == 0) Lam[r] = dlT[row]; }
+        }
         const int nchunk = (T + CH - 1) / CH;
         for (int c = nchunk - 1; c >= 0; --c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
             wave_lds_sync();
-            if (lane < cnt) {                       // lane = time step: evaluate all path matrices at (x_t, u_t, lambda_{t+1})
+            if (lane < cnt) {                       // (A) lane = time step: F, G, E, c_x at (x_t, u_t)
                 const int t = t0 + lane;
-                double xc[NX], uc[NU], lc[NX];
+                double xc[NX], uc[NU];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; lc[i] = lb[t * NX + i]; }
+                for (int i = 0; i < NX; ++i) xc[i] = xb[t * NX + i];
 #pragma unroll
                 for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
                 PackedSink s{pool + lane * L::BSTRIDE};
-                Mdl::eval_path(xc, uc, lc, th, pc, s);
+                Mdl::eval_patha(xc, uc, nullptr, th, pc, s);
+            }
+            wave_lds_sync();
+            if (!given) {                           // (C) costates through the chunk; pool row tl receives lambda_{t+1}
+                for (int tl = cnt - 1; tl >= 0; --tl) {
+                    if (tile_col(lane) == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) pool[tl * L::BSTRIDE + L::LAM + row] = Lam[r]; }
+                    }
+                    d4 Ft = gather_tile(blk, gF, tl), CX = gather_tile(blk, gCX, tl);
+                    Lam = mma_tn(Ft, Lam, CX);      // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                }
+                wave_lds_sync();
+            }
+            if (lane < cnt) {                       // (B) lane = time step: Hamiltonian Hessians at (x_t, u_t, lambda_{t+1})
+                const int t = t0 + lane;
+                double xc[NX], uc[NU], lc[NX];
+                double* row = pool + lane * L::BSTRIDE;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xc[i] = xb[t * NX + i];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+                if (given) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) lc[i] = lb[t * NX + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { lc[i] = row[L::LAM + i]; lb[t * NX + i] = lc[i]; }      // costate is an API output
+                }
+                PackedSink s{row + NA};
+                Mdl::eval_pathb(xc, uc, lc, th, pc, s);
             }
             wave_lds_sync();
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk)
@@ -420,13 +455,6 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 store_mapped<4>(gw + t * GSZ, mKT, g.KT);
                 store_mapped<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
                 Ft = Ft_n; Y2 = Y2_n; Hxx = Hxx_n; HX2 = HX2_n; HU2 = HU2_n;
-#ifdef PDP_SCHED_PIPELINE
-#pragma unroll
-                for (int q = 0; q < 25; ++q) {               // 1 MFMA, then up to PDP_SCHED_PIPELINE VALU/SALU/DS/VMEM instructions
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x096, PDP_SCHED_PIPELINE, 0);
-                }
-#endif
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
             }
