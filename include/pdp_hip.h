@@ -191,8 +191,10 @@ int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const doub
                           double* dhx, void* stream);
 
 /* ControlPlanning.step (PDP.py:850-878), fused: loss [B] = sum c + h, grad [B][p] = sum_t c_x X_t + c_u U_t + h_x X_T;
- * optional x [B][T+1][n], u [B][T][m] (NULL = not stored).  Provided for PDP_POLICY_POLY (p <= 64); for the MLP policy it
- * returns PDP_E_MODE and the caller composes integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched. */
+ * optional x [B][T+1][n], u [B][T][m] (NULL = not stored).  PDP_POLICY_POLY with p <= 64: forward sensitivities on MFMA tiles
+ * (the reference's own formulation); PDP_POLICY_MLP (<= 8 layers of <= 32 units, p <= 512) and larger Lagrange policies: the same
+ * gradient by one adjoint sweep, O(T (n^2 + p)) instead of O(T n^2 p).  The materialised route of the reference
+ * (integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched) stays available for getAuxSys/integrateAuxSys. */
 int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int theta_bstride,
                         double* loss, double* grad, double* x, double* u, void* stream);
 

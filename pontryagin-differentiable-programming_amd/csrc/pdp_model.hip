@@ -127,7 +127,21 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
             void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_CP && Mdl::NX <= 16 && Mdl::NU <= 4) {
         if (B <= 0 || T <= 0 || !pol || !x0 || !th || !loss || !grad) return PDP_E_ARG;
-        if (pol->kind != PDP_POLICY_POLY) return PDP_E_MODE;
+        if (pol->kind == PDP_POLICY_MLP || p > 64) {          // adjoint (reverse-mode) kernel: MLP policy, or many Lagrange pivots
+            if (p > 512) return PDP_E_SIZE;
+            if (pol->kind == PDP_POLICY_MLP) {
+                int cols = Mdl::NX, cnt = 0;
+                if (pol->n_layers < 1 || pol->n_layers > 8 || Mdl::NX > MLP_MAX_WIDTH) return PDP_E_SIZE;
+                for (int k = 0; k < pol->n_layers; ++k) { if (pol->sizes[k] > MLP_MAX_WIDTH || pol->sizes[k] < 1) return PDP_E_SIZE; cnt += pol->sizes[k] * cols + pol->sizes[k]; cols = pol->sizes[k]; }
+                if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
+            } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
+            const size_t lds = sizeof(double) * (size_t)cp_adjoint_layout<Mdl>(*pol, p, T).total;
+            if (lds > 160 * 1024) return PDP_E_SIZE;
+            (void)hipFuncSetAttribute((const void*)cp_step_adjoint_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            PDP_CLEAR();
+            hipLaunchKernelGGL((cp_step_adjoint_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
+            return launched();
+        }
         if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
         const int nt = (p + 15) / 16;
         switch (nt) {

@@ -733,6 +733,228 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     if (lane == 0) loss[b] = J;
 }
 
+// Fused ControlPlanning.step for ANY policy (tanh MLP up to 8 layers x 32 units, or Lagrange), p <= 512, by the adjoint
+// (reverse-mode) sweep.  The reference propagates the n x p sensitivities X_t forward (PDP.py:826-834, O(T n^2 p)) and
+// contracts them with c_x, c_u, h_x (871-876); the same gradient is
+//     mu_T = h_x ;  v_t = c_u + G_t' mu_{t+1} ;  grad += (d pi/d theta)' v_t ;  mu_t = c_x + F_t' mu_{t+1} + (d pi/d x)' v_t
+// i.e. O(T (n^2 + p)) - for the 420-parameter quadrotor policy 100x less arithmetic and no HBM traffic for sensitivities.
+// One wavefront per trajectory: lanes = MLP rows / state components / parameter slots (8 parameters per lane in registers);
+// activations of the forward pass are kept in LDS for the backward pass; F, G, c_x, c_u come from the lane = time-step
+// chunk evaluation like in the other fused kernels.
+struct AdjLayout { int theta, xs, acts, actw, zs, ds, mu, v, blk, total; };
+template <class Mdl>
+__host__ __device__ inline AdjLayout cp_adjoint_layout(const pdp_policy& pol, int p, int T) {
+    AdjLayout L;
+    int o = 0;
+    L.theta = o; o += p;
+    L.xs = o; o += (T + 1) * Mdl::NX;
+    L.actw = 0;                                        // hidden activations stored per time step (MLP): sum of hidden widths
+    if (pol.kind == PDP_POLICY_MLP) for (int k = 0; k + 1 < pol.n_layers; ++k) L.actw += pol.sizes[k];
+    L.acts = o; o += T * L.actw;
+    L.zs = o; o += 8 * MLP_MAX_WIDTH + 1;              // per-layer inputs z_k of the current step (+ a constant 1.0 for the biases)
+    L.ds = o; o += 8 * MLP_MAX_WIDTH;                  // per-layer deltas of the current step
+    L.mu = o; o += Mdl::NX;
+    L.v = o; o += Mdl::NU + Mdl::NX;                   // v_t, then (d pi/dx)' v_t
+    L.blk = o; o += 1 + Mdl::PATH_NCONST + Mdl::CHUNK * (Mdl::PATH_NVAR | 1);
+    L.total = o + 8;
+    return L;
+}
+
+template <class Mdl>
+__global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0,
+                                                              const double* __restrict__ theta, int tb, double* __restrict__ loss,
+                                                              double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = Mdl::CHUNK, W = MLP_MAX_WIDTH;
+    constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const AdjLayout L = cp_adjoint_layout<Mdl>(pol, p, T);
+    double *ths = lds + L.theta, *xs = lds + L.xs, *acts = lds + L.acts, *zs = lds + L.zs, *ds = lds + L.ds, *mu = lds + L.mu,
+           *vv = lds + L.v, *blk = lds + L.blk, *pool = blk + NC;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const bool mlp = pol.kind == PDP_POLICY_MLP;
+    const int nl = mlp ? pol.n_layers : 0, np = pol.n_pivots;
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
+    for (int i = lane; i < p; i += 64) ths[i] = theta[(int64_t)b * tb + i];
+    if (lane == 0) { blk[0] = 0.0; zs[8 * W] = 1.0; }
+    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    // layer tables (uniform): parameter offset, rows, cols, offset of the stored activations
+    int loff[8], lrows[8], lcols[8], aoff[8];
+    {
+        int cols = NX, off = 0, ao = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            loff[k] = off; lcols[k] = cols; lrows[k] = (k < nl) ? pol.sizes[k] : 0; aoff[k] = ao;
+            if (k < nl) { off += lrows[k] * cols + lrows[k]; if (k + 1 < nl) ao += lrows[k]; cols = lrows[k]; }
+        }
+    }
+    // per-lane parameter slots q = 0..7 (parameter index lane + 64 q): LDS offsets of the two factors of d cost / d theta_j
+    int pr[8], pz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        pr[q] = L.ds; pz[q] = L.blk;                   // blk[0] == 0.0 -> contributes nothing
+        if (j < p) {
+            if (mlp) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k < nl && j >= loff[k] && j < loff[k] + lrows[k] * lcols[k] + lrows[k]) {
+                        const int e = j - loff[k], nw = lrows[k] * lcols[k];
+                        if (e < nw) { pr[q] = L.ds + k * W + e % lrows[k]; pz[q] = L.zs + k * W + e / lrows[k]; }     // vec_F(A_k): row + col*rows
+                        else { pr[q] = L.ds + k * W + (e - nw); pz[q] = L.zs + 8 * W; }                             // bias: factor 1.0
+                    }
+                }
+            } else { pr[q] = L.ds + j % NU; pz[q] = L.zs + j / NU; }       // theta = vcat(U_0..U_N): delta = v[j % m], factor = b_{j / m}(t)
+        }
+    }
+    wave_lds_sync();
+
+    // policy forward at time t from xs[t]: leaves layer inputs in zs, pre-activation deltas untouched; returns u in vv[0..NU)
+    auto policy_forward = [&](int t, bool store_acts) {
+        if (!mlp) {
+            if (lane < np) zs[lane] = lagrange_basis(pol, lane, (double)t);
+            wave_lds_sync();
+            if (lane < NU) { double u = 0.0; for (int i = 0; i < np; ++i) u += zs[i] * ths[i * NU + lane]; vv[lane] = u; }
+            wave_lds_sync();
+            return;
+        }
+        if (lane < NX) zs[lane] = xs[t * NX + lane];
+        wave_lds_sync();
+        for (int k = 0; k < nl; ++k) {
+            const int rows = lrows[k], cols = lcols[k];
+            double a = 0.0;
+            if (lane < rows) {
+                a = ths[loff[k] + rows * cols + lane];
+                for (int c = 0; c < cols; ++c) a += ths[loff[k] + lane + c * rows] * zs[k * W + c];
+            }
+            if (k + 1 < nl) {
+                double zk = tanh(a);
+                if (lane < rows) { zs[(k + 1) * W + lane] = zk; if (store_acts) acts[t * L.actw + aoff[k] + lane] = zk; }
+            } else if (lane < NU) vv[lane] = a;
+            wave_lds_sync();
+        }
+    };
+
+    // ---------------- forward rollout
+    double J = 0.0;
+    {
+        double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+        }
+        wave_lds_sync();
+        for (int t = 0; t < T; ++t) {
+            policy_forward(t, true);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uc[j] = vv[j];
+            if (uo && lane < NU) uo[((int64_t)b * T + t) * NU + lane] = vv[lane];
+            Mdl::dyn(xc, uc, nullptr, pc, xn);
+            J += Mdl::path_cost(xc, uc, nullptr, pc);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+            }
+            wave_lds_sync();
+        }
+        J += Mdl::final_cost(xc, nullptr, pc);
+        double h[NX];
+        Mdl::dhx(xc, nullptr, pc, h);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) mu[i] = h[i];
+        }
+        wave_lds_sync();
+    }
+    if (xo) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
+
+    // ---------------- adjoint sweep
+    double gacc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gacc[q] = 0.0;
+    // per-lane pool offsets: column `lane` of F (lane < NX) and of G (lane < NU), entries c_x[lane], c_u[lane]
+    int fo[NX], fm[NX], go[NX], gm[NX], cxo = 0, cxm = 0, cuo = 0, cum = 0;
+    auto enc = [&](int code, int& o, int& m) { if (code >= 0) { o = NC + code; m = STRIDE; } else { o = (code == -1) ? 0 : 1 + (-2 - code); m = 0; } };
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        enc(lane < NX ? Mdl::path_code(0, k * NX + lane) : -1, fo[k], fm[k]);
+        enc(lane < NU ? Mdl::path_code(1, k * NU + lane) : -1, go[k], gm[k]);
+    }
+    enc(lane < NX ? Mdl::path_code(2, lane) : -1, cxo, cxm);
+    enc(lane < NU ? Mdl::path_code(3, lane) : -1, cuo, cum);
+    const int nchunk = (T + CH - 1) / CH;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int t0 = c * CH, cnt = min(CH, T - t0);
+        wave_lds_sync();
+        if (lane < cnt) {
+            const int t = t0 + lane;
+            double xc[NX], uc[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xs[t * NX + i];
+            // u_t is re-derived from the stored trajectory through the policy only for the MLP (cheap for the polynomial)
+            if (!mlp) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { double u = 0.0; for (int i = 0; i < np; ++i) u += lagrange_basis(pol, i, (double)t) * ths[i * NU + j]; uc[j] = u; }
+            } else {
+                policy_eval<NX, NU>(pol, t, xc, ths, uc);
+            }
+            PackedSink sk{pool + lane * STRIDE};
+            Mdl::eval_path(xc, uc, nullptr, nullptr, pc, sk);
+        }
+        wave_lds_sync();
+        for (int tl = cnt - 1; tl >= 0; --tl) {
+            const int t = t0 + tl;
+            // v = c_u + G' mu
+            if (lane < NU) {
+                double a = blk[cuo + tl * cum];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) a += blk[go[k] + tl * gm[k]] * mu[k];
+                vv[lane] = a;
+            }
+            wave_lds_sync();
+            // policy backward: deltas per layer into ds, layer inputs into zs
+            if (!mlp) {
+                if (lane < np) zs[lane] = lagrange_basis(pol, lane, (double)t);
+                if (lane < NU) ds[lane] = vv[lane];
+                if (lane < NX) vv[NU + lane] = 0.0;                   // d pi/dx = 0
+                wave_lds_sync();
+            } else {
+                if (lane < NX) zs[lane] = xs[t * NX + lane];
+                for (int k = 1; k < nl; ++k) if (lane < lrows[k - 1]) zs[k * W + lane] = acts[t * L.actw + aoff[k - 1] + lane];
+                if (lane < NU) ds[(nl - 1) * W + lane] = vv[lane];
+                wave_lds_sync();
+                for (int k = nl - 1; k >= 0; --k) {
+                    const int rows = lrows[k], cols = lcols[k];
+                    double a = 0.0;
+                    if (lane < cols) for (int r = 0; r < rows; ++r) a += ths[loff[k] + r + lane * rows] * ds[k * W + r];      // A_k' delta_k
+                    if (k > 0) { if (lane < cols) { double zk = zs[k * W + lane]; ds[(k - 1) * W + lane] = a * (1.0 - zk * zk); } }
+                    else if (lane < NX) vv[NU + lane] = a;                                                                     // (d pi/dx)' v
+                    wave_lds_sync();
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gacc[q] += lds[pr[q]] * lds[pz[q]];
+            // mu_t = c_x + F' mu_{t+1} + (d pi/dx)' v
+            double m_new = 0.0;
+            if (lane < NX) {
+                m_new = blk[cxo + tl * cxm] + vv[NU + lane];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) m_new += blk[fo[k] + tl * fm[k]] * mu[k];
+            }
+            wave_lds_sync();
+            if (lane < NX) mu[lane] = m_new;
+            wave_lds_sync();
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int j = lane + 64 * q; if (j < p) grad[(int64_t)b * p + j] = gacc[q]; }
+    if (lane == 0) loss[b] = J;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // SysID (PDP_KIND_SYSID)
 // ------------------------------------------------------------------------------------------------------

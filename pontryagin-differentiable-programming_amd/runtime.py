@@ -388,17 +388,27 @@ class ModelLib:
         x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda") if want_traj else None
         u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda") if want_traj else None
         rc = self.lib.pdp_cp_step_batched(B, int(T), C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(loss), ptr(grad), ptr(x), ptr(u), current_stream_ptr())
-        if rc == -4 and pol.kind == 1:          # MLP: integrate -> auxsys -> aux integrate (MFMA) -> chain rule
-            x, u, loss = self.cp_integrate_T(pol, p, x0, th, T)
-            aux = self.cp_auxsys(pol, p, x, u, th)
-            X, U = cp_aux_integrate(aux["dynF"], aux["dynG"], aux["dUx"], aux["dUe"])
-            lib = load_core()
-            lib.pdp_cp_grad_contract_batched.restype = C.c_int
-            lib.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
-            check(lib.pdp_cp_grad_contract_batched(B, int(T), self.n, self.m, p, ptr(aux["dcx"]), ptr(aux["dcu"]), ptr(aux["dhx"]), ptr(X), ptr(U),
-                                                   ptr(grad), current_stream_ptr()), "pdp_cp_grad_contract_batched")
-            return (loss, grad, x, u) if want_traj else (loss, grad)
+        if rc == -2 and pol.kind == 1:          # policy outside the fused kernel's limits: the reference's materialised route
+            return self.cp_step_materialised(pol, p, x0, th, T, want_traj)
         check(rc, "pdp_cp_step_batched")
+        return (loss, grad, x, u) if want_traj else (loss, grad)
+
+    def cp_step_materialised(self, pol, p, x0, theta, T, want_traj=False):
+        """ControlPlanning.step exactly as the reference composes it (PDP.py:850-878): integrateSys -> getAuxSys ->
+        integrateAuxSys (forward sensitivities, MFMA tiles over the parameter dimension) -> chain rule; every stage materialised in HBM."""
+        torch = torch_cuda()
+        x0 = dev(x0).reshape(-1, self.n)
+        B = x0.shape[0]
+        th, tb = self._theta(theta, B, p)
+        x, u, loss = self.cp_integrate_T(pol, p, x0, th, T)
+        aux = self.cp_auxsys(pol, p, x, u, th)
+        X, U = cp_aux_integrate(aux["dynF"], aux["dynG"], aux["dUx"], aux["dUe"])
+        grad = torch.empty((B, p), dtype=torch.float64, device="cuda")
+        lib = load_core()
+        lib.pdp_cp_grad_contract_batched.restype = C.c_int
+        lib.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
+        check(lib.pdp_cp_grad_contract_batched(B, int(T), self.n, self.m, p, ptr(aux["dcx"]), ptr(aux["dcu"]), ptr(aux["dhx"]), ptr(X), ptr(U),
+                                               ptr(grad), current_stream_ptr()), "pdp_cp_grad_contract_batched")
         return (loss, grad, x, u) if want_traj else (loss, grad)
 
     # -- SysID

@@ -210,6 +210,20 @@ def test_control_planning_matches_reference_run(golden_dir, tag):
     assert rel(npy(grad)[0], g["grad"]) < 1e-10
 
 
+def test_adjoint_and_materialised_forward_mode_step_agree(golden_dir):
+    """the fused adjoint kernel (MLP policy) and the reference's materialised forward-sensitivity route give the same gradient"""
+    g = load(golden_dir, "ref_cp_quadrotor_mlp.npz")
+    mdl, pol, T = _cp_setup(g, "quadrotor_mlp")
+    p = g["theta"].size
+    rng = np.random.default_rng(5)
+    x0 = np.tile(g["x0"], (6, 1)) + 0.1 * rng.standard_normal((6, 13))
+    theta = g["theta"][None] + 0.05 * rng.standard_normal((6, p))
+    l1, g1 = mdl.cp_step(pol, p, x0, theta, T)
+    l2, g2 = mdl.cp_step_materialised(pol, p, x0, theta, T)
+    assert rel(npy(l1), npy(l2)) < 1e-12 and rel(npy(g1), npy(g2)) < TOL
+    assert rel(npy(g1)[0:1], npy(mdl.cp_step(pol, p, x0[0:1], theta[0:1], T)[1])) == 0.0
+
+
 def test_control_planning_batch_matches_oracle():
     from oracle import models, pdp_oracle as po
     from pdp_amd import runtime as rt, zoo
