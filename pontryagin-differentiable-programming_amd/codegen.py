@@ -356,8 +356,10 @@ def write_header(problem):
     os.makedirs(GEN_DIR, exist_ok=True)
     path = header_path(info["name"])
     if not os.path.exists(path) or open(path).read() != src:
-        with open(path, "w") as f:
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
             f.write(src)
+        os.replace(tmp, path)
     return path, info
 
 
@@ -377,7 +379,9 @@ def compile_model(name, force=False):
         return out
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
-    _run([HIPCC] + HIP_FLAGS + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip"), "-o", out])
+    tmp = "%s.%d.tmp" % (out, os.getpid())           # several ranks may build the same model at once: write aside, rename atomically
+    _run([HIPCC] + HIP_FLAGS + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip"), "-o", tmp])
+    os.replace(tmp, out)
     return out
 
 
@@ -387,7 +391,9 @@ def compile_core(force=False):
     deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_riccati.h", "pdp_tile.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
-    _run([HIPCC] + HIP_FLAGS + ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip"), "-o", out])
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    _run([HIPCC] + HIP_FLAGS + ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip"), "-o", tmp])
+    os.replace(tmp, out)
     return out
 
 
