@@ -45,9 +45,21 @@ def make_problem(system, mode):
     return codegen.Problem(codegen.KIND_CP, env.X, env.U, dyn, None, env.path_cost, env.final_cost, label=system)
 
 
-def build_all(force=False):
+def build_all(force=False, prune=True):
+    """generate + compile every zoo model in-tree; `prune` removes generated headers / libraries of zoo systems left over from
+    older versions of the generator (their content hash no longer matches), so the tree only carries the current set."""
+    import glob
+    import os
     problems = [make_problem(s, m) for (s, m) in SPECS]
     res = codegen.build_many(problems, force=force)
+    if prune:
+        keep = set(info["name"] for _, info in res)
+        systems = set(s for s, _ in SPECS)
+        for path in glob.glob(os.path.join(codegen.GEN_DIR, "*.h")) + glob.glob(os.path.join(codegen.LIB_DIR, "libpdp_model_*.so")):
+            name = os.path.basename(path)
+            name = name[len("libpdp_model_"):-3] if name.endswith(".so") else name[:-2]
+            if name not in keep and name.split("_")[0] in systems and name.rsplit("_", 2)[-2] in ("oc", "cp", "sysid"):
+                os.remove(path)
     return {key: r for key, r in zip(SPECS, res)}
 
 
