@@ -219,6 +219,21 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
 // OC: fused forward + costates + aux system (LDS) + Riccati + PDP gradient, one wavefront per trajectory
 // ------------------------------------------------------------------------------------------------------
 struct Gather { int off[4]; int tmul[4]; };
+// running form: cur[r] is the LDS offset (in doubles) of the element for the current step; step() moves it by one time step
+struct GatherRun { int cur[4]; int tmul[4]; };
+PDP_DEV GatherRun gather_at(const Gather& g, int tl) {
+    GatherRun r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { r.cur[k] = g.off[k] + tl * g.tmul[k]; r.tmul[k] = g.tmul[k]; }
+    return r;
+}
+template <int NR = 4>
+PDP_DEV d4 gather_run(const double* lds, GatherRun& g, int dir) {      // read, then advance by dir (+1 / -1) time steps
+    d4 v = zero4();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { v[k] = lds[g.cur[k]]; g.cur[k] += dir * g.tmul[k]; }
+    return v;
+}
 
 // offsets (in doubles, relative to the LDS block [cpool | pool]) of tile element (lane, r)
 template <class CodeFn>
@@ -439,14 +454,20 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 Mdl::eval_pathb(xc, uc, lc, th, pc, s);
             }
             wave_lds_sync();
-            // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk)
-            d4 Ft = gather_tile(blk, gF, cnt - 1), Y2 = gather_tile(blk, gY, cnt - 1), Hxx = gather_tile(blk, gHxx, cnt - 1),
-               HX2 = gather_tile(blk, gHX, cnt - 1), HU2 = gather_tile_r0(blk, gHU, cnt - 1);
+            // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
+            GatherRun rF = gather_at(gF, cnt - 1), rY = gather_at(gY, cnt - 1), rHxx = gather_at(gHxx, cnt - 1), rHX = gather_at(gHX, cnt - 1),
+                      rHU = gather_at(gHU, cnt - 1);
+            const int d0 = cnt > 1 ? -1 : 0;
+            d4 Ft = gather_run(blk, rF, d0), Y2 = gather_run(blk, rY, d0), Hxx = gather_run(blk, rHxx, d0), HX2 = gather_run(blk, rHX, d0),
+               HU2 = gather_run<1>(blk, rHU, d0);
+#pragma unroll 2
             for (int tl = cnt - 1; tl >= 0; --tl) {
-                const int t = t0 + tl, tn = tl > 0 ? tl - 1 : 0;
+                const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
-                d4 Ft_n = gather_tile(blk, gF, tn), Y2_n = gather_tile(blk, gY, tn), Hxx_n = gather_tile(blk, gHxx, tn),
-                   HX2_n = gather_tile(blk, gHX, tn), HU2_n = gather_tile_r0(blk, gHU, tn);
+                // the prefetch reads row tl-1; the offsets stop at row 0 (the last prefetch of a chunk re-reads row 0, unused)
+                const int dir = tl > 1 ? -1 : 0;
+                d4 Ft_n = gather_run(blk, rF, dir), Y2_n = gather_run(blk, rY, dir), Hxx_n = gather_run(blk, rHxx, dir),
+                   HX2_n = gather_run(blk, rHX, dir), HU2_n = gather_run<1>(blk, rHU, dir);
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
