@@ -370,31 +370,43 @@ def _run(cmd):
     return r.stdout
 
 
-def compile_model(name, force=False):
-    """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
+def _stamp_of(deps, flags):
+    """content hash of everything a library is built from (sources, headers, flags): decides rebuilds, not file mtimes - the
+    snapshot copied to a GPU box carries arbitrary mtimes, and 8 ranks must not all decide to rebuild because of them"""
+    h = hashlib.sha1(" ".join(flags).encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _build(out, deps, cmd_tail, force):
     os.makedirs(LIB_DIR, exist_ok=True)
-    hdr, out = header_path(name), lib_path(name)
-    deps = [hdr] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+    stamp_path = out + ".stamp"
+    stamp = _stamp_of(deps, HIP_FLAGS + cmd_tail[:-1])
+    if not force and os.path.exists(out) and os.path.exists(stamp_path) and open(stamp_path).read().strip() == stamp:
         return out
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
-    tmp = "%s.%d.tmp" % (out, os.getpid())           # several ranks may build the same model at once: write aside, rename atomically
-    _run([HIPCC] + HIP_FLAGS + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip"), "-o", tmp])
+    tmp = "%s.%d.tmp" % (out, os.getpid())           # several ranks may build the same library at once: write aside, rename atomically
+    _run([HIPCC] + HIP_FLAGS + cmd_tail + ["-o", tmp])
     os.replace(tmp, out)
+    with open(stamp_path + ".%d.tmp" % os.getpid(), "w") as f:
+        f.write(stamp)
+    os.replace(stamp_path + ".%d.tmp" % os.getpid(), stamp_path)
     return out
+
+
+def compile_model(name, force=False):
+    """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
+    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
+    return _build(lib_path(name), deps, ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)
 
 
 def compile_core(force=False):
-    os.makedirs(LIB_DIR, exist_ok=True)
-    out = os.path.join(LIB_DIR, "libpdp_hip.so")
-    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_riccati.h", "pdp_tile.h")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
-    tmp = "%s.%d.tmp" % (out, os.getpid())
-    _run([HIPCC] + HIP_FLAGS + ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip"), "-o", tmp])
-    os.replace(tmp, out)
-    return out
+    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_riccati.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
+    return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force)
 
 
 def build_problem(problem, force=False):

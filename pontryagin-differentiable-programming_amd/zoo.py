@@ -60,6 +60,8 @@ def build_all(force=False, prune=True):
             name = name[len("libpdp_model_"):-3] if name.endswith(".so") else name[:-2]
             if name not in keep and name.split("_")[0] in systems and name.rsplit("_", 2)[-2] in ("oc", "cp", "sysid"):
                 os.remove(path)
+                if os.path.exists(path + ".stamp"):
+                    os.remove(path + ".stamp")
     return {key: r for key, r in zip(SPECS, res)}
 
 
