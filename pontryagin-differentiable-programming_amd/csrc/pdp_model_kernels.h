@@ -279,7 +279,7 @@ __host__ __device__ inline int fused_pool_doubles(int T) {
 }
 template <class Mdl>
 __host__ __device__ inline size_t fused_lds_bytes(int T) {
-    return sizeof(double) * (size_t)(RICCATI_SCRATCH + FusedLayout<Mdl>::NC + fused_pool_doubles<Mdl>(T) + Mdl::NX + 8);
+    return sizeof(double) * (size_t)(RICCATI_SCRATCH + FusedLayout<Mdl>::NC + fused_pool_doubles<Mdl>(T) + Mdl::NX + Mdl::NP + Mdl::NPC + 8);
 }
 
 template <class Mdl>
@@ -298,10 +298,25 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     double* dlT = pool + fused_pool_doubles<Mdl>(T);    // x_T - xdemo_T (NX)
     const int b = blockIdx.x, lane = threadIdx.x;
     const d4 z = zero4();
-    double th[NP];
-    load_theta<Mdl>(theta, b, tb, th);
-    double pc[Mdl::NPC];
-    Mdl::precompute(th, pc);
+    // theta and the theta-only precomputed values are parked in LDS and re-read inside every block of generated scalar code:
+    // kept in registers they would occupy 2 (NP + NPC) VGPRs for the whole kernel, which sits at the 256-VGPR ceiling
+    double* par = dlT + NX;                             // [theta (NP) | pc (NPC)]
+    {
+        double th0[NP], pc0[Mdl::NPC];
+        load_theta<Mdl>(theta, b, tb, th0);
+        Mdl::precompute(th0, pc0);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) par[i] = th0[i];
+#pragma unroll
+            for (int i = 0; i < Mdl::NPC; ++i) par[NP + i] = pc0[i];
+        }
+        wave_lds_sync();
+    }
+#define PDP_LOAD_PAR()                                              \
+    double th[NP], pc[Mdl::NPC];                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) th[i_] = par[i_]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < Mdl::NPC; ++i_) pc[i_] = par[NP + i_]
     double* xb = x + (int64_t)b * (T + 1) * NX;
     double* lb = lam + (int64_t)b * T * NX;
     const double* ub = u + (int64_t)b * T * NU;
@@ -324,6 +339,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         double* xs = pool;                                   // (T+1) x NX
         double* us = pool + (T + 1) * NX;                    // T x NU
         for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
+        PDP_LOAD_PAR();
         double xc[NX], xn[NX], uc[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
@@ -357,6 +373,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         if (lane == 0) blk[0] = 0.0;
         if (lane < Mdl::FIN_NCONST) blk[1 + lane] = Mdl::fin_const(lane);
         if (lane == 0) {
+            PDP_LOAD_PAR();
             double xT[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
@@ -397,6 +414,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
         if (!given) {
+            PDP_LOAD_PAR();
             double xT[NX], lT[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
@@ -414,6 +432,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             const int t0 = c * CH, cnt = min(CH, T - t0);
             wave_lds_sync();
             if (lane < cnt) {                       // (A) lane = time step: F, G, E, c_x at (x_t, u_t)
+                PDP_LOAD_PAR();
                 const int t = t0 + lane;
                 double xc[NX], uc[NU];
 #pragma unroll
@@ -436,6 +455,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 wave_lds_sync();
             }
             if (lane < cnt) {                       // (B) lane = time step: Hamiltonian Hessians at (x_t, u_t, lambda_{t+1})
+                PDP_LOAD_PAR();
                 const int t = t0 + lane;
                 double xc[NX], uc[NU], lc[NX];
                 double* row = pool + lane * L::BSTRIDE;
@@ -508,6 +528,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             const int t0 = c * CH, cnt = min(CH, T - t0);
             wave_lds_sync();
             if (lane < cnt) {
+                PDP_LOAD_PAR();
                 const int t = t0 + lane;
                 double xc[NX], uc[NU];
                 double* row = pool + lane * L::FSTRIDE;
