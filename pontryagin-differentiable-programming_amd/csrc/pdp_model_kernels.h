@@ -220,18 +220,18 @@ __global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, con
 // ------------------------------------------------------------------------------------------------------
 struct Gather { int off[4]; int tmul[4]; };
 // running form: cur[r] is the LDS offset (in doubles) of the element for the current step; step() moves it by one time step
-struct GatherRun { int cur[4]; int tmul[4]; };
+struct GatherRun { int cur[4]; int tmul[4]; };      // BYTE offsets from `lds`: the ds_read address is the register itself, no shift/add per read
 PDP_DEV GatherRun gather_at(const Gather& g, int tl) {
     GatherRun r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { r.cur[k] = g.off[k] + tl * g.tmul[k]; r.tmul[k] = g.tmul[k]; }
+    for (int k = 0; k < 4; ++k) { r.cur[k] = 8 * (g.off[k] + tl * g.tmul[k]); r.tmul[k] = 8 * g.tmul[k]; }
     return r;
 }
 template <int NR = 4>
 PDP_DEV d4 gather_run(const double* lds, GatherRun& g, int dir) {      // read, then advance by dir (+1 / -1) time steps
     d4 v = zero4();
 #pragma unroll
-    for (int k = 0; k < NR; ++k) { v[k] = lds[g.cur[k]]; g.cur[k] += dir * g.tmul[k]; }
+    for (int k = 0; k < NR; ++k) { v[k] = *(const double*)((const char*)lds + g.cur[k]); g.cur[k] += dir * g.tmul[k]; }
     return v;
 }
 
