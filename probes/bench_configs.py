@@ -43,5 +43,14 @@ t0 = time.perf_counter(); sol = ocsolver.solve_batch(oc, x0, T, theta, warm_star
 dt = timeit(lambda: oc.pdp_grad_batch(sol["control"], theta, demo["state"], demo["control"], state_traj=sol["state"], costate_traj=sol["costate"]))
 res["C2 cart-pole aux+Riccati+grad (given optimum) T=50 p=7 B=256"] = (B / dt, dt * 1e3)
 res["C2 cart-pole OC solve, closed-loop warm start, %d iterations, B=256" % sol["iterations"]] = (B / t_solve, t_solve * 1e3)
+# materialised API route of the reference on C3 sizes: getAuxSys (dense matrices to HBM) then lqrSolver (dense matrices from HBM)
+mdl = zoo.get("quadrotor", "irl"); B, T = 1024, 50
+import bench as _b
+x0, u, dx, du = (rt.dev(a) for a in _b.synth_inputs(B, 7)); th = rt.dev(np.array(_b.THETA))
+x, _ = mdl.oc_rollout(x0, u, th); lam = mdl.oc_costate(x, u, th)
+dt = timeit(lambda: mdl.oc_auxsys(x, u, lam, th)); res["C3 materialised OCSys.getAuxSys (all 11 families to HBM), quadrotor T=50 B=1024"] = (B / dt, dt * 1e3)
+aux = mdl.oc_auxsys(x, u, lam, th)
+dt = timeit(lambda: rt.lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], aux["hxe"], E=aux["dynE"], Hxu=aux["Hxu"], Hxe=aux["Hxe"], Hue=aux["Hue"]))
+res["C3 materialised LQR.lqrSolver (X,U,Lambda out), quadrotor T=50 p=9 B=1024"] = (B / dt, dt * 1e3)
 for k, (v, ms) in res.items(): print("%-82s %12.0f traj/s  %9.3f ms" % (k, v, ms))
 json.dump({k: {"traj_per_s": v, "ms": ms} for k, (v, ms) in res.items()}, open("gpurun_out/bench_configs.json", "w"), indent=1)
