@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -36,3 +37,10 @@ def test_sysid_example_recovers_parameter():
     assert "done:" in out
     first, last = [float(v) for v in out.split("loss ")[-1].split(";")[0].split(" -> ")]
     assert last < 0.1 * first, out
+
+
+def test_multi_gpu_example_runs_single_process():
+    out = run("irl_pdp_multi_gpu.py", "--batch", "512", "--iters", "6")
+    assert "done: 6 iterations x 512 trajectories on 1 GPU(s)" in out
+    first = float(out.split("mean loss")[1].split()[0])
+    assert np.isfinite(first)
