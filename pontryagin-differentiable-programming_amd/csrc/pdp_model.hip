@@ -64,9 +64,9 @@ template <class Mdl>
 int oc_auxsys(int B, int T, const double* x, const double* u, const double* lam, const double* th, int tb, const pdp_oc_auxsys* o, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_OC) {
         if (B <= 0 || T <= 0 || !x || !u || !lam || !th || !o) return PDP_E_ARG;
-        const int64_t n = (int64_t)B * (T + 1);
+        const int nchunk = (T + Mdl::CHUNK - 1) / Mdl::CHUNK;
         PDP_CLEAR();
-        hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, x, u, lam, th, tb, *o);
+        hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), dim3((unsigned)((int64_t)B * (nchunk + 1))), dim3(64), 0, S(st), B, T, x, u, lam, th, tb, *o);
         return launched();
     } else { return PDP_E_MODE; }
 }

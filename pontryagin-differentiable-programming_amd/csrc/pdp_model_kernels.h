@@ -152,67 +152,107 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
     }
 }
 
-template <class Mdl>
-PDP_DEV void fill_static(double* dst, int mat, int count, bool fin) {
-    if (!dst) return;
-    for (int i = 0; i < count; ++i) {
-        int code = fin ? Mdl::fin_code(mat, i) : Mdl::path_code(mat, i);
-        if (code < 0) dst[i] = (code == -1) ? 0.0 : (fin ? Mdl::fin_const(-2 - code) : Mdl::path_const(-2 - code));
+// OCSys.getAuxSys, materialised.  One wavefront per (trajectory, chunk of CHUNK time steps): lane = time step evaluates the
+// generated code into the packed LDS pool (as in the fused kernel), then the wave expands every matrix family into the dense
+// API layout [B][T][rows][cols] with COALESCED stores - the chunk's slice of a family is one contiguous run of cnt*rows*cols
+// doubles.  (A lane-per-(b,t) scatter of 5.8 KB per thread ran at 1.3 TB/s of 8-byte stores; this form is bound by the
+// 314 KB per trajectory it has to write.)
+template <class Mdl, int MAT>
+PDP_DEV void auxsys_expand(const double* blk, const short* codes, int nc, int stride, int cnt, double* __restrict__ dst, int lane) {
+    constexpr int RC = Mdl::PATH_ROWS[MAT] * Mdl::PATH_COLS[MAT];
+    if (!dst || RC == 0) return;
+    for (int q = lane; q < cnt * RC; q += 64) {
+        const int tl = q / RC, i = q - tl * RC;
+        const int code = codes[i];
+        dst[q] = code >= 0 ? blk[nc + tl * stride + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
     }
 }
 
 template <class Mdl>
-__global__ void oc_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ lam,
-                                 const double* __restrict__ theta, int tb, pdp_oc_auxsys o) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (int64_t)B * (T + 1)) return;
-    const int b = (int)(g / (T + 1)), t = (int)(g % (T + 1));
+__global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u,
+                                                        const double* __restrict__ lam, const double* __restrict__ theta, int tb, pdp_oc_auxsys o) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+    constexpr int NC = 1 + (Mdl::PATH_NCONST > Mdl::FIN_NCONST ? Mdl::PATH_NCONST : Mdl::FIN_NCONST), STRIDE = Mdl::PATH_NVAR | 1;
+    constexpr int NCODE = NX * NX + NX * NU + NX * NP + NX * NX + NX * NU + NX * NP + NU * NU + NU * NP;   // entries of the 8 path families
+    __shared__ double blk[NC + CH * STRIDE + Mdl::FIN_NVAR + 8];
+    __shared__ short codes[NCODE > NX * NX + NX * NP ? NCODE : NX * NX + NX * NP];
+    const int nchunk = (T + CH - 1) / CH;
+    const int b = blockIdx.x / (nchunk + 1), c = blockIdx.x % (nchunk + 1), lane = threadIdx.x;
     double th[NP > 0 ? NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
     double pc[Mdl::NPC];
     Mdl::precompute(th, pc);
-    double xc[NX], uc[NU], lc[NX];
+    if (lane == 0) blk[0] = 0.0;
+    if (c == nchunk) {                                       // terminal matrices hxx, hxe at x_T (PDP.py:300-301)
+        if (lane < Mdl::FIN_NCONST) blk[1 + lane] = Mdl::fin_const(lane);
+        for (int i = lane; i < NX * NX; i += 64) codes[i] = (short)Mdl::fin_code(0, i);
+        for (int i = lane; i < NX * NP; i += 64) codes[NX * NX + i] = (short)Mdl::fin_code(1, i);
+        if (lane == 0) {
+            double xT[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xc[i] = x[((int64_t)b * (T + 1) + t) * NX + i];
-    if (t == T) {                                          // terminal matrices hxx, hxe at x_T (PDP.py:300-301)
-        OcFinDense<Mdl> s;
-        s.p[0] = o.hxx ? o.hxx + (int64_t)b * NX * NX : nullptr;
-        s.p[1] = o.hxe ? o.hxe + (int64_t)b * NX * NP : nullptr;
-        fill_static<Mdl>(s.p[0], 0, NX * NX, true);
-        fill_static<Mdl>(s.p[1], 1, NX * NP, true);
-        Mdl::eval_fin(xc, nullptr, nullptr, th, pc, s);
+            for (int i = 0; i < NX; ++i) xT[i] = x[((int64_t)b * (T + 1) + T) * NX + i];
+            PackedSink s{blk + NC};
+            Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
+        }
+        __syncthreads();
+        for (int m2 = 0; m2 < 2; ++m2) {
+            double* dst = m2 == 0 ? o.hxx : o.hxe;
+            const int rc = m2 == 0 ? NX * NX : NX * NP, co = m2 == 0 ? 0 : NX * NX;
+            if (!dst) continue;
+            for (int q = lane; q < rc; q += 64) {
+                const int code = codes[co + q];
+                dst[(int64_t)b * rc + q] = code >= 0 ? blk[NC + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
+            }
+        }
         return;
     }
-    const int64_t bt = (int64_t)b * T + t;
+    const int t0 = c * CH, cnt = min(CH, T - t0);
+    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    {
+        int base = 0;
 #pragma unroll
-    for (int i = 0; i < NU; ++i) uc[i] = u[bt * NU + i];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) lc[i] = lam[bt * NX + i];
-    OcPathDense<Mdl> s;
-    s.p[0] = o.dynF ? o.dynF + bt * NX * NX : nullptr;
-    s.p[1] = o.dynG ? o.dynG + bt * NX * NU : nullptr;
-    s.p[2] = o.dynE ? o.dynE + bt * NX * NP : nullptr;
-    s.p[3] = o.Hxx ? o.Hxx + bt * NX * NX : nullptr;
-    s.p[4] = o.Hxu ? o.Hxu + bt * NX * NU : nullptr;
-    s.p[5] = o.Hxe ? o.Hxe + bt * NX * NP : nullptr;
-    s.p[6] = o.Huu ? o.Huu + bt * NU * NU : nullptr;
-    s.p[7] = o.Hue ? o.Hue + bt * NU * NP : nullptr;
-    s.p[8] = o.Hux ? o.Hux + bt * NU * NX : nullptr;
-    if (o.dHu) {
-        double hu[NU];
-        Mdl::dHu(xc, uc, lc, th, pc, hu);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) o.dHu[bt * NU + i] = hu[i];
-    }
-    for (int mat = 0; mat < 8; ++mat) fill_static<Mdl>(s.p[mat], mat, Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat], false);
-    if (s.p[8]) {
-        for (int i = 0; i < NX * NU; ++i) {
-            int code = Mdl::path_code(4, i);
-            if (code < 0) s.p[8][(i % NU) * NX + i / NU] = (code == -1) ? 0.0 : Mdl::path_const(-2 - code);
+        for (int mat = 0; mat < 8; ++mat) {
+            const int rc = Mdl::PATH_ROWS[mat] * Mdl::PATH_COLS[mat];
+            for (int i = lane; i < rc; i += 64) codes[base + i] = (short)Mdl::path_code(mat, i);
+            base += rc;
         }
     }
-    Mdl::eval_path(xc, uc, lc, th, pc, s);
+    const int64_t bt0 = (int64_t)b * T + t0;
+    if (lane < cnt) {
+        const int64_t bt = bt0 + lane;
+        double xc[NX], uc[NU], lc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = x[((int64_t)b * (T + 1) + t0 + lane) * NX + i]; lc[i] = lam[bt * NX + i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uc[i] = u[bt * NU + i];
+        PackedSink s{blk + NC + lane * STRIDE};
+        Mdl::eval_path(xc, uc, lc, th, pc, s);
+        if (o.dHu) {
+            double hu[NU];
+            Mdl::dHu(xc, uc, lc, th, pc, hu);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) o.dHu[bt * NU + i] = hu[i];
+        }
+    }
+    __syncthreads();
+    constexpr int oF = 0, oG = oF + NX * NX, oE = oG + NX * NU, oHxx = oE + NX * NP, oHxu = oHxx + NX * NX, oHxe = oHxu + NX * NU,
+                  oHuu = oHxe + NX * NP, oHue = oHuu + NU * NU;
+    auxsys_expand<Mdl, 0>(blk, codes + oF, NC, STRIDE, cnt, o.dynF ? o.dynF + bt0 * NX * NX : nullptr, lane);
+    auxsys_expand<Mdl, 1>(blk, codes + oG, NC, STRIDE, cnt, o.dynG ? o.dynG + bt0 * NX * NU : nullptr, lane);
+    auxsys_expand<Mdl, 2>(blk, codes + oE, NC, STRIDE, cnt, o.dynE ? o.dynE + bt0 * NX * NP : nullptr, lane);
+    auxsys_expand<Mdl, 3>(blk, codes + oHxx, NC, STRIDE, cnt, o.Hxx ? o.Hxx + bt0 * NX * NX : nullptr, lane);
+    auxsys_expand<Mdl, 4>(blk, codes + oHxu, NC, STRIDE, cnt, o.Hxu ? o.Hxu + bt0 * NX * NU : nullptr, lane);
+    auxsys_expand<Mdl, 5>(blk, codes + oHxe, NC, STRIDE, cnt, o.Hxe ? o.Hxe + bt0 * NX * NP : nullptr, lane);
+    auxsys_expand<Mdl, 6>(blk, codes + oHuu, NC, STRIDE, cnt, o.Huu ? o.Huu + bt0 * NU * NU : nullptr, lane);
+    auxsys_expand<Mdl, 7>(blk, codes + oHue, NC, STRIDE, cnt, o.Hue ? o.Hue + bt0 * NU * NP : nullptr, lane);
+    if (o.Hux) {                                             // Hux = Hxu' (the reference stores both, PDP.py:295)
+        double* dst = o.Hux + bt0 * NU * NX;
+        for (int q = lane; q < cnt * NU * NX; q += 64) {
+            const int tl = q / (NU * NX), r = q - tl * (NU * NX), j = r / NX, i = r - j * NX;      // Hux[j][i] = Hxu[i][j]
+            const int code = codes[oHxu + i * NU + j];
+            dst[q] = code >= 0 ? blk[NC + tl * STRIDE + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
