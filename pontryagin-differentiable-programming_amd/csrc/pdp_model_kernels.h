@@ -366,9 +366,14 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
 #define PDP_STAMP() tstamp[nst++] = __builtin_readcyclecounter()
     long long fine[16]; for (int i = 0; i < 16; ++i) fine[i] = 0;
 #define PDP_FINE(i, cond) if (cond) fine[i] = __builtin_readcyclecounter()
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;           // per-phase cycle totals over all chunks
+#define PDP_ACC0() tlast = __builtin_readcyclecounter()
+#define PDP_ACC(k) { long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
 #else
 #define PDP_STAMP()
 #define PDP_FINE(i, cond)
+#define PDP_ACC0()
+#define PDP_ACC(k)
 #endif
     PDP_STAMP();
 
@@ -470,6 +475,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const int nchunk = (T + CH - 1) / CH;
         for (int c = nchunk - 1; c >= 0; --c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
+            PDP_ACC0();
             wave_lds_sync();
             if (lane < cnt) {                       // (A) lane = time step: F, G, E, c_x at (x_t, u_t)
                 PDP_LOAD_PAR();
@@ -483,6 +489,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 Mdl::eval_patha(xc, uc, nullptr, th, pc, s);
             }
             wave_lds_sync();
+            PDP_ACC(0);
             if (!given) {                           // (C) costates through the chunk; pool row tl receives lambda_{t+1}
                 for (int tl = cnt - 1; tl >= 0; --tl) {
                     if (tile_col(lane) == 0) {
@@ -494,6 +501,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 }
                 wave_lds_sync();
             }
+            PDP_ACC(1);
             if (lane < cnt) {                       // (B) lane = time step: Hamiltonian Hessians at (x_t, u_t, lambda_{t+1})
                 PDP_LOAD_PAR();
                 const int t = t0 + lane;
@@ -514,6 +522,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 Mdl::eval_pathb(xc, uc, lc, th, pc, s);
             }
             wave_lds_sync();
+            PDP_ACC(2);
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
             GatherRun rF = gather_at(gF, cnt - 1), rY = gather_at(gY, cnt - 1), rHxx = gather_at(gHxx, cnt - 1), rHX = gather_at(gHX, cnt - 1),
                       rHU = gather_at(gHU, cnt - 1);
@@ -539,6 +548,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
             }
+            PDP_ACC(3);
         }
     }
     bool finite = tile_finite(P) && tile_finite(W2);
@@ -566,6 +576,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const int nchunk = (T + CH - 1) / CH;
         for (int c = 0; c < nchunk; ++c) {
             const int t0 = c * CH, cnt = min(CH, T - t0);
+            PDP_ACC0();
             wave_lds_sync();
             if (lane < cnt) {
                 PDP_LOAD_PAR();
@@ -580,6 +591,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 Mdl::eval_fwd(xc, uc, nullptr, th, pc, s);
             }
             wave_lds_sync();
+            PDP_ACC(4);
             for (int tl = 0; tl < cnt; ++tl) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
@@ -602,6 +614,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 PDP_FINE(11, t == 20);
                 PDP_FINE(12, t == 21);
             }
+            PDP_ACC(5);
         }
         // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
         wave_lds_sync();
@@ -624,6 +637,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     PDP_STAMP();
     if (lane == 0 && (b == 0 || b == 700)) { long long* o = (long long*)(loss + B) + (b ? 8 : 0); for (int i = 0; i < nst; ++i) o[i] = tstamp[i]; }
     if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 16; for (int i = 0; i < 16; ++i) o[i] = fine[i]; }
+    if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 32; for (int i = 0; i < 8; ++i) o[i] = tacc[i]; }
 #endif
 }
 

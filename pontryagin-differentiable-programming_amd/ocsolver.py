@@ -21,7 +21,8 @@ from . import runtime
 NEWTON_SWITCH = 1e-2
 
 
-def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, force_init=False, want_gains=False):
+def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, force_init=False, want_gains=False,
+           straggler_patience=0):
     """oc: PDP.OCSys.  ini_state [B,n]; auxvar_value [p] or [B,p]; returns dict of CUDA tensors
     state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], iterations (int), converged [B] (bool).
     u_init (optional warm start) is used per sample only where its rollout is finite and cheaper than u = 0."""
@@ -47,6 +48,7 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
     converged = torch.zeros((B,), dtype=torch.bool, device="cuda")
     gnorm = torch.full((B,), float("inf"), dtype=torch.float64, device="cuda")
     it = 0
+    last_nconv, last_gain = 0, 0
     for it in range(max_iter):
         lam = mdl.oc_costate(x, u, th)
         aux = mdl.oc_auxsys(x, u, lam, th, only=keys)
@@ -58,8 +60,16 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
                 it, float(gnorm.max()), float(J.mean()), int(converged.sum()), B, int(newton.sum()), float(mu.max())))
         if bool(converged.all()):
             break
+        # stragglers: once most of the batch is done and nothing new has converged for a while, stop - solve_batch re-solves the
+        # rest from the closed-loop warm start of a converged neighbour, which takes a handful of iterations
+        nconv = int(converged.sum())
+        if nconv > last_nconv:
+            last_nconv, last_gain = nconv, it
+        elif straggler_patience and nconv >= 0.9 * B and it - last_gain >= straggler_patience:
+            break
         # Newton once the stationarity residual is small relative to the controls, Gauss-Newton (always a descent direction) before
-        newton = newton | (gnorm <= NEWTON_SWITCH * scale)
+        # (with hysteresis: a sample whose residual has grown back by two orders of magnitude is no longer in Newton's basin)
+        newton = (newton & (gnorm <= 100.0 * NEWTON_SWITCH * scale)) | (gnorm <= NEWTON_SWITCH * scale)
         if bool((~newton).any()):                                            # Gauss-Newton Hessians = Hamiltonian Hessians at lambda = 0
             gn = mdl.oc_auxsys(x, u, zeros_lam, th, only=("Hxx", "Hxu", "Huu"))
             sel = (~newton).view(B, 1, 1, 1)
@@ -116,8 +126,9 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
         _, u_init, _ = mdl.oc_rollout_feedback(x0w, warm_start["control"], warm_start["state"], warm_start["gains"],
                                                torch.zeros((x0w.shape[0],), dtype=torch.float64, device="cuda"), oc._theta(auxvar_value, x0w.shape[0]))
         force = True
+    nb = runtime.dev(ini_state).reshape(-1, mdl.n).shape[0]
     sol = _solve(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level, force_init=force,
-                 want_gains=want_gains)
+                 want_gains=want_gains, straggler_patience=10 if (nb > 1 and neighbor_retries > 0) else 0)
     B = sol["state"].shape[0]
     if B == 1 or neighbor_retries <= 0:
         return sol
@@ -158,5 +169,5 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
             sub["gains"] = sub2["gains"]
         for k in ("state", "control", "costate", "cost", "grad_norm", "converged") + (("gains",) if want_gains else ()):
             sol[k][idx] = sub[k][better]
-        sol["iterations"] = max(sol["iterations"], sub["iterations"])
+        sol["iterations"] += don["iterations"] + sub["iterations"] + 2         # sequential iterations executed, retries included
     return sol

@@ -24,3 +24,5 @@ for blk in (0,1):
 f = st[16:32]
 print('backward step t=20: gather-issue %d | riccati_backward %d | gain stores %d | loop tail %d  (step total %d)' % (f[1]-f[0], f[2]-f[1], f[3]-f[2], f[4]-f[3], f[4]-f[0]))
 print('forward  step t=20: loads+gathers %d | riccati_forward %d | acc/tail %d | (step total %d)' % (f[9]-f[8], f[10]-f[9], f[11]-f[10], f[12]-f[8]))
+a = st[32:40]
+print('phase totals over all chunks (cycles): eval_patha %d | costates(MFMA) %d | eval_pathb %d | riccati backward loop %d | eval_fwd %d | forward loop %d' % tuple(a[:6]))
