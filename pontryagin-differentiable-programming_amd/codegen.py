@@ -236,10 +236,15 @@ def _emit_vecfn(name, args, outputs, inputs, L, scalar=False, replace=None):
         L.append("    }")
 
 
-def _pick_chunk(nvar, extra):
-    """time steps per lane-parallel aux pass: LDS pool = chunk * (nvar+extra, odd) * 8 B, budget 34 KB so that
-    4 wavefronts (one per SIMD) fit a CU's 160 KB together with the Riccati scratch."""
+def _pick_chunk(nvar, extra, other_doubles=0):
+    """Time steps per lane-parallel aux pass (lane = step, so at most 64); the LDS pool is chunk * (nvar+extra, odd) doubles.
+    Fused OC kernel (`other_doubles` = its Riccati scratch, constants and parameters): the most steps that still let 4 workgroups
+    (one wavefront per SIMD) share a CU's 160 KB, i.e. 40 KB per workgroup - the kernel splits a horizon into ceil(T / CHUNK)
+    chunks of equal length, so any value helps, not just powers of two (quadrotor: 21 -> T = 50 runs as 3 chunks of 17).
+    Other kernels also stage the trajectory in LDS and want several workgroups per SIMD: powers of two within 34 KB."""
     stride = (nvar + extra) | 1
+    if other_doubles:
+        return max(2, min(64, (40 * 1024 - 8 * other_doubles) // (stride * 8)))
     for c in (32, 16, 8, 4):
         if c * stride * 8 <= 34 * 1024:
             return c
@@ -289,7 +294,7 @@ def generate(problem):
         groups["pathb"] = _Group("pathb", [(k,) + dims[k] + (mats[k],) for k in ("Hxx", "Hxu", "Hxe", "Huu", "Hue")])
         groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD])
         groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN])
-        chunk = _pick_chunk(groups["patha"].nvar + groups["pathb"].nvar, n)
+        chunk = None                                          # needs the number of hoisted values: decided below
     elif pb.kind == KIND_CP:
         c, h = pb.path_cost, pb.final_cost
         assert p == 0, "ControlPlanning dynamics / costs carry no auxvar (PDP.py:672-697)"
@@ -310,6 +315,10 @@ def generate(problem):
         opt.mark_hoisted(g.var_nodes)
     repl = opt.replace_map()
     npc = len(opt.pc_nodes)
+    if chunk is None:
+        # fused kernel (csrc/pdp_model_kernels.h fused_lds_bytes): Riccati scratch 608 + constants + dl_T + theta + pc + pad
+        nconst = 1 + max(len(groups["patha"].consts) + len(groups["pathb"].consts), len(groups["fwd"].consts), len(groups["fin"].consts))
+        chunk = _pick_chunk(groups["patha"].nvar + groups["pathb"].nvar, n, other_doubles=608 + nconst + n + p + max(1, npc) + 8)
     L = []
     L.append("    // ---- theta-only sub-expressions, evaluated once per trajectory (pc[NPC])")
     L.append("    static constexpr int NPC = %d;" % max(1, npc))

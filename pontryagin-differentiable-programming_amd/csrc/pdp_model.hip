@@ -64,7 +64,7 @@ template <class Mdl>
 int oc_auxsys(int B, int T, const double* x, const double* u, const double* lam, const double* th, int tb, const pdp_oc_auxsys* o, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_OC) {
         if (B <= 0 || T <= 0 || !x || !u || !lam || !th || !o) return PDP_E_ARG;
-        const int nchunk = (T + Mdl::CHUNK - 1) / Mdl::CHUNK;
+        const int nchunk = (T + auxsys_chunk<Mdl>() - 1) / auxsys_chunk<Mdl>();
         PDP_CLEAR();
         hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), dim3((unsigned)((int64_t)B * (nchunk + 1))), dim3(64), 0, S(st), B, T, x, u, lam, th, tb, *o);
         return launched();

@@ -157,6 +157,10 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
 // API layout [B][T][rows][cols] with COALESCED stores - the chunk's slice of a family is one contiguous run of cnt*rows*cols
 // doubles.  (A lane-per-(b,t) scatter of 5.8 KB per thread ran at 1.3 TB/s of 8-byte stores; this form is bound by the
 // 314 KB per trajectory it has to write.)
+// steps per workgroup of the materialised getAuxSys kernel: write-bound, wants many small workgroups in flight
+template <class Mdl>
+__host__ __device__ constexpr int auxsys_chunk() { return Mdl::CHUNK < 16 ? Mdl::CHUNK : 16; }
+
 template <class Mdl, int MAT>
 PDP_DEV void auxsys_expand(const double* blk, const short* codes, int nc, int stride, int cnt, double* __restrict__ dst, int lane) {
     constexpr int RC = Mdl::PATH_ROWS[MAT] * Mdl::PATH_COLS[MAT];
@@ -171,12 +175,13 @@ PDP_DEV void auxsys_expand(const double* blk, const short* codes, int nc, int st
 template <class Mdl>
 __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u,
                                                         const double* __restrict__ lam, const double* __restrict__ theta, int tb, pdp_oc_auxsys o) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = auxsys_chunk<Mdl>();
     constexpr int NC = 1 + (Mdl::PATH_NCONST > Mdl::FIN_NCONST ? Mdl::PATH_NCONST : Mdl::FIN_NCONST), STRIDE = Mdl::PATH_NVAR | 1;
     constexpr int NCODE = NX * NX + NX * NU + NX * NP + NX * NX + NX * NU + NX * NP + NU * NU + NU * NP;   // entries of the 8 path families
     __shared__ double blk[NC + CH * STRIDE + Mdl::FIN_NVAR + 8];
     __shared__ short codes[NCODE > NX * NX + NX * NP ? NCODE : NX * NX + NX * NP];
     const int nchunk = (T + CH - 1) / CH;
+    const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     const int b = blockIdx.x / (nchunk + 1), c = blockIdx.x % (nchunk + 1), lane = threadIdx.x;
     double th[NP > 0 ? NP : 1];
     load_theta<Mdl>(theta, b, tb, th);
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const doubl
         }
         return;
     }
-    const int t0 = c * CH, cnt = min(CH, T - t0);
+    const int t0 = c * ch, cnt = min(ch, T - t0);
     if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
     {
         int base = 0;
@@ -473,8 +478,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX && tile_col(lane) == 0) Lam[r] = dlT[row]; }
         }
         const int nchunk = (T + CH - 1) / CH;
+        const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
         for (int c = nchunk - 1; c >= 0; --c) {
-            const int t0 = c * CH, cnt = min(CH, T - t0);
+            const int t0 = c * ch, cnt = min(ch, T - t0);
             PDP_ACC0();
             wave_lds_sync();
             if (lane < cnt) {                       // (A) lane = time step: F, G, E, c_x at (x_t, u_t)
@@ -491,13 +497,19 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             wave_lds_sync();
             PDP_ACC(0);
             if (!given) {                           // (C) costates through the chunk; pool row tl receives lambda_{t+1}
+                // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
+                GatherRun cF = gather_at(gF, cnt - 1), cC = gather_at(gCX, cnt - 1);
+                const int c0 = cnt > 1 ? -1 : 0;
+                d4 Fc = gather_run(blk, cF, c0), CX = gather_run(blk, cC, c0);
                 for (int tl = cnt - 1; tl >= 0; --tl) {
+                    const int dir = tl > 1 ? -1 : 0;
+                    d4 Fc_n = gather_run(blk, cF, dir), CX_n = gather_run(blk, cC, dir);
                     if (tile_col(lane) == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) pool[tl * L::BSTRIDE + L::LAM + row] = Lam[r]; }
                     }
-                    d4 Ft = gather_tile(blk, gF, tl), CX = gather_tile(blk, gCX, tl);
-                    Lam = mma_tn(Ft, Lam, CX);      // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                    Lam = mma_tn(Fc, Lam, CX);      // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                    Fc = Fc_n; CX = CX_n;
                 }
                 wave_lds_sync();
             }
@@ -574,8 +586,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         d4 KTn = -load_mapped<4>(gw, mKT);
         d4 kn = -load_mapped<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;
+        const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
         for (int c = 0; c < nchunk; ++c) {
-            const int t0 = c * CH, cnt = min(CH, T - t0);
+            const int t0 = c * ch, cnt = min(ch, T - t0);
             PDP_ACC0();
             wave_lds_sync();
             if (lane < cnt) {
@@ -788,8 +801,9 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     for (int j = 0; j < NT; ++j) { X[j] = z; acc[j] = 0.0; }
     const int row0 = lane >> 4, col = lane & 15;
     const int nchunk = (T + CH - 1) / CH;
+    const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = 0; c < nchunk; ++c) {
-        const int t0 = c * CH, cnt = min(CH, T - t0);
+        const int t0 = c * ch, cnt = min(ch, T - t0);
         __syncthreads();
         if (lane < cnt) {
             const int t = t0 + lane;
@@ -983,8 +997,9 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
     enc(lane < NX ? Mdl::path_code(2, lane) : -1, cxo, cxm);
     enc(lane < NU ? Mdl::path_code(3, lane) : -1, cuo, cum);
     const int nchunk = (T + CH - 1) / CH;
+    const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = nchunk - 1; c >= 0; --c) {
-        const int t0 = c * CH, cnt = min(CH, T - t0);
+        const int t0 = c * ch, cnt = min(ch, T - t0);
         wave_lds_sync();
         if (lane < cnt) {
             const int t = t0 + lane;
@@ -1155,8 +1170,9 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
 #pragma unroll
     for (int j = 0; j < NT; ++j) { X[j] = z; acc[j] = 0.0; }
     const int nchunk = (T + CH - 1) / CH;
+    const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = 0; c < nchunk; ++c) {
-        const int t0 = c * CH, cnt = min(CH, T - t0);
+        const int t0 = c * ch, cnt = min(ch, T - t0);
         __syncthreads();
         if (lane < cnt) {
             const int t = t0 + lane;
