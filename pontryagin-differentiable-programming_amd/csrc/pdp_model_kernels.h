@@ -538,17 +538,17 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
             GatherRun rF = gather_at(gF, cnt - 1), rY = gather_at(gY, cnt - 1), rHxx = gather_at(gHxx, cnt - 1), rHX = gather_at(gHX, cnt - 1),
                       rHU = gather_at(gHU, cnt - 1);
+            // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
+            // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers
             const int d0 = cnt > 1 ? -1 : 0;
-            d4 Ft = gather_run(blk, rF, d0), Y2 = gather_run(blk, rY, d0), Hxx = gather_run(blk, rHxx, d0), HX2 = gather_run(blk, rHX, d0),
-               HU2 = gather_run<1>(blk, rHU, d0);
-#pragma unroll 2
+            d4 Ft = gather_run(blk, rF, d0), Y2 = gather_run(blk, rY, d0);
             for (int tl = cnt - 1; tl >= 0; --tl) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
                 // the prefetch reads row tl-1; the offsets stop at row 0 (the last prefetch of a chunk re-reads row 0, unused)
-                const int dir = tl > 1 ? -1 : 0;
-                d4 Ft_n = gather_run(blk, rF, dir), Y2_n = gather_run(blk, rY, dir), Hxx_n = gather_run(blk, rHxx, dir),
-                   HX2_n = gather_run(blk, rHX, dir), HU2_n = gather_run<1>(blk, rHU, dir);
+                const int dir = tl > 1 ? -1 : 0, dirh = tl > 0 ? -1 : 0;
+                d4 Hxx = gather_run(blk, rHxx, dirh), HX2 = gather_run(blk, rHX, dirh), HU2 = gather_run<1>(blk, rHU, dirh);
+                d4 Ft_n = gather_run(blk, rF, dir), Y2_n = gather_run(blk, rY, dir);
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 PDP_FINE(2, t == 20);
                 store_mapped<4>(gw + t * GSZ, mKT, g.KT);
                 store_mapped<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
-                Ft = Ft_n; Y2 = Y2_n; Hxx = Hxx_n; HX2 = HX2_n; HU2 = HU2_n;
+                Ft = Ft_n; Y2 = Y2_n;
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
             }

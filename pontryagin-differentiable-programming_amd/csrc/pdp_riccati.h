@@ -80,11 +80,16 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         const double m20 = q[r2 * 16 + c0], m21 = q[r2 * 16 + c1], m22 = q[r2 * 16 + c2];
         double cof = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
         cof = ((i + j) & 1) ? -cof : cof;
-        const double a00 = readlane_f64(Q2[0], 0), a01 = readlane_f64(Q2[0], 1), a02 = readlane_f64(Q2[0], 2), a03 = readlane_f64(Q2[0], 3);
-        const double det = a00 * readlane_f64(cof, 0) + a01 * readlane_f64(cof, 1) + a02 * readlane_f64(cof, 2) + a03 * readlane_f64(cof, 3);
-        const double dprod = a00 * readlane_f64(Q2[0], 17) * readlane_f64(Q2[0], 34) * readlane_f64(Q2[0], 51);
-        if (fabs(det) > 1e-10 * fabs(dprod) && fabs(det) <= 1.7e308) {      // uniform branch
-            Z[0] = (col < 4) ? cof / det : 0.0;
+        // Laplace expansion along row 0; the size of its terms against the size of their sum is the conditioning guard
+        const double t0 = readlane_f64(Q2[0], 0) * readlane_f64(cof, 0), t1 = readlane_f64(Q2[0], 1) * readlane_f64(cof, 1),
+                     t2 = readlane_f64(Q2[0], 2) * readlane_f64(cof, 2), t3 = readlane_f64(Q2[0], 3) * readlane_f64(cof, 3);
+        const double det = (t0 + t1) + (t2 + t3), mag = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
+        if (fabs(det) > 1e-10 * mag && fabs(det) <= 1.7e308) {      // uniform branch
+            // 1/det: hardware reciprocal + one Newton step (the full IEEE division sequence is a 12-instruction dependent chain
+            // in front of the gain MFMAs; det is nowhere near the subnormal / overflow ranges that sequence exists for)
+            double rdet = __builtin_amdgcn_rcp(det);
+            rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+            Z[0] = (col < 4) ? cof * rdet : 0.0;
         } else {                                 // ill-conditioned / singular: pivoted Gauss-Jordan, uniform over the wave
             double a[16], ai[16];
 #pragma unroll
