@@ -29,7 +29,7 @@ template <class Mdl> constexpr bool fused_oc_ok() { return Mdl::KIND == PDP_KIND
 
 template <class Mdl>
 int64_t oc_ws_bytes(int B, int T) {
-    return (int64_t)B * T * (Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP) * (int64_t)sizeof(double);
+    return (int64_t)B * T * fused_gain_doubles<Mdl>() * (int64_t)sizeof(double);
 }
 
 template <class Mdl>

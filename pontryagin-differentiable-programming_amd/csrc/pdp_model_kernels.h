@@ -302,6 +302,11 @@ PDP_DEV d4 gather_tile_r0(const double* lds, const Gather& g, int tl) {
     return v;
 }
 
+// feedback gains of one step in the workspace: K' [NX x NU], k [NU x NP], and one slot that receives (and hands back) the zeros of
+// the tile elements outside those blocks
+template <class Mdl>
+__host__ __device__ constexpr int fused_gain_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }
+
 template <class Mdl>
 struct FusedLayout {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
     using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK, M = NU;
-    constexpr int GSZ = NX * NU + NU * NP;
+    constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K' [NX x NU] | k [NU x NP] | zero sink
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
@@ -459,7 +464,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
-        const TileMap mKT = make_tile_map(NX, NU, NU, 0, 0, lane), mIK = make_tile_map(NU, NP, NP, 0, M, lane);
+        const TileMap mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
@@ -554,8 +559,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 PDP_FINE(1, t == 20);
                 ok = riccati_backward<M>(P, W2, Ft, Y2, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
-                store_mapped<4>(gw + t * GSZ, mKT, g.KT);
-                store_mapped<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
+                store_all<4>(gw + t * GSZ, mKT, g.KT);
+                store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
                 Ft = Ft_n; Y2 = Y2_n;
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
@@ -582,9 +587,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
-        const TileMap mKT = make_tile_map(NX, NU, NU, 0, 0, lane), mIK = make_tile_map(NU, NP, NP, 0, M, lane);
-        d4 KTn = -load_mapped<4>(gw, mKT);
-        d4 kn = -load_mapped<1>(gw + NX * NU, mIK);
+        const TileMap mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        d4 KTn = -load_all<4>(gw, mKT);
+        d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
         for (int c = 0; c < nchunk; ++c) {
@@ -608,8 +613,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             for (int tl = 0; tl < cnt; ++tl) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
-                d4 KTn_n = -load_mapped<4>(gw + tnx * GSZ, mKT);
-                d4 kn_n = -load_mapped<1>(gw + tnx * GSZ + NX * NU, mIK);
+                d4 KTn_n = -load_all<4>(gw + tnx * GSZ, mKT);
+                d4 kn_n = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
                 d4 FT = gather_tile(blk, gFT, tl);
                 d4 GT = gather_tile_r0(blk, gGT, tl);
                 d4 E2 = gather_tile(blk, gE, tl);

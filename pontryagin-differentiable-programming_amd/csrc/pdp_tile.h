@@ -85,19 +85,27 @@ PDP_DEV TileMap make_tile_map(int R, int C, int ld, int roff, int coff, int lane
     }
     return m;
 }
-template <int NR = 4>
-PDP_DEV void store_mapped(double* __restrict__ base, const TileMap& m, const d4 v) {
+// Branch-free variant: elements outside the block are directed to one `sink` offset.  A tile that is exactly zero outside the
+// block (every product of zero-padded operands is) stores zeros there, so the same map loads zeros back for those elements:
+// no exec-mask branch around each register's store / load.
+PDP_DEV TileMap make_tile_map_sink(int R, int C, int ld, int roff, int coff, int lane, int sink) {
+    TileMap m = make_tile_map(R, C, ld, roff, coff, lane);
 #pragma unroll
-    for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) base[m.off[r]] = v[r];
+    for (int r = 0; r < 4; ++r) if (m.off[r] < 0) m.off[r] = sink;
+    return m;
 }
 template <int NR = 4>
-PDP_DEV d4 load_mapped(const double* __restrict__ base, const TileMap& m) {
+PDP_DEV void store_all(double* __restrict__ base, const TileMap& m, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) base[m.off[r]] = v[r];
+}
+template <int NR = 4>
+PDP_DEV d4 load_all(const double* __restrict__ base, const TileMap& m) {
     d4 v = zero4();
 #pragma unroll
-    for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) v[r] = base[m.off[r]];
+    for (int r = 0; r < NR; ++r) v[r] = base[m.off[r]];
     return v;
 }
-
 // zero every column outside [c0, c1)
 PDP_DEV d4 keep_cols(const d4 v, int c0, int c1, int lane) {
     int col = tile_col(lane);
