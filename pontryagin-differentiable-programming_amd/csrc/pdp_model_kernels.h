@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
-        const TileMap mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
-        const TileMap mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         d4 KTn = -load_all<4>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;

@@ -88,22 +88,32 @@ PDP_DEV TileMap make_tile_map(int R, int C, int ld, int roff, int coff, int lane
 // Branch-free variant: elements outside the block are directed to one `sink` offset.  A tile that is exactly zero outside the
 // block (every product of zero-padded operands is) stores zeros there, so the same map loads zeros back for those elements:
 // no exec-mask branch around each register's store / load.
-PDP_DEV TileMap make_tile_map_sink(int R, int C, int ld, int roff, int coff, int lane, int sink) {
+struct TileMapBytes { unsigned off[4]; };   // unsigned BYTE offsets: uniform base (SGPR pair) + 32-bit lane offset addressing, no 64-bit VALU add
+PDP_DEV TileMapBytes make_tile_map_sink(int R, int C, int ld, int roff, int coff, int lane, int sink) {
     TileMap m = make_tile_map(R, C, ld, roff, coff, lane);
+    TileMapBytes b;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (m.off[r] < 0) m.off[r] = sink;
-    return m;
+    for (int r = 0; r < 4; ++r) b.off[r] = 8u * (unsigned)(m.off[r] < 0 ? sink : m.off[r]);
+    return b;
 }
 template <int NR = 4>
-PDP_DEV void store_all(double* __restrict__ base, const TileMap& m, const d4 v) {
+PDP_DEV void store_all(double* __restrict__ base, const TileMapBytes& m, const d4 v) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) base[m.off[r]] = v[r];
+    for (int r = 0; r < NR; ++r) {
+        unsigned o = m.off[r];
+        asm("" : "+v"(o));      // keeps the zero-extension next to the access (hoisted out of the loop it hides the base + u32 form)
+        *(double*)((char*)base + o) = v[r];
+    }
 }
 template <int NR = 4>
-PDP_DEV d4 load_all(const double* __restrict__ base, const TileMap& m) {
+PDP_DEV d4 load_all(const double* __restrict__ base, const TileMapBytes& m) {
     d4 v = zero4();
 #pragma unroll
-    for (int r = 0; r < NR; ++r) v[r] = base[m.off[r]];
+    for (int r = 0; r < NR; ++r) {
+        unsigned o = m.off[r];
+        asm("" : "+v"(o));
+        v[r] = *(const double*)((const char*)base + o);
+    }
     return v;
 }
 // zero every column outside [c0, c1)
