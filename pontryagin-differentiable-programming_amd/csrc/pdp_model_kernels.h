@@ -272,6 +272,10 @@ PDP_DEV GatherRun gather_at(const Gather& g, int tl) {
     for (int k = 0; k < 4; ++k) { r.cur[k] = 8 * (g.off[k] + tl * g.tmul[k]); r.tmul[k] = 8 * g.tmul[k]; }
     return r;
 }
+PDP_DEV void scatter_run(double* lds, GatherRun& g, const d4 v, int dir) {      // write, then advance
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { *(double*)((char*)lds + g.cur[k]) = v[k]; g.cur[k] += dir * g.tmul[k]; }
+}
 template <int NR = 4>
 PDP_DEV d4 gather_run(const double* lds, GatherRun& g, int dir) {      // read, then advance by dir (+1 / -1) time steps
     d4 v = zero4();
@@ -502,20 +506,30 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             wave_lds_sync();
             PDP_ACC(0);
             if (!given) {                           // (C) costates through the chunk; pool row tl receives lambda_{t+1}
-                // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
-                GatherRun cF = gather_at(gF, cnt - 1), cC = gather_at(gCX, cnt - 1);
-                const int c0 = cnt > 1 ? -1 : 0;
-                d4 Fc = gather_run(blk, cF, c0), CX = gather_run(blk, cC, c0);
-                for (int tl = cnt - 1; tl >= 0; --tl) {
-                    const int dir = tl > 1 ? -1 : 0;
-                    d4 Fc_n = gather_run(blk, cF, dir), CX_n = gather_run(blk, cC, dir);
-                    if (tile_col(lane) == 0) {
+                // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them.
+                // The running offsets simply keep moving down; the last prefetch of a chunk reads the row below row 0 (scratch
+                // space of this workgroup, or - past the start of LDS - zeros) and is not used.
+                GatherRun cF = gather_at(gF, cnt - 1), cC = gather_at(gCX, cnt - 1), wL;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) pool[tl * L::BSTRIDE + L::LAM + row] = Lam[r]; }
-                    }
-                    Lam = mma_tn(Fc, Lam, CX);      // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
-                    Fc = Fc_n; CX = CX_n;
+                for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
+                    const int row = tile_row(lane, r);
+                    const bool valid = tile_col(lane) == 0 && row < NX;
+                    wL.cur[r] = valid ? 8 * (int)((pool - lds) + (cnt - 1) * L::BSTRIDE + L::LAM + row) : 0;     // scratch[0]: idle here
+                    wL.tmul[r] = valid ? 8 * L::BSTRIDE : 0;
                 }
+                d4 Fc = gather_run(blk, cF, -1), CX = gather_run(blk, cC, -1);
+                auto cstep = [&](const d4 Lin, d4& Lout) {
+                    d4 Fc_n = gather_run(blk, cF, -1), CX_n = gather_run(blk, cC, -1);
+                    scatter_run(lds, wL, Lin, -1);
+                    Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                    Fc = Fc_n; CX = CX_n;
+                };
+                // two steps per trip with the costate tile alternating between two register sets: the MFMA chain of a step reads
+                // its predecessor's tile until its last instruction, so one set would need a copy in the middle of every chain
+                d4 Lam2 = z;
+                int tl = cnt - 1;
+                for (; tl >= 1; tl -= 2) { cstep(Lam, Lam2); cstep(Lam2, Lam); }
+                if (tl == 0) { cstep(Lam, Lam2); Lam = Lam2; }
                 wave_lds_sync();
             }
             PDP_ACC(1);
@@ -544,27 +558,29 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             GatherRun rF = gather_at(gF, cnt - 1), rY = gather_at(gY, cnt - 1), rHxx = gather_at(gHxx, cnt - 1), rHX = gather_at(gHX, cnt - 1),
                       rHU = gather_at(gHU, cnt - 1);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
-            // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers
-            const int d0 = cnt > 1 ? -1 : 0;
-            d4 Ft = gather_run(blk, rF, d0), Y2 = gather_run(blk, rY, d0);
-            for (int tl = cnt - 1; tl >= 0; --tl) {
+            // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The running
+            // offsets keep moving down (the last prefetch of a chunk reads below row 0 and is unused).  Two steps per trip with the
+            // prefetched tiles alternating between two register sets (no copies at the back edge).
+            d4 Fa = gather_run(blk, rF, -1), Ya = gather_run(blk, rY, -1), Fb, Yb;
+            auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
-                // the prefetch reads row tl-1; the offsets stop at row 0 (the last prefetch of a chunk re-reads row 0, unused)
-                const int dir = tl > 1 ? -1 : 0, dirh = tl > 0 ? -1 : 0;
-                d4 Hxx = gather_run(blk, rHxx, dirh), HX2 = gather_run(blk, rHX, dirh), HU2 = gather_run<1>(blk, rHU, dirh);
-                d4 Ft_n = gather_run(blk, rF, dir), Y2_n = gather_run(blk, rY, dir);
+                d4 Hxx = gather_run(blk, rHxx, -1), HX2 = gather_run(blk, rHX, -1), HU2 = gather_run<1>(blk, rHU, -1);
+                Fn = gather_run(blk, rF, -1);
+                Yn = gather_run(blk, rY, -1);
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
-                ok = riccati_backward<M>(P, W2, Ft, Y2, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
+                ok = riccati_backward<M>(P, W2, Fc, Yc, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<4>(gw + t * GSZ, mKT, g.KT);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
-                Ft = Ft_n; Y2 = Y2_n;
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
-            }
+            };
+            int tl = cnt - 1;
+            for (; tl >= 1; tl -= 2) { bstep(tl, Fa, Ya, Fb, Yb); bstep(tl - 1, Fb, Yb, Fa, Ya); }
+            if (tl == 0) bstep(0, Fa, Ya, Fb, Yb);
             PDP_ACC(3);
         }
     }
@@ -610,28 +626,32 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             }
             wave_lds_sync();
             PDP_ACC(4);
-            for (int tl = 0; tl < cnt; ++tl) {
+            GatherRun rFT = gather_at(gFT, 0), rGT = gather_at(gGT, 0), rE = gather_at(gE, 0), rDX = gather_at(gDX, 0), rDU = gather_at(gDU, 0);
+            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
-                d4 KTn_n = -load_all<4>(gw + tnx * GSZ, mKT);
-                d4 kn_n = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                d4 FT = gather_tile(blk, gFT, tl);
-                d4 GT = gather_tile_r0(blk, gGT, tl);
-                d4 E2 = gather_tile(blk, gE, tl);
-                d4 DX = gather_tile(blk, gDX, tl);          // (x_t - xd_t)[row] broadcast over columns
-                d4 DU = gather_tile_r0(blk, gDU, tl);
-                d4 U2, Xn;
+                KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
+                knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
+                d4 FT = gather_run(blk, rFT, 1);
+                d4 GT = gather_run<1>(blk, rGT, 1);
+                d4 E2 = gather_run(blk, rE, 1);
+                d4 DX = gather_run(blk, rDX, 1);            // (x_t - xd_t)[row] broadcast over columns
+                d4 DU = gather_run<1>(blk, rDU, 1);
+                d4 U2;
                 PDP_FINE(9, t == 20);
-                riccati_forward(KTn, kn, FT, GT, E2, X2, U2, Xn);
+                riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                 PDP_FINE(10, t == 20);
-                acc += DX[0] * X2[0] + DX[1] * X2[1] + DX[2] * X2[2] + DX[3] * X2[3] + DU[0] * U2[0];
-                if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+                acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
+                if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                 if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
-                X2 = Xn;
-                KTn = KTn_n; kn = kn_n;
                 PDP_FINE(11, t == 20);
                 PDP_FINE(12, t == 21);
-            }
+            };
+            // two steps per trip, the sensitivity tile and the prefetched gains alternating between two register sets
+            d4 Xb, KTb, kb;
+            int tl = 0;
+            for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); fstep(tl + 1, Xb, X2, KTb, kb, KTn, kn); }
+            if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; }
             PDP_ACC(5);
         }
         // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
