@@ -407,9 +407,14 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             for (int i = 0; i < NX; ++i) xs[i] = xc[i];
         }
         wave_lds_sync();
-        for (int t = 0; t < T; ++t) {
+        PDP_ACC0();
+        double un[NU];                                       // u_{t+1} is read from LDS while step t computes
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
+        for (int i = 0; i < NU; ++i) un[i] = us[i];
+        for (int t = 0; t < T; ++t) {
+            const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { uc[i] = un[i]; un[i] = us[tn * NU + i]; }
             Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
@@ -419,6 +424,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             }
         }
         wave_lds_sync();
+        PDP_ACC(6);
         for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API output
         __threadfence_block();                               // x is re-read below by other lanes of this wave
         wave_lds_sync();

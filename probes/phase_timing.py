@@ -26,3 +26,4 @@ print('backward step t=20: gather-issue %d | riccati_backward %d | gain stores %
 print('forward  step t=20: loads+gathers %d | riccati_forward %d | acc/tail %d | (step total %d)' % (f[9]-f[8], f[10]-f[9], f[11]-f[10], f[12]-f[8]))
 a = st[32:40]
 print('phase totals over all chunks (cycles): eval_patha %d | costates(MFMA) %d | eval_pathb %d | riccati backward loop %d | eval_fwd %d | forward loop %d' % tuple(a[:6]))
+print('rollout recursion alone (cycles): %d' % a[6])
