@@ -88,6 +88,32 @@ PDP_DEV TileMap make_tile_map(int R, int C, int ld, int roff, int coff, int lane
 // Branch-free variant: elements outside the block are directed to one `sink` offset.  A tile that is exactly zero outside the
 // block (every product of zero-padded operands is) stores zeros there, so the same map loads zeros back for those elements:
 // no exec-mask branch around each register's store / load.
+template <bool TRANS>
+PDP_DEV TileMap make_dense_map(int R, int C, int ld, int roff, int coff, int lane) {      // TRANS: tile = (R x C block)^T
+    if (!TRANS) return make_tile_map(R, C, ld, roff, coff, lane);
+    TileMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row = tile_row(lane, r) - roff, col = tile_col(lane) - coff;
+        m.off[r] = (row >= 0 && row < C && col >= 0 && col < R) ? col * ld + row : -1;
+    }
+    return m;
+}
+// Loads / stores through a loop-invariant map: the per-step cost is one address add per register (load_dense / store_dense redo the
+// index arithmetic and bound checks of every element on every call).  Loads are branch-free (absent elements read element 0 of the
+// block and are zeroed by a select), stores are predicated.
+template <int NR = 4>
+PDP_DEV d4 load_map(const double* __restrict__ base, const TileMap& m) {
+    d4 v = zero4();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { const int o = m.off[r]; const double x = base[o >= 0 ? o : 0]; v[r] = o >= 0 ? x : 0.0; }
+    return v;
+}
+template <int NR = 4>
+PDP_DEV void store_map(double* __restrict__ base, const TileMap& m, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) base[m.off[r]] = v[r];
+}
 struct TileMapBytes { unsigned off[4]; };   // unsigned BYTE offsets: uniform base (SGPR pair) + 32-bit lane offset addressing, no 64-bit VALU add
 PDP_DEV TileMapBytes make_tile_map_sink(int R, int C, int ld, int roff, int coff, int lane, int sink) {
     TileMap m = make_tile_map(R, C, ld, roff, coff, lane);
