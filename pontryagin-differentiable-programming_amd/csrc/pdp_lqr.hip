@@ -192,28 +192,58 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     if (lane == 0 && status) status[b] = st;
 }
 
-// U_t = Ux X + Ue ; X+ = F X + G U.   Generic n <= 16, m <= 16, p tiled by 16 columns (grid.y).
+// U_t = Ux X + Ue ; X+ = F X + G U.   Generic n <= 16, m <= 16.  A wavefront carries NT tiles of 16 parameter columns (grid.y covers
+// the rest), so F, G and Ux are read once per NT tiles; the operands of step t+1 stream in while step t computes (see RunPtr).
+template <int NT>
 __global__ void __launch_bounds__(64) cp_aux_kernel(int B, int T, int n, int m, int p, const double* __restrict__ F, const double* __restrict__ G,
                                                      const double* __restrict__ Ux, const double* __restrict__ Ue, const double* __restrict__ X0,
                                                      double* __restrict__ Xo, double* __restrict__ Uo) {
-    const int b = blockIdx.x, c0 = blockIdx.y * 16, lane = threadIdx.x;
-    const int w = min(16, p - c0);
+    const int b = blockIdx.x, cbase = blockIdx.y * 16 * NT, lane = threadIdx.x;
     const d4 z = zero4();
-    d4 X = X0 ? load_dense<false>(X0 + (int64_t)b * n * p + c0, n, w, p, 0, 0, lane) : z;
-    store_dense(Xo + (int64_t)b * (T + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
-    for (int t = 0; t < T; ++t) {
-        const int64_t bt = (int64_t)b * T + t;
-        d4 FT = load_dense<true>(F + bt * n * n, n, n, n, 0, 0, lane);
-        d4 GT = load_dense<true>(G + bt * n * m, n, m, m, 0, 0, lane);       // m x n
-        d4 UxT = load_dense<true>(Ux + bt * m * n, m, n, n, 0, 0, lane);     // n x m
-        d4 Uet = load_dense<false>(Ue + bt * m * p + c0, m, w, p, 0, 0, lane);
-        d4 U = mma_tn(UxT, X, Uet);        // Ux X + Ue
-        d4 Xn = mma_tn(FT, X, z);
-        Xn = mma_tn(GT, U, Xn);
-        X = Xn;
-        store_dense(Uo + bt * m * p + c0, m, w, p, 0, 0, lane, U);
-        store_dense(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + c0, n, w, p, 0, 0, lane, Xn);
+    TileMap mX[NT], mU[NT];
+    d4 X[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int w = max(0, min(16, p - cbase - 16 * j));          // 0: this tile is past the last column (maps all absent)
+        mX[j] = make_dense_map<false>(n, w, p, 0, 0, lane);
+        mU[j] = make_dense_map<false>(m, w, p, 0, 0, lane);
+        X[j] = (X0 && w > 0) ? load_map(X0 + (int64_t)b * n * p + cbase + 16 * j, mX[j]) : z;
+        store_map(Xo + (int64_t)b * (T + 1) * n * p + cbase + 16 * j, mX[j], X[j]);
     }
+    const pdp_mat none = {nullptr, 0, 0}, aF = {F, (int64_t)T * n * n, n * n}, aG = {G, (int64_t)T * n * m, n * m},
+                  aUx = {Ux, (int64_t)T * m * n, m * n};
+    RunPtr qF = make_run(aF, make_dense_map<true>(n, n, n, 0, 0, lane), none, mX[0], b, 0),
+           qG = make_run(aG, make_dense_map<true>(n, m, m, 0, 0, lane), none, mX[0], b, 0),       // m x n
+           qUx = make_run(aUx, make_dense_map<true>(m, n, n, 0, 0, lane), none, mX[0], b, 0),    // n x m
+           qUe[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const pdp_mat aUe = {Ue + cbase + 16 * j, (int64_t)T * m * p, m * p};
+        qUe[j] = make_run(aUe, mU[j], none, mX[0], b, 0);
+    }
+    struct Tiles { d4 FT, GT, UxT, Ue[NT]; };
+    auto request = [&](Tiles& q) {
+        q.FT = load_run(qF, 1); q.GT = load_run(qG, 1); q.UxT = load_run(qUx, 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) q.Ue[j] = load_run(qUe[j], 1);
+    };
+    auto step = [&](int t, const Tiles& c, Tiles& nx) {
+        if (t + 1 < T) request(nx);
+        const int64_t bt = (int64_t)b * T + t;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            d4 U = mma_tn(c.UxT, X[j], c.Ue[j]);        // Ux X + Ue
+            d4 Xn = mma_tn(c.FT, X[j], z);
+            X[j] = mma_tn(c.GT, U, Xn);
+            store_map(Uo + bt * m * p + cbase + 16 * j, mU[j], U);
+            store_map(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + cbase + 16 * j, mX[j], X[j]);
+        }
+    };
+    Tiles ta, tb;
+    request(ta);
+    int t = 0;
+    for (; t + 1 < T; t += 2) { step(t, ta, tb); step(t + 1, tb, ta); }
+    if (t < T) step(t, ta, tb);
 }
 
 __global__ void __launch_bounds__(64) sysid_aux_kernel(int B, int T, int n, int p, const double* __restrict__ F, const double* __restrict__ E,
@@ -221,15 +251,23 @@ __global__ void __launch_bounds__(64) sysid_aux_kernel(int B, int T, int n, int 
     const int b = blockIdx.x, c0 = blockIdx.y * 16, lane = threadIdx.x;
     const int w = min(16, p - c0);
     const d4 z = zero4();
-    d4 X = X0 ? load_dense<false>(X0 + (int64_t)b * n * p + c0, n, w, p, 0, 0, lane) : z;
-    store_dense(Xo + (int64_t)b * (T + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
-    for (int t = 0; t < T; ++t) {
-        const int64_t bt = (int64_t)b * T + t;
-        d4 FT = load_dense<true>(F + bt * n * n, n, n, n, 0, 0, lane);
-        d4 Et = load_dense<false>(E + bt * n * p + c0, n, w, p, 0, 0, lane);
-        X = mma_tn(FT, X, Et);
-        store_dense(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + c0, n, w, p, 0, 0, lane, X);
-    }
+    const TileMap mX = make_dense_map<false>(n, w, p, 0, 0, lane);
+    d4 X = X0 ? load_map(X0 + (int64_t)b * n * p + c0, mX) : z;
+    store_map(Xo + (int64_t)b * (T + 1) * n * p + c0, mX, X);
+    const pdp_mat none = {nullptr, 0, 0}, aF = {F, (int64_t)T * n * n, n * n}, aE = {E + c0, (int64_t)T * n * p, n * p};
+    RunPtr qF = make_run(aF, make_dense_map<true>(n, n, n, 0, 0, lane), none, mX, b, 0), qE = make_run(aE, mX, none, mX, b, 0);
+    struct Tiles { d4 FT, Et; };
+    auto request = [&](Tiles& q) { q.FT = load_run(qF, 1); q.Et = load_run(qE, 1); };
+    auto step = [&](int t, const Tiles& c, Tiles& nx) {
+        if (t + 1 < T) request(nx);
+        X = mma_tn(c.FT, X, c.Et);
+        store_map(Xo + ((int64_t)b * (T + 1) + t + 1) * n * p + c0, mX, X);
+    };
+    Tiles ta, tb;
+    request(ta);
+    int t = 0;
+    for (; t + 1 < T; t += 2) { step(t, ta, tb); step(t + 1, tb, ta); }
+    if (t < T) step(t, ta, tb);
 }
 
 // grad[b][j] = sum_t dcx.X + dcu.U + dhx.X_T : one thread per (b, j), coalesced over j
@@ -305,7 +343,9 @@ int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double
     if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !F || !G || !Ux || !Ue || !X || !U) return PDP_E_ARG;
     if (n > 16 || m > 16) return PDP_E_SIZE;
     PDP_CLEAR();
-    hipLaunchKernelGGL(cp_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
+    const int ntile = (p + 15) / 16;
+    if (ntile == 1) hipLaunchKernelGGL(cp_aux_kernel<1>, dim3(B, 1), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
+    else hipLaunchKernelGGL(cp_aux_kernel<2>, dim3(B, (ntile + 1) / 2), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
     return launched();
 }
 

@@ -52,5 +52,12 @@ dt = timeit(lambda: mdl.oc_auxsys(x, u, lam, th)); res["C3 materialised OCSys.ge
 aux = mdl.oc_auxsys(x, u, lam, th)
 dt = timeit(lambda: rt.lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], aux["hxe"], E=aux["dynE"], Hxu=aux["Hxu"], Hxe=aux["Hxe"], Hue=aux["Hue"]))
 res["C3 materialised LQR.lqrSolver (X,U,Lambda out), quadrotor T=50 p=9 B=1024"] = (B / dt, dt * 1e3)
+# materialised ControlPlanning.integrateAuxSys / SysID.integrateAuxSys (random operands of the C3 / C5a shapes: timing only)
+B, T, n, m, p = 1024, 50, 13, 4, 24
+Fm, Gm, Uxm, Uem = (rt.dev(rng.standard_normal(s) * .1) for s in ((B, T, n, n), (B, T, n, m), (B, T, m, n), (B, T, m, p)))
+dt = timeit(lambda: rt.cp_aux_integrate(Fm, Gm, Uxm, Uem)); res["C3 materialised ControlPlanning.integrateAuxSys, n=13 m=4 p=24 T=50 B=1024"] = (B / dt, dt * 1e3)
+B, T, n, p = 1024, 100, 13, 5
+Fm, Em = (rt.dev(rng.standard_normal(s) * .1) for s in ((B, T, n, n), (B, T, n, p)))
+dt = timeit(lambda: rt.sysid_aux_integrate(Fm, Em)); res["C5a materialised SysID.integrateAuxSys, n=13 p=5 T=100 B=1024"] = (B / dt, dt * 1e3)
 for k, (v, ms) in res.items(): print("%-82s %12.0f traj/s  %9.3f ms" % (k, v, ms))
 json.dump({k: {"traj_per_s": v, "ms": ms} for k, (v, ms) in res.items()}, open("gpurun_out/bench_configs.json", "w"), indent=1)
