@@ -144,9 +144,31 @@ typedef struct pdp_oc_auxsys {
     double *dynF, *dynG, *dynE, *Hxx, *Hxu, *Hxe, *Hux, *Huu, *Hue, *hxx, *hxe;
     double* dHu; /* optional extra (not part of the reference dict): dH/du [B][T][m] = c_u + f_u' lambda_{t+1}, the PMP
                     stationarity residual (dHu_fn, PDP.py:245-246) used by the batched OC solver */
+    const double* Huu_damp; /* optional INPUT [B]: Huu[b][t] += Huu_damp[b] I (Levenberg-Marquardt damping of the OC solver) */
 } pdp_oc_auxsys;
 int pdp_oc_auxsys_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta,
                           int theta_bstride, const pdp_oc_auxsys* out, void* stream);
+
+/* Batched optimal-control solve standing where OCSys.ocSolver hands its multiple-shooting NLP to IPOPT (PDP.py:121-220):
+ * stagewise Newton (Gauss-Newton + Levenberg-Marquardt damping far from the optimum) on the single-shooting problem, every
+ * trajectory of the batch in parallel, the iterations sequenced by the library on `stream` with no host round trip per
+ * iteration - costates -> H_u, Hessians (this library's kernels) -> LQ sub-problem (the LQR.lqrSolver kernel, p = 1) ->
+ * closed-loop line search over ls_trials step lengths -> per-sample acceptance.  The count of converged samples is polled
+ * every `check_every` iterations (that poll synchronises the stream).  Convergence: |H_u|_inf <= tol (1 + |u|_inf); at
+ * convergence (x, u, lam) satisfy the KKT conditions IPOPT solves, lam[t] = lambda_{t+1} = its `lam_g`.
+ *   in : x0 [B][n], theta, u [B][T][m] (initial controls, overwritten by the solution)
+ *   out: x [B][T+1][n], lam [B][T][n], cost [B], grad_norm [B], converged [B], *iterations (host),
+ *        gains [B][T][n m + m] (optional, NULL = skip): the LQR feedback {K^T, k} around the solution (closed-loop warm starts)
+ * straggler_patience > 0: stop once >= 90 % of the batch has converged and no further sample converged for that many
+ * iterations (the caller re-solves the rest from a neighbour's solution).  n <= 16, m <= 4. */
+typedef struct pdp_oc_solve_opts {
+    double tol, newton_switch;
+    int max_iter, check_every, ls_trials, straggler_patience, print_level;
+} pdp_oc_solve_opts;
+int64_t pdp_oc_solve_workspace_bytes(int B, int T, int ls_trials);
+int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, int theta_bstride, double* u, double* x, double* lam,
+                         double* cost, double* grad_norm, int32_t* converged, double* gains, const pdp_oc_solve_opts* opts,
+                         int* iterations, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Fused "forward + Riccati + PDP gradient" unit (the loop body of the IRL drivers,
  * Examples/IRL/cartpole/cartpole_PDP.py:45-74, with ocSolver replaced by the given controls, or by the

@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../include/pdp_hip.h"
-#include "pdp_riccati.h"
+#include "pdp_lqr_kernels.h"
 
 using namespace pdp;
 
@@ -22,175 +22,6 @@ inline int launched() {
     return PDP_E_LAUNCH;
 }
 #define PDP_CLEAR() (void)hipGetLastError()   // parameter tiles: p <= (16 - m) + 16 * (MAX_NT - 1)
-
-PDP_DEV const double* mat_at(const pdp_mat& M, int b, int t) {
-    return M.ptr ? M.ptr + (int64_t)b * M.bstride + (int64_t)t * M.tstride : nullptr;
-}
-
-// Streaming operand tiles.  Each lane keeps, per tile register, a pointer to ITS element of the current time step and the byte
-// stride to the same element of the next step; elements a tile does not have (padding, absent optional matrices) point at a zero
-// word with stride 0.  A load is then the bare global_load - no bound check, select or add behind it - so the tiles of step t-1
-// can be requested while step t computes and the wait lands at their first use (with post-processing next to the load the
-// compiler waits for the data immediately and every step pays an HBM round trip: 2.4 us per step instead of ~1).
-__device__ const double PDP_ZERO[2] = {0.0, 0.0};
-struct RunPtr { const double* p[4]; int step[4]; };
-template <int NR = 4>
-PDP_DEV RunPtr make_run(const pdp_mat& A, const TileMap& mA, const pdp_mat& Bm, const TileMap& mB, int b, int t) {
-    RunPtr r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        r.p[k] = PDP_ZERO; r.step[k] = 0;
-        if (k < NR) {
-            if (A.ptr && mA.off[k] >= 0) { r.p[k] = mat_at(A, b, t) + mA.off[k]; r.step[k] = (int)(A.tstride * 8); }
-            else if (Bm.ptr && mB.off[k] >= 0) { r.p[k] = mat_at(Bm, b, t) + mB.off[k]; r.step[k] = (int)(Bm.tstride * 8); }
-        }
-    }
-    return r;
-}
-template <int NR = 4>
-PDP_DEV d4 load_run(RunPtr& r, int dir) {          // read the current step's elements, then move by dir (+1 / -1) time steps
-    d4 v = zero4();
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { v[k] = *r.p[k]; r.p[k] = (const double*)((const char*)r.p[k] + dir * r.step[k]); }
-    return v;
-}
-
-// gains workspace per (b,t): KT [n*m] then k [m*p];  P/W workspace per (b,t): P [n*n] then W [n*p]
-template <int M, int NT>
-__global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
-                                                        double* __restrict__ Lo, int32_t* __restrict__ status,
-                                                        double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
-    __shared__ double scratch[RICCATI_SCRATCH];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int n = pr.n, p = pr.p, T = pr.T;
-    const int p0 = min(p, 16 - M);
-    const d4 z = zero4();
-    const int gsz = n * M + M * p, pwsz = n * n + n * p;
-    bool ok = true, finite = true;
-    // loop-invariant tile <-> dense maps of the first parameter tile (parameter columns sit behind the M control columns)
-    const TileMap mNN = make_dense_map<false>(n, n, n, 0, 0, lane), mNM = make_dense_map<false>(n, M, M, 0, 0, lane),
-                  mNP = make_dense_map<false>(n, p0, p, 0, M, lane), mMM = make_dense_map<false>(M, M, M, 0, 0, lane),
-                  mMP = make_dense_map<false>(M, p0, p, 0, M, lane), mFT = make_dense_map<true>(n, n, n, 0, 0, lane),
-                  mGT = make_dense_map<true>(n, M, M, 0, 0, lane);
-
-    // terminal condition: PP[T-1] = hxx, WW[T-1] = hxe (PDP.py:561-562)
-    d4 P = load_map(mat_at(pr.hxx, b, 0), mNN);
-    d4 W[NT];
-    {
-        const double* hxe = mat_at(pr.hxe, b, 0);
-        W[0] = hxe ? load_map(hxe, mNP) : z;
-#pragma unroll
-        for (int j = 1; j < NT; ++j) W[j] = hxe ? load_dense<false>(hxe + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane) : z;
-    }
-    // The matrices of step t-1 are requested from HBM before the Riccati step of t runs (one step = ~3k cycles of MFMA / VALU work,
-    // an HBM round trip ~2k): two steps per trip, the operand tiles alternating between two register sets.
-    struct BwdTiles { d4 Ft, Y2, Hxx, HX2, HU2; };
-    const pdp_mat none = {nullptr, 0, 0};
-    RunPtr rF = make_run(pr.F, mNN, none, mNN, b, T - 1), rY = make_run(pr.G, mNM, pr.E, mNP, b, T - 1), rHxx = make_run(pr.Hxx, mNN, none, mNN, b, T - 1),
-           rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1);
-    auto load_bwd = [&](BwdTiles& w) {     // (the request after the last step reads one step before the arrays' first: never used)
-        w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1); w.HU2 = load_run<1>(rHU, -1);
-    };
-    auto bstep = [&](int t, const BwdTiles& c, BwdTiles& nx) {
-        if (t > 0) load_bwd(nx);
-        if (ws_pw) {   // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
-            double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
-            store_map(pw, mNN, P);
-            store_map(pw + n * n, mNP, W[0]);
-#pragma unroll
-            for (int j = 1; j < NT; ++j) store_dense(pw + n * n + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane, W[j]);
-        }
-        RiccatiGains g;
-        d4 P_old;
-        ok = riccati_backward<M>(P, W[0], c.Ft, c.Y2, c.Hxx, c.HX2, c.HU2, scratch, lane, p0, g, P_old) && ok;
-        double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
-        store_map(gw, mNM, g.KT);
-        store_map<1>(gw + n * M, mMP, g.IK);
-        if constexpr (NT > 1) {
-            const double *E = mat_at(pr.E, b, t), *Hxe = mat_at(pr.Hxe, b, t), *Hue = mat_at(pr.Hue, b, t);
-#pragma unroll
-            for (int j = 1; j < NT; ++j) {
-                const int c0 = p0 + 16 * (j - 1), w = min(16, p - c0);
-                d4 Ej = E ? load_dense<false>(E + c0, n, w, p, 0, 0, lane) : z;
-                d4 Hxej = Hxe ? load_dense<false>(Hxe + c0, n, w, p, 0, 0, lane) : z;
-                d4 Huej = Hue ? load_dense<false>(Hue + c0, M, w, p, 0, 0, lane) : z;
-                d4 kj;
-                riccati_backward_extra(P_old, W[j], c.Ft, c.Y2, Ej, Hxej, Huej, g, kj);
-                store_dense(gw + n * M + c0, M, w, p, 0, 0, lane, kj);
-            }
-        }
-        finite = finite && tile_finite(P) && tile_finite(W[0]);
-    };
-    {
-        BwdTiles ta, tb;
-        load_bwd(ta);
-        int t = T - 1;
-        for (; t >= 1; t -= 2) { bstep(t, ta, tb); bstep(t - 1, tb, ta); }
-        if (t == 0) bstep(0, ta, tb);
-    }
-    // ---- forward rollout (PDP.py:582-608)
-    d4 X[NT];
-    {
-        const double* X0 = mat_at(pr.X0, b, 0);
-        X[0] = X0 ? load_map(X0, mNP) : z;
-#pragma unroll
-        for (int j = 1; j < NT; ++j) X[j] = X0 ? load_dense<false>(X0 + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane) : z;
-        double* x0o = Xo + (int64_t)b * (T + 1) * n * p;
-        store_map(x0o, mNP, X[0]);
-#pragma unroll
-        for (int j = 1; j < NT; ++j) store_dense(x0o + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane, X[j]);
-    }
-    __threadfence_block();
-    // forward sweep, same scheme: everything step t+1 reads for its first parameter tile is requested while step t computes
-    struct FwdTiles { d4 FT, GT, KT, Pt, k, Et, Wt; };
-    const pdp_mat gKT = {ws_gain, (int64_t)T * gsz, gsz}, gk = {ws_gain + n * M, (int64_t)T * gsz, gsz},
-                  wP = {ws_pw, (int64_t)T * pwsz, pwsz}, wW = {(ws_pw && Lo) ? ws_pw + n * n : nullptr, (int64_t)T * pwsz, pwsz};
-    RunPtr qFT = make_run(pr.F, mFT, none, mFT, b, 0), qGT = make_run<1>(pr.G, mGT, none, mGT, b, 0), qKT = make_run(gKT, mNM, none, mNM, b, 0),
-           qk = make_run<1>(gk, mMP, none, mMP, b, 0), qE = make_run(pr.E, mNP, none, mNP, b, 0), qP = make_run(wP, mNN, none, mNN, b, 0),
-           qW = make_run(wW, mNP, none, mNP, b, 0);
-    auto load_fwd = [&](FwdTiles& w) {
-        w.FT = load_run(qFT, 1); w.GT = load_run<1>(qGT, 1); w.KT = load_run(qKT, 1); w.k = load_run<1>(qk, 1);
-        w.Et = load_run(qE, 1); w.Pt = load_run(qP, 1); w.Wt = load_run(qW, 1);
-    };
-    auto fstep = [&](int t, const FwdTiles& c, FwdTiles& nx) {
-        if (t + 1 < T) load_fwd(nx);
-        const d4 KTn = -c.KT;
-        const double* E = mat_at(pr.E, b, t);
-        const double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
-        const double* pw = ws_pw ? ws_pw + ((int64_t)b * T + t) * pwsz : nullptr;
-        double* xo = Xo + ((int64_t)b * (T + 1) + t + 1) * n * p;
-        double* uo = Uo + ((int64_t)b * T + t) * M * p;
-        double* lo = Lo ? Lo + ((int64_t)b * T + t) * n * p : nullptr;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int c0 = (j == 0) ? 0 : p0 + 16 * (j - 1), w = (j == 0) ? p0 : min(16, p - c0), sh = (j == 0) ? M : 0;
-            d4 kn = (j == 0) ? -c.k : -load_dense<false>(gw + n * M + c0, M, w, p, 0, sh, lane);
-            d4 Et = (j == 0) ? c.Et : (E ? load_dense<false>(E + c0, n, w, p, 0, sh, lane) : z);
-            d4 U, Xn;
-            riccati_forward(KTn, kn, c.FT, c.GT, Et, X[j], U, Xn);
-            X[j] = Xn;
-            if (j == 0) { store_map<1>(uo, mMP, U); store_map(xo, mNP, Xn); }
-            else { store_dense(uo + c0, M, w, p, 0, sh, lane, U); store_dense(xo + c0, n, w, p, 0, sh, lane, Xn); }
-            if (lo) {
-                d4 Wt = (j == 0) ? c.Wt : load_dense<false>(pw + n * n + c0, n, w, p, 0, sh, lane);
-                d4 L = mma_tn(c.Pt, Xn, Wt);                    // P x+ + W  (P symmetric)
-                if (j == 0) store_map(lo, mNP, L); else store_dense(lo + c0, n, w, p, 0, sh, lane, L);
-            }
-            finite = finite && tile_finite(Xn);
-        }
-    };
-    {
-        FwdTiles ta, tb;
-        load_fwd(ta);
-        int t = 0;
-        for (; t + 1 < T; t += 2) { fstep(t, ta, tb); fstep(t + 1, tb, ta); }
-        if (t < T) fstep(t, ta, tb);
-    }
-    int st = 0;
-    if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
-    if (!ok) st |= PDP_STATUS_PIVOT;
-    if (lane == 0 && status) status[b] = st;
-}
 
 // U_t = Ux X + Ue ; X+ = F X + G U.   Generic n <= 16, m <= 16.  A wavefront carries NT tiles of 16 parameter columns (grid.y covers
 // the rest), so F, G and Ux are read once per NT tiles; the operands of step t+1 stream in while step t computes (see RunPtr).

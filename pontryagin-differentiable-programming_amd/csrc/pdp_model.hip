@@ -9,6 +9,7 @@
 #define PDP_HD __host__ __device__ inline
 #include PDP_MODEL_HEADER
 #include "pdp_model_kernels.h"
+#include "pdp_lqr_kernels.h"
 
 using namespace pdp;
 
@@ -84,6 +85,94 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         PDP_CLEAR();
         hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
                            dudp, status, (double*)ws);
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+// ---- batched Newton solve (pdp_oc_solve_batched): workspace carve-up and the iteration loop ---------------------------------
+template <class Mdl>
+struct OcSolveWs {
+    double *lam_eff, *F, *G, *Hxx, *Hxu, *Huu, *hxx, *dHu, *hxe0, *dX, *dU, *lqr, *xt, *ut, *Jt;
+    OcSolveState st;
+    int64_t bytes;
+    OcSolveWs(void* base, int B, int T, int K) {
+        constexpr int n = Mdl::NX, m = Mdl::NU;
+        char* p = (char*)base;
+        int64_t off = 0;
+        auto take = [&](int64_t count, int64_t elem) { void* r = p ? p + off : nullptr; off += (count * elem + 255) / 256 * 256; return r; };
+        const int64_t BT = (int64_t)B * T;
+        lam_eff = (double*)take(BT * n, 8); F = (double*)take(BT * n * n, 8); G = (double*)take(BT * n * m, 8);
+        Hxx = (double*)take(BT * n * n, 8); Hxu = (double*)take(BT * n * m, 8); Huu = (double*)take(BT * m * m, 8);
+        hxx = (double*)take((int64_t)B * n * n, 8); dHu = (double*)take(BT * m, 8); hxe0 = (double*)take((int64_t)B * n, 8);
+        dX = (double*)take((int64_t)B * (T + 1) * n, 8); dU = (double*)take(BT * m, 8); lqr = (double*)take(BT * (n * m + m), 8);
+        xt = (double*)take((int64_t)B * K * (T + 1) * n, 8); ut = (double*)take((int64_t)B * K * T * m, 8); Jt = (double*)take((int64_t)B * K, 8);
+        st.J = (double*)take(B, 8); st.mu = (double*)take(B, 8); st.gnorm = (double*)take(B, 8);
+        st.newton = (int32_t*)take(B, 4); st.converged = (int32_t*)take(B, 4); st.lqr_status = (int32_t*)take(B, 4); st.counters = (int32_t*)take(2, 4);
+        bytes = off;
+    }
+};
+
+template <class Mdl>
+int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u, double* x, double* lam, double* cost, double* grad_norm,
+             int32_t* converged, double* gains, const pdp_oc_solve_opts* op, int* iterations, void* ws, int64_t wsb, void* stv) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
+        constexpr int n = Mdl::NX, m = Mdl::NU;
+        if (B <= 0 || T <= 0 || !x0 || !th || !u || !x || !lam || !op || !ws) return PDP_E_ARG;
+        const int K = op->ls_trials > 0 ? op->ls_trials : 10, every = op->check_every > 0 ? op->check_every : 4;
+        OcSolveWs<Mdl> w(ws, B, T, K);
+        if (wsb < w.bytes) return PDP_E_ARG;
+        hipStream_t st = S(stv);
+        const int nchunk = (T + auxsys_chunk<Mdl>() - 1) / auxsys_chunk<Mdl>();
+        const dim3 gaux((unsigned)((int64_t)B * (nchunk + 1))), gB((B + 63) / 64), gBK((B * K + 63) / 64);
+        PDP_CLEAR();
+        (void)hipMemsetAsync(w.hxe0, 0, sizeof(double) * B * n, st);
+        (void)hipMemsetAsync(w.st.mu, 0, sizeof(double) * B, st);
+        (void)hipMemsetAsync(w.st.newton, 0, sizeof(int32_t) * B, st);
+        (void)hipMemsetAsync(w.st.counters, 0, sizeof(int32_t) * 2, st);
+        hipLaunchKernelGGL((oc_rollout_kernel<Mdl>), gB, dim3(64), 0, st, B, T, x0, u, th, tb, x, w.st.J);
+        // LQ sub-problem for (dx, du): the LQR.lqrSolver kernel with p = 1, Hue := H_u, E = Hxe = 0 (PDP.py:557-608)
+        pdp_lqr_problem pr{};
+        pr.B = B; pr.T = T; pr.n = n; pr.m = m; pr.p = 1;
+        pr.F = {w.F, (int64_t)T * n * n, n * n}; pr.G = {w.G, (int64_t)T * n * m, n * m}; pr.Hxx = {w.Hxx, (int64_t)T * n * n, n * n};
+        pr.Hxu = {w.Hxu, (int64_t)T * n * m, n * m}; pr.Huu = {w.Huu, (int64_t)T * m * m, m * m}; pr.Hue = {w.dHu, (int64_t)T * m, m};
+        pr.hxx = {w.hxx, n * n, 0}; pr.hxe = {w.hxe0, n, 0};
+        auto lq = [&]() { hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr); };
+        pdp_oc_auxsys only_hu{}, hess{};
+        only_hu.dHu = w.dHu;
+        hess.dynF = w.F; hess.dynG = w.G; hess.Hxx = w.Hxx; hess.Hxu = w.Hxu; hess.Huu = w.Huu; hess.hxx = w.hxx; hess.Huu_damp = w.st.mu;
+        int it = 0, last_nconv = 0, last_gain = 0, nconv = 0;
+        for (it = 0; it < op->max_iter; ++it) {
+            hipLaunchKernelGGL((oc_costate_kernel<Mdl>), gB, dim3(64), 0, st, B, T, x, u, th, tb, lam);
+            hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), gaux, dim3(64), 0, st, B, T, x, u, lam, th, tb, only_hu);
+            hipLaunchKernelGGL((oc_newton_prepare_kernel<Mdl>), dim3(B), dim3(64), 0, st, B, T, it, op->tol, op->newton_switch, u, w.dHu, lam, w.lam_eff, w.st);
+            if (it % every == 0 || op->print_level > 0) {                 // poll the number of converged samples (synchronises the stream)
+                int32_t c = 0;
+                if (hipMemcpyAsync(&c, &w.st.counters[it & 1], sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess) return PDP_E_LAUNCH;
+                if (hipStreamSynchronize(st) != hipSuccess) return launched() ? PDP_E_LAUNCH : PDP_E_LAUNCH;
+                nconv = c;
+                if (op->print_level > 0) fprintf(stderr, "  pdp_oc_solve iter %3d  converged %d/%d\n", it, nconv, B);
+                if (nconv == B) break;
+                // stragglers: most of the batch done and nothing new for a while -> stop, the caller re-solves the rest from a neighbour
+                if (nconv > last_nconv) { last_nconv = nconv; last_gain = it; }
+                else if (op->straggler_patience > 0 && nconv >= 0.9 * B && it - last_gain >= op->straggler_patience) break;
+            }
+            hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), gaux, dim3(64), 0, st, B, T, x, u, w.lam_eff, th, tb, hess);
+            lq();
+            hipLaunchKernelGGL((oc_linesearch_kernel<Mdl>), gBK, dim3(64), 0, st, B, T, K, x0, u, x, w.lqr, th, tb, w.xt, w.ut, w.Jt);
+            hipLaunchKernelGGL((oc_ls_select_kernel<Mdl>), dim3(B), dim3(64), 0, st, B, T, K, w.dHu, w.dU, w.xt, w.ut, w.Jt, x, u, w.st);
+        }
+        if (it == op->max_iter) hipLaunchKernelGGL((oc_costate_kernel<Mdl>), gB, dim3(64), 0, st, B, T, x, u, th, tb, lam);
+        if (gains) {       // time-varying LQR feedback around the final trajectory (full Hamiltonian Hessians, no damping)
+            hess.Huu_damp = nullptr;
+            hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), gaux, dim3(64), 0, st, B, T, x, u, lam, th, tb, only_hu);
+            hipLaunchKernelGGL((oc_auxsys_kernel<Mdl>), gaux, dim3(64), 0, st, B, T, x, u, lam, th, tb, hess);
+            lq();
+            (void)hipMemcpyAsync(gains, w.lqr, sizeof(double) * (int64_t)B * T * (n * m + m), hipMemcpyDeviceToDevice, st);
+        }
+        if (cost) (void)hipMemcpyAsync(cost, w.st.J, sizeof(double) * B, hipMemcpyDeviceToDevice, st);
+        if (grad_norm) (void)hipMemcpyAsync(grad_norm, w.st.gnorm, sizeof(double) * B, hipMemcpyDeviceToDevice, st);
+        if (converged) (void)hipMemcpyAsync(converged, w.st.converged, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st);
+        if (iterations) *iterations = it;
         return launched();
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
@@ -211,6 +300,14 @@ int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const
 int pdp_oc_auxsys_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta, int tb, const pdp_oc_auxsys* out,
                           void* stream) {
     return oc_auxsys<PdpModel>(B, T, x, u, lam, theta, tb, out, stream);
+}
+int64_t pdp_oc_solve_workspace_bytes(int B, int T, int ls_trials) {
+    if constexpr (PdpModel::KIND == PDP_KIND_OC) return OcSolveWs<PdpModel>(nullptr, B, T, ls_trials > 0 ? ls_trials : 10).bytes; else return 0;
+}
+int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, int tb, double* u, double* x, double* lam, double* cost,
+                         double* grad_norm, int32_t* converged, double* gains, const pdp_oc_solve_opts* opts, int* iterations, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+    return oc_solve<PdpModel>(B, T, x0, theta, tb, u, x, lam, cost, grad_norm, converged, gains, opts, iterations, workspace, workspace_bytes, stream);
 }
 int64_t pdp_oc_pdp_workspace_bytes(int B, int T) {
     if constexpr (PdpModel::KIND == PDP_KIND_OC) return oc_ws_bytes<PdpModel>(B, T); else return 0;

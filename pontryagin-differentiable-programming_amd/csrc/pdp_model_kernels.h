@@ -162,13 +162,15 @@ template <class Mdl>
 __host__ __device__ constexpr int auxsys_chunk() { return Mdl::CHUNK < 16 ? Mdl::CHUNK : 16; }
 
 template <class Mdl, int MAT>
-PDP_DEV void auxsys_expand(const double* blk, const short* codes, int nc, int stride, int cnt, double* __restrict__ dst, int lane) {
+PDP_DEV void auxsys_expand(const double* blk, const short* codes, int nc, int stride, int cnt, double* __restrict__ dst, int lane,
+                           double diag = 0.0) {      // diag: added to the diagonal (Levenberg-Marquardt damping of Huu in the OC solver)
     constexpr int RC = Mdl::PATH_ROWS[MAT] * Mdl::PATH_COLS[MAT];
     if (!dst || RC == 0) return;
     for (int q = lane; q < cnt * RC; q += 64) {
         const int tl = q / RC, i = q - tl * RC;
         const int code = codes[i];
-        dst[q] = code >= 0 ? blk[nc + tl * stride + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
+        const double v = code >= 0 ? blk[nc + tl * stride + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
+        dst[q] = (diag != 0.0 && i % (Mdl::PATH_COLS[MAT] + 1) == 0) ? v + diag : v;
     }
 }
 
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const doubl
     auxsys_expand<Mdl, 3>(blk, codes + oHxx, NC, STRIDE, cnt, o.Hxx ? o.Hxx + bt0 * NX * NX : nullptr, lane);
     auxsys_expand<Mdl, 4>(blk, codes + oHxu, NC, STRIDE, cnt, o.Hxu ? o.Hxu + bt0 * NX * NU : nullptr, lane);
     auxsys_expand<Mdl, 5>(blk, codes + oHxe, NC, STRIDE, cnt, o.Hxe ? o.Hxe + bt0 * NX * NP : nullptr, lane);
-    auxsys_expand<Mdl, 6>(blk, codes + oHuu, NC, STRIDE, cnt, o.Huu ? o.Huu + bt0 * NU * NU : nullptr, lane);
+    auxsys_expand<Mdl, 6>(blk, codes + oHuu, NC, STRIDE, cnt, o.Huu ? o.Huu + bt0 * NU * NU : nullptr, lane, o.Huu_damp ? o.Huu_damp[b] : 0.0);
     auxsys_expand<Mdl, 7>(blk, codes + oHue, NC, STRIDE, cnt, o.Hue ? o.Hue + bt0 * NU * NP : nullptr, lane);
     if (o.Hux) {                                             // Hux = Hxu' (the reference stores both, PDP.py:295)
         double* dst = o.Hux + bt0 * NU * NX;
@@ -257,6 +259,134 @@ __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const doubl
             const int code = codes[oHxu + i * NU + j];
             dst[q] = code >= 0 ? blk[NC + tl * STRIDE + code] : blk[code == -1 ? 0 : 1 + (-2 - code)];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OC: batched Newton solve (pdp_oc_solve_batched): per-sample bookkeeping between the costate / aux / LQR / rollout kernels.
+// The iteration logic is the one of pdp_amd/ocsolver.py (which documents the choices); here it runs without the host.
+// ------------------------------------------------------------------------------------------------------
+struct OcSolveState {            // per-sample solver state in the workspace
+    double *J, *mu, *gnorm;      // cost of the current trajectory, Levenberg-Marquardt damping, |H_u|_inf
+    int32_t *newton, *converged, *lqr_status;
+    int32_t* counters;           // [2]: number of converged samples of even / odd iterations (polled by the host)
+};
+PDP_DEV double wave_max_nan(double v) {                      // max over the wave; NaN if any lane holds NaN (like torch.amax)
+    bool nan = v != v;
+    v = nan ? 0.0 : v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return __any(nan) ? __builtin_nan("") : v;
+}
+
+// after the costates: stationarity residual, convergence, Newton / Gauss-Newton mode, costates used for the Hessians
+template <class Mdl>
+__global__ void __launch_bounds__(64) oc_newton_prepare_kernel(int B, int T, int it, double tol, double newton_switch, const double* __restrict__ u,
+                                                                const double* __restrict__ dHu, const double* __restrict__ lam,
+                                                                double* __restrict__ lam_eff, OcSolveState s) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double g = 0.0, um = 0.0;
+    for (int q = lane; q < T * NU; q += 64) {
+        const double h = fabs(dHu[(int64_t)b * T * NU + q]), a = fabs(u[(int64_t)b * T * NU + q]);
+        g = (h != h || g != g) ? __builtin_nan("") : fmax(g, h);
+        um = (a != a || um != um) ? __builtin_nan("") : fmax(um, a);
+    }
+    g = wave_max_nan(g);
+    const double scale = 1.0 + wave_max_nan(um);
+    const bool conv = g <= tol * scale;
+    // Newton once the residual is small relative to the controls (Gauss-Newton, always a descent direction, before), with
+    // hysteresis: a sample whose residual has grown back by two orders of magnitude is no longer in Newton's basin
+    const bool newton = (s.newton[b] != 0 && g <= 100.0 * newton_switch * scale) || g <= newton_switch * scale;
+    for (int q = lane; q < T * NX; q += 64) lam_eff[(int64_t)b * T * NX + q] = newton ? lam[(int64_t)b * T * NX + q] : 0.0;   // GN: Hessians at lambda = 0
+    if (lane == 0) {
+        s.gnorm[b] = g; s.converged[b] = conv; s.newton[b] = newton;
+        if (conv) atomicAdd(&s.counters[it & 1], 1);
+        if (b == 0) s.counters[(it + 1) & 1] = 0;
+    }
+}
+
+// closed-loop line search: one lane per (sample, trial); trial k uses alpha = 2^-k
+template <class Mdl>
+__global__ void oc_linesearch_kernel(int B, int T, int K, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
+                                     const double* __restrict__ gains, const double* __restrict__ theta, int tb, double* __restrict__ xt,
+                                     double* __restrict__ ut, double* __restrict__ Jt) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, GSZ = NX * NU + NU;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K) return;
+    const int b = idx / K, k = idx - b * K;
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
+    const double a = ldexp(1.0, -k);
+    double xc[NX], xn[NX], uc[NU];
+    double* xb = xt + (int64_t)idx * (T + 1) * NX;
+    double* ub = ut + (int64_t)idx * T * NU;
+    const double* xr = xbar + (int64_t)b * (T + 1) * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double* g = gains + ((int64_t)b * T + t) * GSZ;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            double v = ubar[((int64_t)b * T + t) * NU + j] - a * g[NX * NU + j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= g[i * NU + j] * (xc[i] - xr[t * NX + i]);
+            uc[j] = v;
+            ub[t * NU + j] = v;
+        }
+        Mdl::dyn(xc, uc, th, pc, xn);
+        J += Mdl::path_cost(xc, uc, th, pc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
+    }
+    Jt[idx] = J + Mdl::final_cost(xc, th, pc);
+}
+
+// Armijo selection among the trials, acceptance of the step, damping / mode update (one wavefront per sample)
+template <class Mdl>
+__global__ void __launch_bounds__(64) oc_ls_select_kernel(int B, int T, int K, const double* __restrict__ dHu, const double* __restrict__ dU,
+                                                           const double* __restrict__ xt, const double* __restrict__ ut, const double* __restrict__ Jt,
+                                                           double* __restrict__ x, double* __restrict__ u, OcSolveState s) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    // first-order change of the cost along the open-loop direction, sum_t H_u' du, must be negative
+    double sl = 0.0;
+    bool fin = true;
+    for (int q = lane; q < T * NU; q += 64) {
+        const double d = dU[(int64_t)b * T * NU + q];
+        sl += dHu[(int64_t)b * T * NU + q] * d;
+        fin = fin && fabs(d) <= 1.7e308;
+    }
+    sl = wave_sum(sl);
+    const bool conv = s.converged[b] != 0, newton = s.newton[b] != 0;
+    const bool bad = s.lqr_status[b] != 0 || !__all(fin) || !(sl < 0.0);
+    const double J = s.J[b];
+    int pick = -1;
+    if (!conv && !bad) {
+        for (int k = 0; k < K; ++k) {
+            const double a = ldexp(1.0, -k), Jk = Jt[(int64_t)b * K + k];
+            if (fabs(Jk) <= 1.7e308 && Jk <= J + 1e-4 * a * sl + 1e-13 * fabs(J)) { pick = k; break; }      // Armijo, up to rounding of J
+        }
+    }
+    if (pick >= 0) {
+        const double* xs = xt + ((int64_t)b * K + pick) * (T + 1) * NX;
+        const double* us = ut + ((int64_t)b * K + pick) * T * NU;
+        for (int q = lane; q < (T + 1) * NX; q += 64) x[(int64_t)b * (T + 1) * NX + q] = xs[q];
+        for (int q = lane; q < T * NU; q += 64) u[(int64_t)b * T * NU + q] = us[q];
+    }
+    if (lane == 0) {
+        const bool failed = pick < 0 && !conv;                // no acceptable step (bad direction included)
+        if (pick >= 0) s.J[b] = Jt[(int64_t)b * K + pick];
+        // failure: Newton falls back to Gauss-Newton, Gauss-Newton raises its damping; success: relax the damping
+        double mu = s.mu[b];
+        if (failed && !newton) mu = fmax(mu * 4.0, 1e-4);
+        else if (!failed) mu *= 0.5;
+        if (mu < 1e-8) mu = 0.0;
+        s.mu[b] = mu;
+        s.newton[b] = newton && !failed;
     }
 }
 

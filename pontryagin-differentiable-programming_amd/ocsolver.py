@@ -1,6 +1,6 @@
 """Batched optimal-control solve on the GPU - stands where the reference's OCSys.ocSolver hands a multiple-shooting NLP to
 IPOPT (PDP/PDP.py:121-220).  Stagewise Newton / iLQR on the single-shooting problem, every trajectory of the batch in
-parallel, all arithmetic in the HIP kernels (Python only sequences launches and does the per-sample line-search bookkeeping):
+parallel, all arithmetic and the iteration loop in the model library (pdp_oc_solve_batched); per iteration:
 
     repeat:  costates  lambda = c_x + f_x' lambda+           (pdp_oc_costate_batched)
              F, G, Hxx, Hxu, Huu, hxx, H_u along (x,u,lambda) (pdp_oc_auxsys_batched)
@@ -25,7 +25,17 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
            straggler_patience=0):
     """oc: PDP.OCSys.  ini_state [B,n]; auxvar_value [p] or [B,p]; returns dict of CUDA tensors
     state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], iterations (int), converged [B] (bool).
-    u_init (optional warm start) is used per sample only where its rollout is finite and cheaper than u = 0."""
+    u_init (optional warm start) is used per sample only where its rollout is finite and cheaper than u = 0.
+    The iterations run inside the model library (pdp_oc_solve_batched, csrc/pdp_model.hip: oc_solve), which sequences
+
+        costates  lambda = c_x + f_x' lambda+ , stationarity residual H_u                  (oc_costate / oc_auxsys kernels)
+        per sample: converged?  Newton or Gauss-Newton (Hessians at lambda = 0)?           (oc_newton_prepare_kernel)
+        F, G, Hxx, Hxu, Huu + mu I, hxx                                                    (oc_auxsys kernel)
+        LQ sub-problem for (dx, du): the LQR.lqrSolver kernel with p = 1, Hue := H_u       (lqr_solve_kernel)
+        closed-loop rollouts u = ubar - alpha k - K (x - xbar) for alpha = 1, 1/2, ...     (oc_linesearch_kernel)
+        Armijo selection, step acceptance, damping / mode update                           (oc_ls_select_kernel)
+
+    on the stream without a host round trip per iteration; Python only picks the starting controls."""
     torch = runtime.torch_cuda()
     mdl = oc.model()
     n, m = mdl.n, mdl.m
@@ -33,81 +43,18 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
     B, T = x0.shape[0], int(horizon)
     th = oc._theta(auxvar_value, B)
     u = torch.zeros((B, T, m), dtype=torch.float64, device="cuda")
-    x, J = mdl.oc_rollout(x0, u, th)
     if u_init is not None:
         uw = runtime.dev(u_init).reshape(B, T, m)
-        xw, Jw = mdl.oc_rollout(x0, uw, th)
-        better = torch.isfinite(Jw) & torch.isfinite(xw).all(dim=(1, 2)) & ((Jw < J) | ~torch.isfinite(J) | force_init)
-        u, x, J = torch.where(better.view(B, 1, 1), uw, u), torch.where(better.view(B, 1, 1), xw, x), torch.where(better, Jw, J)
-    zeros_lam = torch.zeros((B, T, n), dtype=torch.float64, device="cuda")
-    hxe0 = torch.zeros((B, n, 1), dtype=torch.float64, device="cuda")
-    mu = torch.zeros((B,), dtype=torch.float64, device="cuda")            # Levenberg-Marquardt damping per sample
-    newton = torch.zeros((B,), dtype=torch.bool, device="cuda")            # per-sample mode: False = Gauss-Newton (iLQR), True = Newton
-    eye_m = torch.eye(m, dtype=torch.float64, device="cuda")
-    keys = ("dynF", "dynG", "Hxx", "Hxu", "Huu", "hxx", "dHu")
-    converged = torch.zeros((B,), dtype=torch.bool, device="cuda")
-    gnorm = torch.full((B,), float("inf"), dtype=torch.float64, device="cuda")
-    it = 0
-    last_nconv, last_gain = 0, 0
-    for it in range(max_iter):
-        lam = mdl.oc_costate(x, u, th)
-        aux = mdl.oc_auxsys(x, u, lam, th, only=keys)
-        gnorm = aux["dHu"].abs().amax(dim=(1, 2))
-        scale = 1.0 + u.abs().amax(dim=(1, 2))
-        converged = gnorm <= tol * scale
-        if print_level:
-            print("  ocsolver iter %3d  max|H_u| %.3e  mean cost %.10g  converged %d/%d  newton %d  max mu %.1e" % (
-                it, float(gnorm.max()), float(J.mean()), int(converged.sum()), B, int(newton.sum()), float(mu.max())))
-        if bool(converged.all()):
-            break
-        # stragglers: once most of the batch is done and nothing new has converged for a while, stop - solve_batch re-solves the
-        # rest from the closed-loop warm start of a converged neighbour, which takes a handful of iterations
-        nconv = int(converged.sum())
-        if nconv > last_nconv:
-            last_nconv, last_gain = nconv, it
-        elif straggler_patience and nconv >= 0.9 * B and it - last_gain >= straggler_patience:
-            break
-        # Newton once the stationarity residual is small relative to the controls, Gauss-Newton (always a descent direction) before
-        # (with hysteresis: a sample whose residual has grown back by two orders of magnitude is no longer in Newton's basin)
-        newton = (newton & (gnorm <= 100.0 * NEWTON_SWITCH * scale)) | (gnorm <= NEWTON_SWITCH * scale)
-        if bool((~newton).any()):                                            # Gauss-Newton Hessians = Hamiltonian Hessians at lambda = 0
-            gn = mdl.oc_auxsys(x, u, zeros_lam, th, only=("Hxx", "Hxu", "Huu"))
-            sel = (~newton).view(B, 1, 1, 1)
-            Hxx, Hxu, Huu = torch.where(sel, gn["Hxx"], aux["Hxx"]), torch.where(sel, gn["Hxu"], aux["Hxu"]), torch.where(sel, gn["Huu"], aux["Huu"])
+        if force_init:
+            xw, Jw = mdl.oc_rollout(x0, uw, th)
+            better = torch.isfinite(Jw) & torch.isfinite(xw).all(dim=(1, 2))
         else:
-            Hxx, Hxu, Huu = aux["Hxx"], aux["Hxu"], aux["Huu"]
-        Huu = Huu + mu.view(B, 1, 1, 1) * eye_m
-        _, dU, _, status, gains = runtime.lqr_solve(aux["dynF"], aux["dynG"], Hxx, Huu, aux["hxx"], hxe0, Hxu=Hxu, Hue=aux["dHu"].unsqueeze(-1),
-                                                    want_costate=False, return_gains=True)
-        # first-order change of the cost along the open-loop direction, sum_t H_u' du, must be negative
-        slope = (aux["dHu"] * dU.squeeze(-1)).sum(dim=(1, 2))
-        bad = (status != 0) | ~torch.isfinite(dU).all(dim=(1, 2, 3)) | ~(slope < 0)
-        alpha = torch.where(bad | converged, torch.zeros_like(J), torch.ones_like(J))
-        accepted = converged | bad
-        x_new, u_new, J_new = x, u, J
-        for _ls in range(10):
-            xt, ut, Jt = mdl.oc_rollout_feedback(x0, u, x, gains, alpha, th)
-            ok = torch.isfinite(Jt) & (Jt <= J + 1e-4 * alpha * slope + 1e-13 * J.abs()) & ~accepted      # Armijo, up to rounding of J
-            sel3 = ok.view(B, 1, 1)
-            x_new, u_new, J_new = torch.where(sel3, xt, x_new), torch.where(sel3, ut, u_new), torch.where(ok, Jt, J_new)
-            accepted = accepted | ok
-            if bool(accepted.all()):
-                break
-            alpha = torch.where(accepted, alpha, alpha * 0.5)
-        failed = (~accepted | bad) & ~converged                               # no acceptable step
-        x, u, J = x_new, u_new, J_new                                         # (unchanged where nothing was accepted)
-        # failure: Newton falls back to Gauss-Newton; Gauss-Newton raises its damping.  success: relax the damping.
-        mu = torch.where(failed & ~newton, torch.clamp(mu * 4.0, min=1e-4), torch.where(failed, mu, mu * 0.5))
-        mu = torch.where(mu < 1e-8, torch.zeros_like(mu), mu)
-        newton = newton & ~failed
-    lam = mdl.oc_costate(x, u, th)
-    out = {"state": x, "control": u, "costate": lam, "cost": J, "grad_norm": gnorm, "iterations": it, "converged": converged}
-    if want_gains:      # time-varying LQR feedback around the final trajectory (closed-loop warm starts of neighbouring problems)
-        aux = mdl.oc_auxsys(x, u, lam, th, only=keys)
-        _, _, _, _, gains = runtime.lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], hxe0, Hxu=aux["Hxu"],
-                                              Hue=aux["dHu"].unsqueeze(-1), want_costate=False, return_gains=True)
-        out["gains"] = gains.clone()
-    return out
+            _, J = mdl.oc_rollout(x0, u, th)
+            xw, Jw = mdl.oc_rollout(x0, uw, th)
+            better = torch.isfinite(Jw) & torch.isfinite(xw).all(dim=(1, 2)) & ((Jw < J) | ~torch.isfinite(J))
+        u = torch.where(better.view(B, 1, 1), uw, u)
+    return mdl.oc_solve(x0, u, th, tol=tol, newton_switch=NEWTON_SWITCH, max_iter=max_iter, straggler_patience=straggler_patience,
+                        print_level=print_level, want_gains=want_gains)
 
 
 def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,

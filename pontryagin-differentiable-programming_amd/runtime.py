@@ -32,7 +32,12 @@ class PdpModelInfo(C.Structure):
 
 
 class PdpOcAuxsys(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue", "hxx", "hxe", "dHu")]
+    _fields_ = [(k, C.c_void_p) for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue", "hxx", "hxe", "dHu", "Huu_damp")]
+
+
+class PdpOcSolveOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("newton_switch", C.c_double), ("max_iter", C.c_int), ("check_every", C.c_int), ("ls_trials", C.c_int),
+                ("straggler_patience", C.c_int), ("print_level", C.c_int)]
 
 
 class PdpPolicy(C.Structure):
@@ -42,6 +47,7 @@ class PdpPolicy(C.Structure):
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
                 "pdp_sysid_aux_integrate_batched"]
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
+                 "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched",
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
@@ -203,6 +209,8 @@ _MODEL_SIGS = {
     "pdp_oc_costate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
     "pdp_oc_rollout_feedback_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
+    "pdp_oc_solve_workspace_bytes": (_I64, [_I, _I, _I]),
+    "pdp_oc_solve_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcSolveOpts), C.POINTER(C.c_int), _VP, _I64, _VP]),
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
     "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
@@ -278,6 +286,30 @@ class ModelLib:
         check(self.lib.pdp_oc_rollout_feedback_batched(B, T, ptr(x0), ptr(ubar), ptr(xbar), ptr(gains), ptr(alpha), ptr(th), tb, ptr(x), ptr(u), ptr(cost),
                                                        current_stream_ptr()), "pdp_oc_rollout_feedback_batched")
         return x, u, cost
+
+    def oc_solve(self, x0, u_init, theta, tol=1e-9, newton_switch=1e-2, max_iter=300, check_every=4, ls_trials=10, straggler_patience=0,
+                 print_level=0, want_gains=False):
+        """Batched Newton solve of the OC problem (pdp_oc_solve_batched; stands where OCSys.ocSolver calls IPOPT).  u_init [B,T,m] is
+        not modified.  Returns dict(state, control, costate, cost, grad_norm, converged (bool), iterations[, gains])."""
+        torch = torch_cuda()
+        x0, u = dev(x0).reshape(-1, self.n), dev(u_init).clone()
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        f64 = dict(dtype=torch.float64, device="cuda")
+        x, lam = torch.empty((B, T + 1, self.n), **f64), torch.empty((B, T, self.n), **f64)
+        cost, gnorm = torch.empty((B,), **f64), torch.empty((B,), **f64)
+        conv = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        gains = torch.empty((B, T, self.n * self.m + self.m), **f64) if want_gains else None
+        nbytes = self.lib.pdp_oc_solve_workspace_bytes(B, T, ls_trials)
+        ws = torch.empty((max(nbytes, 8) // 8,), **f64)
+        opts = PdpOcSolveOpts(tol, newton_switch, int(max_iter), int(check_every), int(ls_trials), int(straggler_patience), int(print_level))
+        it = C.c_int(0)
+        check(self.lib.pdp_oc_solve_batched(B, T, ptr(x0), ptr(th), tb, ptr(u), ptr(x), ptr(lam), ptr(cost), ptr(gnorm), ptr(conv), ptr(gains),
+                                            C.byref(opts), C.byref(it), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_batched")
+        out = {"state": x, "control": u, "costate": lam, "cost": cost, "grad_norm": gnorm, "converged": conv != 0, "iterations": it.value}
+        if want_gains:
+            out["gains"] = gains
+        return out
 
     def oc_costate(self, x, u, theta):
         torch = torch_cuda()
