@@ -1013,6 +1013,10 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 // activations of the forward pass are kept in LDS for the backward pass; F, G, c_x, c_u come from the lane = time-step
 // chunk evaluation like in the other fused kernels.
 struct AdjLayout { int theta, xs, acts, actw, zs, ds, mu, v, blk, total; };
+// time steps per evaluation pass of the adjoint kernel: its LDS footprint (parameters, trajectory, activations) already limits a CU
+// to ~2 workgroups, so the pool takes as many rows as a wavefront has lanes when that fits 34 KB (fewer passes: +13 % at p = 420)
+template <class Mdl>
+__host__ __device__ constexpr int adjoint_chunk() { return 64 * (Mdl::PATH_NVAR | 1) * 8 <= 34 * 1024 ? 64 : Mdl::CHUNK; }
 template <class Mdl>
 __host__ __device__ inline AdjLayout cp_adjoint_layout(const pdp_policy& pol, int p, int T) {
     AdjLayout L;
@@ -1026,7 +1030,7 @@ __host__ __device__ inline AdjLayout cp_adjoint_layout(const pdp_policy& pol, in
     L.ds = o; o += 8 * MLP_MAX_WIDTH;                  // per-layer deltas of the current step
     L.mu = o; o += Mdl::NX;
     L.v = o; o += Mdl::NU + Mdl::NX;                   // v_t, then (d pi/dx)' v_t
-    L.blk = o; o += 1 + Mdl::PATH_NCONST + Mdl::CHUNK * (Mdl::PATH_NVAR | 1);
+    L.blk = o; o += 1 + Mdl::PATH_NCONST + adjoint_chunk<Mdl>() * (Mdl::PATH_NVAR | 1);
     L.total = o + 8;
     return L;
 }
@@ -1035,7 +1039,7 @@ template <class Mdl>
 __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0,
                                                               const double* __restrict__ theta, int tb, double* __restrict__ loss,
                                                               double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = Mdl::CHUNK, W = MLP_MAX_WIDTH;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = adjoint_chunk<Mdl>(), W = MLP_MAX_WIDTH;
     constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const AdjLayout L = cp_adjoint_layout<Mdl>(pol, p, T);

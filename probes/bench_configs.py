@@ -33,6 +33,8 @@ mdl = zoo.get("quadrotor", "oc"); B, T, p = 256, 100, 420
 x0 = np.zeros((B, 13)); x0[:, :3] = rng.uniform(-2, 2, (B, 3)); x0[:, 6] = 1
 x0d, th = rt.dev(x0), rt.dev(0.1 * rng.standard_normal(p)); pol = rt.make_policy("mlp", layers=[13, 13, 4])
 dt = timeit(lambda: mdl.cp_step(pol, p, x0d, th, T), n=3, warm=1); res["C5b quadrotor MLP-policy step T=100 p=420 B=256 (fused adjoint kernel)"] = (B / dt, dt * 1e3)
+B = 1024; x0 = np.zeros((B, 13)); x0[:, :3] = rng.uniform(-2, 2, (B, 3)); x0[:, 6] = 1; x0d = rt.dev(x0)
+dt = timeit(lambda: mdl.cp_step(pol, p, x0d, th, T), n=3, warm=1); res["C5b quadrotor MLP-policy step T=100 p=420 B=1024 (one GPU's shard of C5)"] = (B / dt, dt * 1e3)
 # C2: cart-pole IRL iteration (OC solve warm-started + PDP gradient), T=50, B=256 per-sample theta
 from test_gpu_ocsolver import make_oc
 oc = make_oc("cartpole"); B, T = 256, 50
