@@ -961,11 +961,15 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 #pragma unroll
     for (int j = 0; j < NT; ++j) { X[j] = z; acc[j] = 0.0; }
     const int row0 = lane >> 4, col = lane & 15;
+    // d pi/d theta = [b_0 I_m ... b_N I_m]: this lane's element of tile j is b_{piv}(t) where piv is fixed (rows < m live in register 0)
+    int piv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { const int cidx = 16 * j + col; piv[j] = (cidx < p && row0 < M && (cidx % NU) == row0) ? cidx / NU : -1; }
     const int nchunk = (T + CH - 1) / CH;
     const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = 0; c < nchunk; ++c) {
         const int t0 = c * ch, cnt = min(ch, T - t0);
-        __syncthreads();
+        wave_lds_sync();
         if (lane < cnt) {
             const int t = t0 + lane;
             double xc[NX], uc[NU];
@@ -976,22 +980,33 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
             PackedSink s{pool + lane * STRIDE};
             Mdl::eval_path(xc, uc, nullptr, nullptr, pc, s);
         }
-        __syncthreads();
-        for (int tl = 0; tl < cnt; ++tl) {
+        wave_lds_sync();
+        // per-step operands are gathered one step ahead (running LDS offsets); two steps per trip, the sensitivity tiles and the
+        // prefetched operands alternating between two register sets
+        GatherRun rFT = gather_at(gFT, 0), rGT = gather_at(gGT, 0), rCX = gather_at(gCX, 0), rCU = gather_at(gCU, 0);
+        struct Ops { d4 FT, GT, CX, CU; };
+        auto request = [&](Ops& o) { o.FT = gather_run(blk, rFT, 1); o.GT = gather_run<1>(blk, rGT, 1); o.CX = gather_run(blk, rCX, 1); o.CU = gather_run<1>(blk, rCU, 1); };
+        auto step = [&](int tl, const Ops& o, Ops& nx, const d4 (&Xc)[NT], d4 (&Xn)[NT]) {
             const int t = t0 + tl;
-            d4 FT = gather_tile(blk, gFT, tl);
-            d4 GT = gather_tile_r0(blk, gGT, tl);
-            d4 CX = gather_tile(blk, gCX, tl);
-            d4 CU = gather_tile_r0(blk, gCU, tl);
+            if (tl + 1 < cnt) request(nx);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int cidx = 16 * j + col;                 // parameter index of this lane's column
-                d4 Ue = z;                                      // d pi/d theta = [b_0 I_m ... b_N I_m]   (rows < m live in register 0)
-                if (cidx < p && row0 < M && (cidx % NU) == row0) Ue[0] = basis[t * np + cidx / NU];
-                acc[j] += CX[0] * X[j][0] + CX[1] * X[j][1] + CX[2] * X[j][2] + CX[3] * X[j][3] + CU[0] * Ue[0];
-                d4 Xn = mma_tn(FT, X[j], z);
-                X[j] = mma_tn_r0(GT, Ue, Xn);
+                d4 Ue = z;
+                if (piv[j] >= 0) Ue[0] = basis[t * np + piv[j]];
+                acc[j] += o.CX[0] * Xc[j][0] + o.CX[1] * Xc[j][1] + o.CX[2] * Xc[j][2] + o.CX[3] * Xc[j][3] + o.CU[0] * Ue[0];
+                d4 Xf = mma_tn(o.FT, Xc[j], z);
+                Xn[j] = mma_tn_r0(o.GT, Ue, Xf);
             }
+        };
+        Ops oa, ob;
+        d4 Xb[NT];
+        request(oa);
+        int tl = 0;
+        for (; tl + 1 < cnt; tl += 2) { step(tl, oa, ob, X, Xb); step(tl + 1, ob, oa, Xb, X); }
+        if (tl < cnt) {
+            step(tl, oa, ob, X, Xb);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) X[j] = Xb[j];
         }
     }
 #pragma unroll
