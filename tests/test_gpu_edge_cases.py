@@ -18,9 +18,10 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 33, 120])
+@pytest.mark.parametrize("T", [1, 2, 3, 16, 17, 33, 64, 65, 120])
 def test_fused_unit_any_horizon_matches_oracle(golden_dir, T):
-    """horizons around the chunk size (16), T = 1, and a long one (LDS staging grows with T): cart-pole, B = 3"""
+    """odd / even horizons (the step loops run two steps per trip), T = 1, horizons around the chunk size of this model (64 lane-steps:
+    one chunk, 64 + 1 -> two chunks of 33 and 32) and a long one (LDS staging grows with T): cart-pole, B = 3"""
     from oracle import models, pdp_oracle as po
     from pdp_amd import zoo
     mdl = zoo.get("cartpole", "irl")
