@@ -27,22 +27,7 @@ struct PackedSink {            // variable entry k -> base[k]   (LDS pool row of
     template <int K> PDP_DEV void put(double v) { base[K] = v; }
 };
 
-template <class Mdl> struct OcPathDense {   // scatter into the dense API layout; Hux written as Hxu^T
-    double* p[9];               // F G E Hxx Hxu Hxe Huu Hue, [8] = Hux
-    template <int K> PDP_DEV void put(double v) {
-        constexpr int mat = Mdl::PATH_MAT[K], off = Mdl::PATH_OFF[K];
-        if (p[mat]) p[mat][off] = v;
-        if constexpr (mat == 4) { if (p[8]) p[8][(off % Mdl::NU) * Mdl::NX + off / Mdl::NU] = v; }
-    }
-};
-template <class Mdl> struct OcFinDense {
-    double* p[2];
-    template <int K> PDP_DEV void put(double v) {
-        constexpr int mat = Mdl::FIN_MAT[K], off = Mdl::FIN_OFF[K];
-        if (p[mat]) p[mat][off] = v;
-    }
-};
-template <class Mdl> struct PathDense {     // generic: group 'path' of CP / SYSID models
+template <class Mdl> struct PathDense {     // scatter into the dense API layout: group 'path' of CP / SYSID models
     double* p[4];
     template <int K> PDP_DEV void put(double v) {
         constexpr int mat = Mdl::PATH_MAT[K], off = Mdl::PATH_OFF[K];
@@ -428,11 +413,6 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
     d4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = lds[g.off[r] + tl * g.tmul[r]];
-    return v;
-}
-PDP_DEV d4 gather_tile_r0(const double* lds, const Gather& g, int tl) {
-    d4 v = zero4();
-    v[0] = lds[g.off[0] + tl * g.tmul[0]];
     return v;
 }
 

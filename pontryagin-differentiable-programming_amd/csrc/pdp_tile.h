@@ -19,7 +19,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace pdp {
 
-PDP_DEV int lane_id() { return threadIdx.x & 63; }
 PDP_DEV int tile_row(int lane, int r) { return (lane >> 4) + 4 * r; }
 PDP_DEV int tile_col(int lane) { return lane & 15; }
 
@@ -56,13 +55,6 @@ PDP_DEV d4 load_dense(const double* __restrict__ M, int R, int C, int ld, int ro
         v[r] = x;
     }
     return v;
-}
-// Add-load: tile += dense block (used to pack two matrices side by side in one tile)
-template <bool TRANS>
-PDP_DEV d4 load_dense_into(d4 v, const double* __restrict__ M, int R, int C, int ld, int roff, int coff, int lane) {
-    if (M == nullptr) return v;
-    d4 w = load_dense<TRANS>(M, R, C, ld, roff, coff, lane);
-    return v + w;
 }
 PDP_DEV void store_dense(double* __restrict__ M, int R, int C, int ld, int roff, int coff, int lane, const d4 v) {
 #pragma unroll
@@ -165,12 +157,6 @@ PDP_DEV double readlane_f64(double v, int src) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
-}
-
-// tile <-> 16x16 row-major LDS scratch (conflict-free: consecutive lanes, consecutive addresses)
-PDP_DEV void tile_to_lds(double* s, const d4 v, int lane) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[64 * r + lane] = v[r];
 }
 
 // In-register inverse of an M x M matrix (M <= 4) by Gauss-Jordan with partial pivoting, executed
