@@ -130,7 +130,7 @@ def _mat(t, B, time_varying):
     return PdpMat(t.data_ptr(), bs, ts), t
 
 
-def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0=None, T=None, want_costate=True, return_gains=False):
+def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0=None, T=None, want_costate=True):
     """Batched LQR.lqrSolver.  Time-varying families are [B,T,r,c] (or [T,r,c] shared over the batch, or [r,c]
     time-invariant); terminal / initial ones [B,r,c] or [r,c].  Returns (X [B,T+1,n,p], U [B,T,m,p], Lam or None, status [B])."""
     torch = torch_cuda()
@@ -167,8 +167,6 @@ def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0
     ws = torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device="cuda")
     rc = lib.pdp_lqr_solve_batched(C.byref(pr), ptr(X), ptr(U), ptr(Lam), ptr(status), ptr(ws), nbytes, current_stream_ptr())
     check(rc, "pdp_lqr_solve_batched")
-    if return_gains:       # feedback gains {K^T [n][m], k [m][p]} per (b,t): the head of the workspace
-        return X, U, Lam, status, ws[:B * T * (n * m + m * p)].view(B, T, n * m + m * p)
     return X, U, Lam, status
 
 

@@ -76,3 +76,32 @@ def test_ocSolver_dropin_signature(golden_dir):
     assert np.abs(traj["costate_traj_opt"] - d["costate"][0]).max() < 1e-6 * np.abs(d["costate"][0]).max()
     traj1 = oc.ocSolver(d["state"][0, 0], 50, d["true_parameter"], costate_option=1)
     assert np.abs(traj1["costate_traj_opt"] - traj["costate_traj_opt"]).max() < 1e-8 * np.abs(d["costate"][0]).max()
+
+
+def test_oc_solve_entry_point_returns_a_kkt_point():
+    """pdp_oc_solve_batched called directly (no batch-level globalisation on top): at convergence the outputs satisfy the conditions
+    IPOPT solves - x is the rollout of u, lam the costate recursion along (x, u), |H_u| below the tolerance - and the reported
+    cost / gradient norm / gains describe that point; the caller's initial controls are left untouched."""
+    import torch
+    oc = make_oc("pendulum")
+    mdl = oc.model()
+    rng = np.random.default_rng(5)
+    B, T = 37, 20
+    x0 = np.stack([rng.uniform(-0.5, 0.5, B), np.zeros(B)], axis=1)
+    th = np.array([1.0, 1.0, 0.05, 10.0, 1.0]) * (1 + 0.1 * rng.uniform(-1, 1, (B, 5)))
+    u0 = torch.zeros((B, T, 1), dtype=torch.float64, device="cuda")
+    sol = mdl.oc_solve(x0, u0, th, tol=1e-9, max_iter=100, want_gains=True)
+    assert bool(sol["converged"].all()) and 0 < sol["iterations"] < 100 and float(u0.abs().max()) == 0.0
+    x, J = mdl.oc_rollout(x0, sol["control"], th)
+    assert float((x - sol["state"]).abs().max()) <= 1e-12 and float((J - sol["cost"]).abs().max()) <= 1e-10 * float(J.abs().max())
+    lam = mdl.oc_costate(sol["state"], sol["control"], th)
+    assert float((lam - sol["costate"]).abs().max()) <= 1e-12 * max(1.0, float(lam.abs().max()))
+    hu = mdl.oc_auxsys(sol["state"], sol["control"], sol["costate"], th, only=("dHu",))["dHu"]
+    scale = 1 + sol["control"].abs().amax(dim=(1, 2))
+    assert bool((hu.abs().amax(dim=(1, 2)) <= 1e-9 * scale).all())
+    assert float((hu.abs().amax(dim=(1, 2)) - sol["grad_norm"]).abs().max()) <= 1e-12
+    # the gains are the LQR feedback around the solution: rolling them out from a perturbed initial state is a descent start
+    xp = x0 + 0.05 * rng.standard_normal(x0.shape)
+    _, u_cl, J_cl = mdl.oc_rollout_feedback(xp, sol["control"], sol["state"], sol["gains"], torch.zeros((B,), dtype=torch.float64, device="cuda"), th)
+    _, J_ol = mdl.oc_rollout(xp, sol["control"], th)
+    assert bool((J_cl <= J_ol + 1e-12).all())
