@@ -6,10 +6,12 @@
                            loss, dp = aux system + Riccati + chain rule  (fused kernel)
                            theta_{k+1} = theta_k - lr * mean(dp)
 
-Demonstrations: the reference's stored demos (tests/golden/demos_<sys>.npz).  Results are saved with the reference's
-field names (results.loss_trace / parameter_trace / learning_rate / time_passed) so its plotting scripts keep working.
+Demonstrations: the reference's stored demos (tests/golden/demos_<sys>.npz), or any `<name>_demos.mat` written by the reference's
+generate_demos.py (field names trajectories[i].state_traj_opt / control_traj_opt, true_parameter, dt; e.g.
+Examples/IRL/cartpole/generate_demos.py:38-43) through --demos.  Results are saved with the reference's field names
+(results.loss_trace / parameter_trace / learning_rate / time_passed) so its plotting scripts keep working.
 
-    python examples/irl_pdp.py --system cartpole --iters 200 --lr 1e-4
+    python examples/irl_pdp.py --system cartpole --iters 200 --lr 1e-4 [--demos path/to/cartpole_demos.mat]
 """
 import argparse
 import os
@@ -26,6 +28,18 @@ from pdp_amd import PDP, ocsolver, zoo          # noqa: E402
 from pdp_amd.sx import vertcat                  # noqa: E402
 
 
+def load_demos(path):
+    """(state [B,T+1,n], control [B,T,m], true_parameter [p]) from the npz fixtures or from a .mat in the reference's schema"""
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return d["state"], d["control"], d["true_parameter"]
+    d = sio.loadmat(path)
+    tr = d["trajectories"]
+    xs = np.stack([np.asarray(tr[0, i]["state_traj_opt"][0, 0], dtype=float) for i in range(tr.shape[1])])
+    us = np.stack([np.asarray(tr[0, i]["control_traj_opt"][0, 0], dtype=float) for i in range(tr.shape[1])])
+    return xs, us, d["true_parameter"].astype(float).flatten()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--system", default="cartpole", choices=["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
@@ -34,6 +48,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.3, help="initial parameter = true + U(-sigma/2, sigma/2)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--demos", default=None, help="<name>_demos.mat in the reference's schema (default: the stored demos of --system)")
     a = ap.parse_args()
 
     env, dt = zoo.make_env(a.system, "irl")
@@ -46,8 +61,7 @@ def main():
     oc.setFinalCost(env.final_cost)
     oc.diffPMP()
 
-    d = np.load(os.path.join(ROOT, "tests", "golden", "demos_%s.npz" % a.system))
-    demo_x, demo_u, true_parameter = d["state"], d["control"], d["true_parameter"]
+    demo_x, demo_u, true_parameter = load_demos(a.demos or os.path.join(ROOT, "tests", "golden", "demos_%s.npz" % a.system))
     T = demo_u.shape[1]
     rng = np.random.default_rng(a.seed)
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2
