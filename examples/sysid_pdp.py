@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """System identification with PDP on the GPU - the loop of the reference's Examples/SysID/<sys>/*_PDP.py (quadrotor/uav_PDP.py:33-59)
-on the reference's stored input/state data (tests/golden/iodata_<sys>.npz), optionally replicated into a larger batch.
+on the reference's stored input/state data (tests/golden/iodata_<sys>.npz), or any `<stem>_iodata.mat` written by the reference's
+generate_traj.py (struct <stem>_iodata with batch_inputs / batch_states / true_parameter, e.g.
+Examples/SysID/quadrotor/generate_traj.py:36-42) through --data.
 
-    python examples/sysid_pdp.py --system quadrotor --iters 2000 --lr 1e-4
+    python examples/sysid_pdp.py --system quadrotor --iters 2000 --lr 1e-4 [--data path/to/uav_iodata.mat]
 """
 import argparse
 import os
@@ -18,6 +20,17 @@ sys.path.insert(0, ROOT)
 from pdp_amd import PDP, zoo          # noqa: E402
 
 
+def load_iodata(path):
+    """(inputs [B,T,m], states [B,T+1,n], true_parameter [p]) from the npz fixtures or from a .mat in the reference's schema"""
+    if path.endswith(".npz"):
+        io = np.load(path)
+        return io["inputs"], io["states"], io["true_parameter"]
+    d = sio.loadmat(path)
+    key = [k for k in d if k.endswith("_iodata")][0]
+    x = d[key][0, 0]
+    return np.asarray(x["batch_inputs"], float), np.asarray(x["batch_states"], float), np.asarray(x["true_parameter"], float).flatten()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--system", default="quadrotor", choices=["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
@@ -26,6 +39,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.6)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--data", default=None, help="<stem>_iodata.mat in the reference's schema (default: the stored data of --system)")
     a = ap.parse_args()
     env, dt = zoo.make_env(a.system, "sysid")
     sid = PDP.SysID(a.system)
@@ -33,10 +47,9 @@ def main():
     sid.setStateVariable(env.X)
     sid.setControlVariable(env.U)
     sid.setDyn(env.X + dt * env.f)
-    io = np.load(os.path.join(ROOT, "tests", "golden", "iodata_%s.npz" % a.system))
-    batch_inputs = [io["inputs"][i] for i in range(io["inputs"].shape[0])]
-    batch_states = [io["states"][i] for i in range(io["states"].shape[0])]
-    true_parameter = io["true_parameter"]
+    inputs, states, true_parameter = load_iodata(a.data or os.path.join(ROOT, "tests", "golden", "iodata_%s.npz" % a.system))
+    batch_inputs = [inputs[i] for i in range(inputs.shape[0])]
+    batch_states = [states[i] for i in range(states.shape[0])]
     rng = np.random.default_rng(a.seed)
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2
     loss_trace, parameter_trace = [], []

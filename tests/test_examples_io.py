@@ -30,3 +30,12 @@ def test_irl_example_reads_reference_mat_schema(tmp_path, golden_dir):
     assert np.array_equal(x, d["state"]) and np.array_equal(u, d["control"]) and np.array_equal(th, d["true_parameter"])
     x2, u2, th2 = irl.load_demos(os.path.join(golden_dir, "demos_cartpole.npz"))
     assert np.array_equal(x2, x) and np.array_equal(u2, u) and np.array_equal(th2, th)
+
+
+def test_sysid_example_reads_reference_mat_schema(tmp_path, golden_dir):
+    sid = _example("sysid_pdp")
+    d = np.load(os.path.join(golden_dir, "iodata_quadrotor.npz"))
+    path = str(tmp_path / "uav_iodata.mat")
+    sio.savemat(path, {"uav_iodata": {"batch_inputs": d["inputs"], "batch_states": d["states"], "true_parameter": list(d["true_parameter"])}})
+    u, x, th = sid.load_iodata(path)
+    assert np.array_equal(u, d["inputs"]) and np.array_equal(x, d["states"]) and np.array_equal(th, d["true_parameter"])
