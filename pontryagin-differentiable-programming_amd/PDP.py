@@ -181,6 +181,14 @@ class OCSys:
                 "time": numpy.array([k for k in range(horizon + 1)]), "horizon": horizon, "cost": np.array([[float(sol["cost"][0])]])}
 
 
+    def ocSolver_batch(self, ini_state, horizon, auxvar_value, **kwargs):
+        """ocSolver for a batch: ini_state [B,n], auxvar_value [p] or [B,p] -> dict of CUDA tensors state [B,T+1,n], control [B,T,m],
+        costate [B,T,n], cost [B], converged [B], ... (ocsolver.solve_batch; kwargs: u_init, warm_start, want_gains, tol, max_iter)"""
+        from . import ocsolver
+        self._require()
+        return ocsolver.solve_batch(self, ini_state, int(horizon), auxvar_value, **kwargs)
+
+
 def _label(name):
     s = "".join(ch if ch.isalnum() else "_" for ch in str(name).lower()).strip("_")
     return (s[:24] or "model")
