@@ -143,6 +143,13 @@ def test_irl_script_flow_cartpole_with_stored_demos(golden_dir):
     # host-side Function objects of diffPMP behave like casadi Functions
     F0 = cartpoleoc.dfx_fn(d["state"][i, 0], d["control"][i, 0], d["true_parameter"]).full()
     assert rel(F0, ra["dynF"][i, 0]) < 1e-12
+    # ocSolver (one trajectory, the reference's dict) and ocSolver_batch (all demos at once) reach the stored IPOPT optima
+    one = cartpoleoc.ocSolver(ini_state=d["state"][i, 0], horizon=d["control"].shape[1], auxvar_value=d["true_parameter"])
+    assert set(one) == {"state_traj_opt", "control_traj_opt", "costate_traj_opt", "auxvar_value", "time", "horizon", "cost"}
+    assert rel(one["state_traj_opt"], d["state"][i]) < 1e-6 and rel(one["costate_traj_opt"], d["costate"][i]) < 1e-6
+    allb = cartpoleoc.ocSolver_batch(d["state"][:, 0], d["control"].shape[1], d["true_parameter"])
+    assert bool(allb["converged"].all()) and rel(allb["state"].cpu().numpy(), d["state"]) < 1e-6
+    assert rel(allb["cost"].cpu().numpy(), d["cost"]) < 1e-9
 
 
 def test_lqr_class_input_polymorphism(golden_dir):
