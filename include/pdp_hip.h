@@ -216,9 +216,12 @@ int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const doub
  * optional x [B][T+1][n], u [B][T][m] (NULL = not stored).  PDP_POLICY_POLY with p <= 64: forward sensitivities on MFMA tiles
  * (the reference's own formulation); PDP_POLICY_MLP (<= 8 layers of <= 32 units, p <= 512) and larger Lagrange policies: the same
  * gradient by one adjoint sweep, O(T (n^2 + p)) instead of O(T n^2 p).  The materialised route of the reference
- * (integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched) stays available for getAuxSys/integrateAuxSys. */
+ * (integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched) stays available for getAuxSys/integrateAuxSys.
+ * workspace (optional, NULL = none): pdp_cp_step_workspace_bytes(B,T,pol,p) bytes; given it, the adjoint kernel keeps the hidden
+ * activations of an MLP policy there instead of in LDS when that is what limits occupancy (0 bytes = not needed). */
+int64_t pdp_cp_step_workspace_bytes(int B, int T, const pdp_policy* pol, int p);
 int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int theta_bstride,
-                        double* loss, double* grad, double* x, double* u, void* stream);
+                        double* loss, double* grad, double* x, double* u, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- PDP_KIND_SYSID --------------------------------------------------------------------------------- */
 

@@ -211,9 +211,26 @@ int cp_step_launch(int B, int T, const pdp_policy* pol, int p, const double* x0,
     hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
     return launched();
 }
+inline int device_cu_count() {
+    static int n = 0;
+    if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
+template <class Mdl>
+int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
+    if constexpr (Mdl::KIND == PDP_KIND_CP) {
+        if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;
+        bool offload; int rows;
+        cp_adjoint_plan<Mdl>(*pol, p, T, B, device_cu_count(), true, offload, rows);
+        if (!offload) return 0;
+        int actw = 0;
+        for (int k = 0; k + 1 < pol->n_layers; ++k) actw += pol->sizes[k];
+        return (int64_t)B * T * actw * (int64_t)sizeof(double);
+    } else { return 0; }
+}
 template <class Mdl>
 int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
-            void* st) {
+            void* ws, int64_t wsb, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_CP && Mdl::NX <= 16 && Mdl::NU <= 4) {
         if (B <= 0 || T <= 0 || !pol || !x0 || !th || !loss || !grad) return PDP_E_ARG;
         if (pol->kind == PDP_POLICY_MLP || p > 64) {          // adjoint (reverse-mode) kernel: MLP policy, or many Lagrange pivots
@@ -224,11 +241,14 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 for (int k = 0; k < pol->n_layers; ++k) { if (pol->sizes[k] > MLP_MAX_WIDTH || pol->sizes[k] < 1) return PDP_E_SIZE; cnt += pol->sizes[k] * cols + pol->sizes[k]; cols = pol->sizes[k]; }
                 if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
             } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
-            const size_t lds = sizeof(double) * (size_t)cp_adjoint_layout<Mdl>(*pol, p, T).total;
+            bool offload; int rows;
+            cp_adjoint_plan<Mdl>(*pol, p, T, B, device_cu_count(), ws != nullptr && wsb >= cp_step_ws_bytes<Mdl>(B, T, pol, p), offload, rows);
+            const size_t lds = sizeof(double) * (size_t)cp_adjoint_layout<Mdl>(*pol, p, T, offload, rows).total;
             if (lds > 160 * 1024) return PDP_E_SIZE;
             (void)hipFuncSetAttribute((const void*)cp_step_adjoint_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             PDP_CLEAR();
-            hipLaunchKernelGGL((cp_step_adjoint_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
+            hipLaunchKernelGGL((cp_step_adjoint_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u,
+                               offload ? (double*)ws : (double*)nullptr, rows);
             return launched();
         }
         if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
@@ -325,9 +345,10 @@ int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const doub
                           double* dynG, double* dUx, double* dUe, double* dcx, double* dcu, double* dhx, void* stream) {
     return cp_auxsys<PdpModel>(B, T, pol, p, x, u, theta, tb, dynF, dynG, dUx, dUe, dcx, dcu, dhx, stream);
 }
+int64_t pdp_cp_step_workspace_bytes(int B, int T, const pdp_policy* pol, int p) { return cp_step_ws_bytes<PdpModel>(B, T, pol, p); }
 int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int tb, double* loss, double* grad,
-                        double* x, double* u, void* stream) {
-    return cp_step<PdpModel>(B, T, pol, p, x0, theta, tb, loss, grad, x, u, stream);
+                        double* x, double* u, void* workspace, int64_t workspace_bytes, void* stream) {
+    return cp_step<PdpModel>(B, T, pol, p, x0, theta, tb, loss, grad, x, u, workspace, workspace_bytes, stream);
 }
 int pdp_sysid_integrate_batched(int B, int T, const double* x0, const double* u, const double* theta, int tb, double* x, void* stream) {
     return sysid_integrate<PdpModel>(B, T, x0, u, theta, tb, x, stream);

@@ -1008,39 +1008,57 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 // activations of the forward pass are kept in LDS for the backward pass; F, G, c_x, c_u come from the lane = time-step
 // chunk evaluation like in the other fused kernels.
 struct AdjLayout { int theta, xs, acts, actw, zs, ds, mu, v, blk, total; };
-// time steps per evaluation pass of the adjoint kernel: its LDS footprint (parameters, trajectory, activations) already limits a CU
-// to ~2 workgroups, so the pool takes as many rows as a wavefront has lanes when that fits 34 KB (fewer passes: +13 % at p = 420)
+// `rows`: time steps per evaluation pass (pool rows, <= 64 lanes); `offload`: the stored hidden activations live in a global
+// workspace instead of LDS.  Resident, the kernel's LDS footprint (parameters, trajectory, activations, pool) limits a CU to ~2
+// workgroups at p = 420, T = 100; with the activations offloaded and the pool sized to the remainder it fits the 40 KB that let 4
+// wavefronts (one per SIMD) share a CU - a batch of 1024 then runs in one wave of workgroups instead of two.
 template <class Mdl>
-__host__ __device__ constexpr int adjoint_chunk() { return 64 * (Mdl::PATH_NVAR | 1) * 8 <= 34 * 1024 ? 64 : Mdl::CHUNK; }
-template <class Mdl>
-__host__ __device__ inline AdjLayout cp_adjoint_layout(const pdp_policy& pol, int p, int T) {
+__host__ __device__ inline AdjLayout cp_adjoint_layout(const pdp_policy& pol, int p, int T, bool offload, int rows) {
     AdjLayout L;
     int o = 0;
     L.theta = o; o += p;
     L.xs = o; o += (T + 1) * Mdl::NX;
     L.actw = 0;                                        // hidden activations stored per time step (MLP): sum of hidden widths
     if (pol.kind == PDP_POLICY_MLP) for (int k = 0; k + 1 < pol.n_layers; ++k) L.actw += pol.sizes[k];
-    L.acts = o; o += T * L.actw;
+    L.acts = o; o += offload ? 0 : T * L.actw;
     L.zs = o; o += 8 * MLP_MAX_WIDTH + 1;              // per-layer inputs z_k of the current step (+ a constant 1.0 for the biases)
     L.ds = o; o += 8 * MLP_MAX_WIDTH;                  // per-layer deltas of the current step
     L.mu = o; o += Mdl::NX;
     L.v = o; o += Mdl::NU + Mdl::NX;                   // v_t, then (d pi/dx)' v_t
-    L.blk = o; o += 1 + Mdl::PATH_NCONST + adjoint_chunk<Mdl>() * (Mdl::PATH_NVAR | 1);
+    L.blk = o; o += 1 + Mdl::PATH_NCONST + rows * (Mdl::PATH_NVAR | 1);
     L.total = o + 8;
     return L;
+}
+// host: how the adjoint kernel is laid out for (policy, p, T): resident when that fits 40 KB or no workspace is given, else offloaded
+template <class Mdl>
+__host__ inline void cp_adjoint_plan(const pdp_policy& pol, int p, int T, int B, int n_cu, bool have_ws, bool& offload, int& rows) {
+    const int stride = Mdl::PATH_NVAR | 1;
+    rows = 64 * stride * 8 <= 34 * 1024 ? 64 : Mdl::CHUNK;       // as many pool rows as a wavefront has lanes when that fits 34 KB
+    offload = false;
+    const int resident_bytes = cp_adjoint_layout<Mdl>(pol, p, T, false, rows).total * 8;
+    if (!have_ws || pol.kind != PDP_POLICY_MLP || resident_bytes <= 40 * 1024) return;
+    if ((int64_t)B <= (int64_t)n_cu * (160 * 1024 / resident_bytes)) return;     // the whole batch is resident at once anyway: keep everything in LDS
+    const int fixed = cp_adjoint_layout<Mdl>(pol, p, T, true, 0).total;
+    const int fit = (40 * 1024 / 8 - fixed) / stride;
+    if (fit < 8) return;                               // not even a small pool fits next to the trajectory: stay resident
+    offload = true;
+    rows = fit < 64 ? fit : 64;
 }
 
 template <class Mdl>
 __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0,
                                                               const double* __restrict__ theta, int tb, double* __restrict__ loss,
-                                                              double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = adjoint_chunk<Mdl>(), W = MLP_MAX_WIDTH;
+                                                              double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo,
+                                                              double* __restrict__ ws_acts, int CH) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = MLP_MAX_WIDTH;
     constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const AdjLayout L = cp_adjoint_layout<Mdl>(pol, p, T);
+    const bool offload = ws_acts != nullptr;
+    const AdjLayout L = cp_adjoint_layout<Mdl>(pol, p, T, offload, CH);
     double *ths = lds + L.theta, *xs = lds + L.xs, *acts = lds + L.acts, *zs = lds + L.zs, *ds = lds + L.ds, *mu = lds + L.mu,
            *vv = lds + L.v, *blk = lds + L.blk, *pool = blk + NC;
     const int b = blockIdx.x, lane = threadIdx.x;
+    double* actg = offload ? ws_acts + (int64_t)b * T * L.actw : nullptr;      // [T][actw], each element written and re-read by the same lane
     const bool mlp = pol.kind == PDP_POLICY_MLP;
     const int nl = mlp ? pol.n_layers : 0, np = pol.n_pivots;
     double pc[Mdl::NPC];
@@ -1099,7 +1117,7 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
             }
             if (k + 1 < nl) {
                 double zk = tanh(a);
-                if (lane < rows) { zs[(k + 1) * W + lane] = zk; if (store_acts) acts[t * L.actw + aoff[k] + lane] = zk; }
+                if (lane < rows) { zs[(k + 1) * W + lane] = zk; if (store_acts) { if (offload) actg[t * L.actw + aoff[k] + lane] = zk; else acts[t * L.actw + aoff[k] + lane] = zk; } }
             } else if (lane < NU) vv[lane] = a;
             wave_lds_sync();
         }
@@ -1156,6 +1174,13 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
     }
     enc(lane < NX ? Mdl::path_code(2, lane) : -1, cxo, cxm);
     enc(lane < NU ? Mdl::path_code(3, lane) : -1, cuo, cum);
+    // offloaded activations of step t are requested from the workspace one step ahead (the sweep visits t = T-1 .. 0 in order)
+    double apre[8];
+    auto request_acts = [&](int t, double (&a)[8]) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) a[k] = (k < nl && lane < lrows[k - 1]) ? actg[t * L.actw + aoff[k - 1] + lane] : 0.0;
+    };
+    if (offload) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); request_acts(T - 1, apre); }
     const int nchunk = (T + CH - 1) / CH;
     const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = nchunk - 1; c >= 0; --c) {
@@ -1195,7 +1220,16 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
                 wave_lds_sync();
             } else {
                 if (lane < NX) zs[lane] = xs[t * NX + lane];
-                for (int k = 1; k < nl; ++k) if (lane < lrows[k - 1]) zs[k * W + lane] = acts[t * L.actw + aoff[k - 1] + lane];
+                if (offload) {
+                    double anext[8];
+                    if (t > 0) request_acts(t - 1, anext);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) if (k < nl && lane < lrows[k - 1]) zs[k * W + lane] = apre[k];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) apre[k] = (t > 0) ? anext[k] : 0.0;
+                } else {
+                    for (int k = 1; k < nl; ++k) if (lane < lrows[k - 1]) zs[k * W + lane] = acts[t * L.actw + aoff[k - 1] + lane];
+                }
                 if (lane < NU) ds[(nl - 1) * W + lane] = vv[lane];
                 wave_lds_sync();
                 for (int k = nl - 1; k >= 0; --k) {

@@ -49,7 +49,7 @@ CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_bat
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
                  "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched",
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
-                 "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
+                 "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
 _core = None
 
@@ -213,7 +213,8 @@ _MODEL_SIGS = {
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
     "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_cp_auxsys_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "pdp_cp_step_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "pdp_cp_step_workspace_bytes": (_I64, [_I, _I, C.POINTER(PdpPolicy), _I]),
+    "pdp_cp_step_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
     "pdp_sysid_integrate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
     "pdp_sysid_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pdp_sysid_step_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
@@ -417,7 +418,10 @@ class ModelLib:
         grad = torch.empty((B, p), dtype=torch.float64, device="cuda")
         x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda") if want_traj else None
         u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda") if want_traj else None
-        rc = self.lib.pdp_cp_step_batched(B, int(T), C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(loss), ptr(grad), ptr(x), ptr(u), current_stream_ptr())
+        nbytes = self.lib.pdp_cp_step_workspace_bytes(B, int(T), C.byref(pol), p)
+        ws = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda") if nbytes > 0 else None
+        rc = self.lib.pdp_cp_step_batched(B, int(T), C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(loss), ptr(grad), ptr(x), ptr(u), ptr(ws), nbytes,
+                                          current_stream_ptr())
         if rc == -2 and pol.kind == 1:          # policy outside the fused kernel's limits: the reference's materialised route
             return self.cp_step_materialised(pol, p, x0, th, T, want_traj)
         check(rc, "pdp_cp_step_batched")

@@ -141,6 +141,28 @@ def test_C5_quadrotor_neural_policy_T100_p420():
         assert np.abs(fd - g[:3, k]).max() <= 1e-5 * max(np.abs(g[:3, k]).max(), 1e-9)
 
 
+def test_C5_neural_policy_full_shard_equals_small_batch():
+    """C5b at one GPU's shard (B = 1024): the adjoint kernel then keeps the hidden activations in its HBM workspace and uses a smaller
+    evaluation pool (4 wavefronts per CU); the arithmetic per trajectory is the same as in the LDS-resident layout used for small
+    batches - loss and gradient of the first 16 trajectories agree to rounding with the 16-trajectory run."""
+    from pdp_amd import runtime as rt, zoo
+    mdl = zoo.get("quadrotor", "oc")
+    rng = np.random.default_rng(3)
+    B, T, p = 1024, 100, 420
+    theta = 0.1 * rng.standard_normal(p)
+    x0 = np.zeros((B, 13))
+    x0[:, :3] = rng.uniform(-2, 2, (B, 3))
+    x0[:, 6] = 1.0
+    pol = rt.make_policy("mlp", layers=[13, 13, 4])
+    assert mdl.lib.pdp_cp_step_workspace_bytes(B, T, rt.C.byref(pol), p) == B * T * 26 * 8          # offloaded: 13 + 13 activations per step
+    assert mdl.lib.pdp_cp_step_workspace_bytes(16, T, rt.C.byref(pol), p) == 0                      # resident
+    L, G = mdl.cp_step(pol, p, x0, theta, T)
+    l, g = mdl.cp_step(pol, p, x0[:16], theta, T)
+    L, G, l, g = npy(L), npy(G), npy(l), npy(g)
+    assert np.all(np.isfinite(G)) and np.abs(L[:16] - l).max() <= 1e-13 * np.abs(l).max()
+    assert np.abs(G[:16] - g).max() <= 1e-12 * np.abs(g).max()
+
+
 def test_lqr_sensitivity_is_linear_in_the_parameter_columns():
     """size-independent property of the aux-system solve: the solution is linear in (E, Hxe, Hue, hxe, X0) - doubling those
     columns doubles X, U, Lambda; a zero right-hand side gives a zero solution (B = 2048 random problems)."""
