@@ -59,9 +59,16 @@ __global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, c
 #pragma unroll
     for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
     double J = 0.0;
-    for (int t = 0; t < T; ++t) {
+    // a lane walks its own trajectory: every per-step load is an uncoalesced HBM round trip, so the operands of step t+1 are
+    // requested before step t computes (the addresses do not depend on the recursion)
+    const double* ub = u + (int64_t)b * T * NU;
+    double un[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
+    for (int i = 0; i < NU; ++i) un[i] = ub[i];
+    for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { uc[i] = un[i]; un[i] = ub[tn * NU + i]; }
         Mdl::dyn(xc, uc, th, pc, xn);
         if (cost) J += Mdl::path_cost(xc, uc, th, pc);
 #pragma unroll
@@ -70,7 +77,46 @@ __global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, c
     if (cost) cost[b] = J + Mdl::final_cost(xc, th, pc);
 }
 
-// closed-loop rollout u = ubar - alpha k - K (x - xbar) (one lane per trajectory); gains[b][t] = {K^T [n][m], k [m]}
+// closed-loop rollout u = ubar - alpha k - K (x - xbar) of ONE lane; gains[t] = {K^T [n][m], k [m]}.  The reference trajectory and the
+// gains of step t+1 are requested before step t computes (uncoalesced per-lane loads: an HBM round trip each otherwise).
+template <class Mdl>
+PDP_DEV double closed_loop_rollout(int T, double a, const double* __restrict__ x0, const double* __restrict__ ub, const double* __restrict__ xr,
+                                   const double* __restrict__ gb, const double* th, const double* pc, double* __restrict__ xo, double* __restrict__ uo) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, GSZ = NX * NU + NU;
+    double xc[NX], xn[NX], uc[NU], gn[GSZ], un[NU], xrn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[i]; xo[i] = xc[i]; xrn[i] = xr[i]; }
+#pragma unroll
+    for (int i = 0; i < GSZ; ++i) gn[i] = gb[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) un[i] = ub[i];
+    double J = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : t;
+        double g[GSZ], ur[NU], xref[NX];
+#pragma unroll
+        for (int i = 0; i < GSZ; ++i) { g[i] = gn[i]; gn[i] = gb[tn * GSZ + i]; }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { ur[i] = un[i]; un[i] = ub[tn * NU + i]; }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xref[i] = xrn[i]; xrn[i] = xr[tn * NX + i]; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            double v = ur[j] - a * g[NX * NU + j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v -= g[i * NU + j] * (xc[i] - xref[i]);
+            uc[j] = v;
+            uo[t * NU + j] = v;
+        }
+        Mdl::dyn(xc, uc, th, pc, xn);
+        J += Mdl::path_cost(xc, uc, th, pc);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xo[(t + 1) * NX + i] = xn[i]; }
+    }
+    return J + Mdl::final_cost(xc, th, pc);
+}
+
+// closed-loop rollout (one lane per trajectory), per-sample step length alpha
 template <class Mdl>
 __global__ void oc_rollout_feedback_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
                                            const double* __restrict__ gains, const double* __restrict__ alpha, const double* __restrict__ theta, int tb,
@@ -82,29 +128,8 @@ __global__ void oc_rollout_feedback_kernel(int B, int T, const double* __restric
     load_theta<Mdl>(theta, b, tb, th);
     double pc[Mdl::NPC];
     Mdl::precompute(th, pc);
-    const double a = alpha[b];
-    double xc[NX], xn[NX], uc[NU];
-    double* xb = x + (int64_t)b * (T + 1) * NX;
-    const double* xr = xbar + (int64_t)b * (T + 1) * NX;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
-    double J = 0.0;
-    for (int t = 0; t < T; ++t) {
-        const double* g = gains + ((int64_t)b * T + t) * GSZ;
-#pragma unroll
-        for (int j = 0; j < NU; ++j) {
-            double v = ubar[((int64_t)b * T + t) * NU + j] - a * g[NX * NU + j];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) v -= g[i * NU + j] * (xc[i] - xr[t * NX + i]);
-            uc[j] = v;
-            u[((int64_t)b * T + t) * NU + j] = v;
-        }
-        Mdl::dyn(xc, uc, th, pc, xn);
-        J += Mdl::path_cost(xc, uc, th, pc);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
-    }
-    cost[b] = J + Mdl::final_cost(xc, th, pc);
+    cost[b] = closed_loop_rollout<Mdl>(T, alpha[b], x0 + (int64_t)b * NX, ubar + (int64_t)b * T * NU, xbar + (int64_t)b * (T + 1) * NX,
+                                       gains + (int64_t)b * T * GSZ, th, pc, x + (int64_t)b * (T + 1) * NX, u + (int64_t)b * T * NU);
 }
 
 template <class Mdl>
@@ -126,11 +151,17 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
     Mdl::dhx(xc, th, pc, lc);                                  // lam[T-1] = h_x(x_T)
 #pragma unroll
     for (int i = 0; i < NX; ++i) lb[(T - 1) * NX + i] = lc[i];
+    double xq[NX], uq[NU];                                 // (x_k, u_k) of the next step, requested one step ahead
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xq[i] = xb[(T - 1) * NX + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uq[i] = ub[(T - 1) * NU + i];
     for (int k = T - 1; k >= 1; --k) {                     // lam[k-1] = c_x(x_k,u_k) + f_x' lam[k]
+        const int kn = k > 1 ? k - 1 : 1;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xc[i] = xb[k * NX + i];
+        for (int i = 0; i < NX; ++i) { xc[i] = xq[i]; xq[i] = xb[kn * NX + i]; }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) uc[i] = ub[k * NU + i];
+        for (int i = 0; i < NU; ++i) { uc[i] = uq[i]; uq[i] = ub[kn * NU + i]; }
         Mdl::costate_step(xc, uc, lc, th, pc, ln);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { lc[i] = ln[i]; lb[(k - 1) * NX + i] = ln[i]; }
@@ -304,30 +335,8 @@ __global__ void oc_linesearch_kernel(int B, int T, int K, const double* __restri
     load_theta<Mdl>(theta, b, tb, th);
     double pc[Mdl::NPC];
     Mdl::precompute(th, pc);
-    const double a = ldexp(1.0, -k);
-    double xc[NX], xn[NX], uc[NU];
-    double* xb = xt + (int64_t)idx * (T + 1) * NX;
-    double* ub = ut + (int64_t)idx * T * NU;
-    const double* xr = xbar + (int64_t)b * (T + 1) * NX;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; xb[i] = xc[i]; }
-    double J = 0.0;
-    for (int t = 0; t < T; ++t) {
-        const double* g = gains + ((int64_t)b * T + t) * GSZ;
-#pragma unroll
-        for (int j = 0; j < NU; ++j) {
-            double v = ubar[((int64_t)b * T + t) * NU + j] - a * g[NX * NU + j];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) v -= g[i * NU + j] * (xc[i] - xr[t * NX + i]);
-            uc[j] = v;
-            ub[t * NU + j] = v;
-        }
-        Mdl::dyn(xc, uc, th, pc, xn);
-        J += Mdl::path_cost(xc, uc, th, pc);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xb[(t + 1) * NX + i] = xn[i]; }
-    }
-    Jt[idx] = J + Mdl::final_cost(xc, th, pc);
+    Jt[idx] = closed_loop_rollout<Mdl>(T, ldexp(1.0, -k), x0 + (int64_t)b * NX, ubar + (int64_t)b * T * NU, xbar + (int64_t)b * (T + 1) * NX,
+                                       gains + (int64_t)b * T * GSZ, th, pc, xt + (int64_t)idx * (T + 1) * NX, ut + (int64_t)idx * T * NU);
 }
 
 // Armijo selection among the trials, acceptance of the step, damping / mode update (one wavefront per sample)
