@@ -81,8 +81,8 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         double cof = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
         cof = ((i + j) & 1) ? -cof : cof;
         // Laplace expansion along row 0; the size of its terms against the size of their sum is the conditioning guard
-        const double t0 = readlane_f64(Q2[0], 0) * readlane_f64(cof, 0), t1 = readlane_f64(Q2[0], 1) * readlane_f64(cof, 1),
-                     t2 = readlane_f64(Q2[0], 2) * readlane_f64(cof, 2), t3 = readlane_f64(Q2[0], 3) * readlane_f64(cof, 3);
+        const double ac = Q2[0] * cof;               // lanes 0..3 hold a_0c C_0c (their element is (0, c)): one product, then 4 broadcasts
+        const double t0 = readlane_f64(ac, 0), t1 = readlane_f64(ac, 1), t2 = readlane_f64(ac, 2), t3 = readlane_f64(ac, 3);
         const double det = (t0 + t1) + (t2 + t3), mag = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
         if (fabs(det) > 1e-10 * mag && fabs(det) <= 1.7e308) {      // uniform branch
             // 1/det: hardware reciprocal + one Newton step (the full IEEE division sequence is a 12-instruction dependent chain
@@ -129,6 +129,8 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
     tile_to_lds17(scratch + 272, P, lane);
     d4 Wn = mms_tn_r0(Qux, g.IK, FY);     // [Qux' - Qux' I | Wn - Qux' k]
+    // columns < M of Wn are Qux' - Qux' (Z Quu): zero only up to the rounding of Z Quu ~ I.  Left in, they perturb P G of the next
+    // step and the error compounds over the horizon (quadrotor T = 50: parity lost) - they are masked out.
     W0 = keep_cols(Wn, M, M + p0, lane);
     g.IK = keep_cols(g.IK, M, M + p0, lane);
     wave_lds_sync();
