@@ -30,6 +30,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: let the fp64 MFMA accumulators live in VGPRs (the kernels sit at the 256-VGPR ceiling; with AGPR accumulators every
 # VALU/LDS use of a product costs v_accvgpr moves - measured +4% on the headline kernel)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("PDP_HIP_EXTRA_FLAGS", "").split()
+# OC models (the fused kernel): loop strength reduction rewrites the running LDS addresses of the step loops as (induction variable + 0)
+# and leaves a `v_add_u32 v, 0, v` in front of every ds_read (39 VALU instructions per time step); the loops already carry their own
+# running addresses.  Measured: fused kernel +5 % without LSR; the SysID / ControlPlanning kernels lose up to 12 % -> OC models only.
+OC_EXTRA_FLAGS = ["-mllvm", "-disable-lsr"]
 
 KIND_OC, KIND_CP, KIND_SYSID = 0, 1, 2
 KIND_NAME = {0: "oc", 1: "cp", 2: "sysid"}
@@ -412,7 +416,8 @@ def compile_model(name, force=False):
     """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
     deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
-    return _build(lib_path(name), deps, ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)
+    extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
+    return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)
 
 
 def compile_core(force=False):

@@ -388,23 +388,28 @@ __global__ void __launch_bounds__(64) oc_ls_select_kernel(int B, int T, int K, c
 // OC: fused forward + costates + aux system (LDS) + Riccati + PDP gradient, one wavefront per trajectory
 // ------------------------------------------------------------------------------------------------------
 struct Gather { int off[4]; int tmul[4]; };
-// running form: cur[r] is the LDS offset (in doubles) of the element for the current step; step() moves it by one time step
-struct GatherRun { int cur[4]; int tmul[4]; };      // BYTE offsets from `lds`: the ds_read address is the register itself, no shift/add per read
-PDP_DEV GatherRun gather_at(const Gather& g, int tl) {
+// running form: cur[r] is the ABSOLUTE LDS byte address of the element for the current step (the base of the dynamic LDS block is a
+// link-time constant the compiler cannot fold: added once here, not as a VALU add in front of every ds_read); the ds_read / ds_write
+// address is the register itself
+#define PDP_LDS __attribute__((address_space(3)))
+PDP_DEV unsigned lds_addr(const double* p) { return (unsigned)(uintptr_t)(PDP_LDS const double*)p; }
+struct GatherRun { unsigned cur[4]; int tmul[4]; };
+PDP_DEV GatherRun gather_at(const Gather& g, int tl, const double* lds) {
     GatherRun r;
+    const unsigned base = lds_addr(lds);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { r.cur[k] = 8 * (g.off[k] + tl * g.tmul[k]); r.tmul[k] = 8 * g.tmul[k]; }
+    for (int k = 0; k < 4; ++k) { r.cur[k] = base + 8u * (unsigned)(g.off[k] + tl * g.tmul[k]); r.tmul[k] = 8 * g.tmul[k]; }
     return r;
 }
-PDP_DEV void scatter_run(double* lds, GatherRun& g, const d4 v, int dir) {      // write, then advance
+PDP_DEV void scatter_run(GatherRun& g, const d4 v, int dir) {      // write, then advance
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { *(double*)((char*)lds + g.cur[k]) = v[k]; g.cur[k] += dir * g.tmul[k]; }
+    for (int k = 0; k < 4; ++k) { *(PDP_LDS double*)(uintptr_t)g.cur[k] = v[k]; g.cur[k] += (unsigned)(dir * g.tmul[k]); }
 }
 template <int NR = 4>
-PDP_DEV d4 gather_run(const double* lds, GatherRun& g, int dir) {      // read, then advance by dir (+1 / -1) time steps
+PDP_DEV d4 gather_run(GatherRun& g, int dir) {      // read, then advance by dir (+1 / -1) time steps
     d4 v = zero4();
 #pragma unroll
-    for (int k = 0; k < NR; ++k) { v[k] = *(const double*)((const char*)lds + g.cur[k]); g.cur[k] += dir * g.tmul[k]; }
+    for (int k = 0; k < NR; ++k) { v[k] = *(PDP_LDS const double*)(uintptr_t)g.cur[k]; g.cur[k] += (unsigned)(dir * g.tmul[k]); }
     return v;
 }
 
@@ -634,18 +639,18 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them.
                 // The running offsets simply keep moving down; the last prefetch of a chunk reads the row below row 0 (scratch
                 // space of this workgroup, or - past the start of LDS - zeros) and is not used.
-                GatherRun cF = gather_at(gF, cnt - 1), cC = gather_at(gCX, cnt - 1), wL;
+                GatherRun cF = gather_at(gF, cnt - 1, blk), cC = gather_at(gCX, cnt - 1, blk), wL;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
                     const int row = tile_row(lane, r);
                     const bool valid = tile_col(lane) == 0 && row < NX;
-                    wL.cur[r] = valid ? 8 * (int)((pool - lds) + (cnt - 1) * L::BSTRIDE + L::LAM + row) : 0;     // scratch[0]: idle here
+                    wL.cur[r] = lds_addr(lds) + (valid ? 8u * (unsigned)((pool - lds) + (cnt - 1) * L::BSTRIDE + L::LAM + row) : 0u);     // scratch[0]: idle here
                     wL.tmul[r] = valid ? 8 * L::BSTRIDE : 0;
                 }
-                d4 Fc = gather_run(blk, cF, -1), CX = gather_run(blk, cC, -1);
+                d4 Fc = gather_run(cF, -1), CX = gather_run(cC, -1);
                 auto cstep = [&](const d4 Lin, d4& Lout) {
-                    d4 Fc_n = gather_run(blk, cF, -1), CX_n = gather_run(blk, cC, -1);
-                    scatter_run(lds, wL, Lin, -1);
+                    d4 Fc_n = gather_run(cF, -1), CX_n = gather_run(cC, -1);
+                    scatter_run(wL, Lin, -1);
                     Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
                     Fc = Fc_n; CX = CX_n;
                 };
@@ -680,19 +685,19 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             wave_lds_sync();
             PDP_ACC(2);
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
-            GatherRun rF = gather_at(gF, cnt - 1), rY = gather_at(gY, cnt - 1), rHxx = gather_at(gHxx, cnt - 1), rHX = gather_at(gHX, cnt - 1),
-                      rHU = gather_at(gHU, cnt - 1);
+            GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
+                      rHU = gather_at(gHU, cnt - 1, blk);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
             // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The running
             // offsets keep moving down (the last prefetch of a chunk reads below row 0 and is unused).  Two steps per trip with the
             // prefetched tiles alternating between two register sets (no copies at the back edge).
-            d4 Fa = gather_run(blk, rF, -1), Ya = gather_run(blk, rY, -1), Fb, Yb;
+            d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb, Yb;
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
-                d4 Hxx = gather_run(blk, rHxx, -1), HX2 = gather_run(blk, rHX, -1), HU2 = gather_run<1>(blk, rHU, -1);
-                Fn = gather_run(blk, rF, -1);
-                Yn = gather_run(blk, rY, -1);
+                d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1);
+                Fn = gather_run(rF, -1);
+                Yn = gather_run(rY, -1);
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
@@ -751,17 +756,17 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             }
             wave_lds_sync();
             PDP_ACC(4);
-            GatherRun rFT = gather_at(gFT, 0), rGT = gather_at(gGT, 0), rE = gather_at(gE, 0), rDX = gather_at(gDX, 0), rDU = gather_at(gDU, 0);
+            GatherRun rFT = gather_at(gFT, 0, blk), rGT = gather_at(gGT, 0, blk), rE = gather_at(gE, 0, blk), rDX = gather_at(gDX, 0, blk), rDU = gather_at(gDU, 0, blk);
             auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
                 KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
                 knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                d4 FT = gather_run(blk, rFT, 1);
-                d4 GT = gather_run<1>(blk, rGT, 1);
-                d4 E2 = gather_run(blk, rE, 1);
-                d4 DX = gather_run(blk, rDX, 1);            // (x_t - xd_t)[row] broadcast over columns
-                d4 DU = gather_run<1>(blk, rDU, 1);
+                d4 FT = gather_run(rFT, 1);
+                d4 GT = gather_run<1>(rGT, 1);
+                d4 E2 = gather_run(rE, 1);
+                d4 DX = gather_run(rDX, 1);            // (x_t - xd_t)[row] broadcast over columns
+                d4 DU = gather_run<1>(rDU, 1);
                 d4 U2;
                 PDP_FINE(9, t == 20);
                 riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
@@ -972,9 +977,9 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
         wave_lds_sync();
         // per-step operands are gathered one step ahead (running LDS offsets); two steps per trip, the sensitivity tiles and the
         // prefetched operands alternating between two register sets
-        GatherRun rFT = gather_at(gFT, 0), rGT = gather_at(gGT, 0), rCX = gather_at(gCX, 0), rCU = gather_at(gCU, 0);
+        GatherRun rFT = gather_at(gFT, 0, blk), rGT = gather_at(gGT, 0, blk), rCX = gather_at(gCX, 0, blk), rCU = gather_at(gCU, 0, blk);
         struct Ops { d4 FT, GT, CX, CU; };
-        auto request = [&](Ops& o) { o.FT = gather_run(blk, rFT, 1); o.GT = gather_run<1>(blk, rGT, 1); o.CX = gather_run(blk, rCX, 1); o.CU = gather_run<1>(blk, rCU, 1); };
+        auto request = [&](Ops& o) { o.FT = gather_run(rFT, 1); o.GT = gather_run<1>(rGT, 1); o.CX = gather_run(rCX, 1); o.CU = gather_run<1>(rCU, 1); };
         auto step = [&](int tl, const Ops& o, Ops& nx, const d4 (&Xc)[NT], d4 (&Xn)[NT]) {
             const int t = t0 + tl;
             if (tl + 1 < cnt) request(nx);
