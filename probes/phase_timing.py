@@ -5,7 +5,7 @@ import bench
 pb = zoo.make_problem('quadrotor','irl'); _, info = codegen.write_header(pb)
 out = '/tmp/libtiming.so'
 EXTRA=[a for a in os.environ.get('PDP_EXTRA','').split() if a]
-subprocess.run([codegen.HIPCC]+codegen.HIP_FLAGS+EXTRA+['-DPDP_PHASE_TIMING','-DPDP_MODEL_HEADER="generated/%s.h"'%info['name'],'-I',codegen.CSRC,os.path.join(codegen.CSRC,'pdp_model.hip'),'-o',out],check=True)
+subprocess.run([codegen.HIPCC]+codegen.HIP_FLAGS+codegen.OC_EXTRA_FLAGS+EXTRA+['-DPDP_PHASE_TIMING','-DPDP_MODEL_HEADER="generated/%s.h"'%info['name'],'-I',codegen.CSRC,os.path.join(codegen.CSRC,'pdp_model.hip'),'-o',out],check=True)
 mdl = runtime.ModelLib(out)
 B=1024
 x0,u,dx,du = (torch.as_tensor(a,device='cuda') for a in bench.synth_inputs(B,1000))
