@@ -75,7 +75,7 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
         force = True
     nb = runtime.dev(ini_state).reshape(-1, mdl.n).shape[0]
     sol = _solve(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level, force_init=force,
-                 want_gains=want_gains, straggler_patience=10 if (nb > 1 and neighbor_retries > 0) else 0)
+                 want_gains=want_gains, straggler_patience=6 if (nb > 1 and neighbor_retries > 0) else 0)
     B = sol["state"].shape[0]
     if B == 1 or neighbor_retries <= 0:
         return sol

@@ -286,7 +286,7 @@ class ModelLib:
                                                        current_stream_ptr()), "pdp_oc_rollout_feedback_batched")
         return x, u, cost
 
-    def oc_solve(self, x0, u_init, theta, tol=1e-9, newton_switch=1e-2, max_iter=300, check_every=4, ls_trials=10, straggler_patience=0,
+    def oc_solve(self, x0, u_init, theta, tol=1e-9, newton_switch=1e-2, max_iter=300, check_every=2, ls_trials=10, straggler_patience=0,
                  print_level=0, want_gains=False):
         """Batched Newton solve of the OC problem (pdp_oc_solve_batched; stands where OCSys.ocSolver calls IPOPT).  u_init [B,T,m] is
         not modified.  Returns dict(state, control, costate, cost, grad_norm, converged (bool), iterations[, gains])."""
