@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     const TileMap mNN = make_dense_map<false>(n, n, n, 0, 0, lane), mNM = make_dense_map<false>(n, M, M, 0, 0, lane),
                   mNP = make_dense_map<false>(n, p0, p, 0, M, lane), mMM = make_dense_map<false>(M, M, M, 0, 0, lane),
                   mMP = make_dense_map<false>(M, p0, p, 0, M, lane), mFT = make_dense_map<true>(n, n, n, 0, 0, lane),
-                  mGT = make_dense_map<true>(n, M, M, 0, 0, lane);
+                  mGT = make_dense_map<true>(n, M, M, 0, 0, lane), mNMrep = make_rep4_map(n, M, M, lane);   // G / K' replicated in the 4 column blocks
 
     // terminal condition: PP[T-1] = hxx, WW[T-1] = hxe (PDP.py:561-562)
     d4 P = load_map(mat_at(pr.hxx, b, 0), mNN);
@@ -68,12 +68,14 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     }
     // The matrices of step t-1 are requested from HBM before the Riccati step of t runs (one step = ~3k cycles of MFMA / VALU work,
     // an HBM round trip ~2k): two steps per trip, the operand tiles alternating between two register sets.
-    struct BwdTiles { d4 Ft, Y2, Hxx, HX2, HU2; };
+    struct BwdTiles { d4 Ft, Y2, Grep, Hxx, HX2, HU2; };
     const pdp_mat none = {nullptr, 0, 0};
     RunPtr rF = make_run(pr.F, mNN, none, mNN, b, T - 1), rY = make_run(pr.G, mNM, pr.E, mNP, b, T - 1), rHxx = make_run(pr.Hxx, mNN, none, mNN, b, T - 1),
-           rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1);
+           rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1),
+           rGr = make_run(pr.G, mNMrep, none, mNN, b, T - 1);
     auto load_bwd = [&](BwdTiles& w) {     // (the request after the last step reads one step before the arrays' first: never used)
-        w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1); w.HU2 = load_run<1>(rHU, -1);
+        w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Grep = load_run(rGr, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1);
+        w.HU2 = load_run<1>(rHU, -1);
     };
     auto bstep = [&](int t, const BwdTiles& c, BwdTiles& nx) {
         if (t > 0) load_bwd(nx);
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
         }
         RiccatiGains g;
         d4 P_old;
-        ok = riccati_backward<M>(P, W[0], c.Ft, c.Y2, c.Hxx, c.HX2, c.HU2, scratch, lane, p0, g, P_old) && ok;
+        ok = riccati_backward<M>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, scratch, lane, p0, g, P_old) && ok;
         double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
         store_map(gw, mNM, g.KT);
         store_map<1>(gw + n * M, mMP, g.IK);
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
                 d4 Hxej = Hxe ? load_dense<false>(Hxe + c0, n, w, p, 0, 0, lane) : z;
                 d4 Huej = Hue ? load_dense<false>(Hue + c0, M, w, p, 0, 0, lane) : z;
                 d4 kj;
-                riccati_backward_extra(P_old, W[j], c.Ft, c.Y2, Ej, Hxej, Huej, g, kj);
+                riccati_backward_extra(P_old, W[j], c.Ft, c.Grep, Ej, Hxej, Huej, g, kj);
                 store_dense(gw + n * M + c0, M, w, p, 0, 0, lane, kj);
             }
         }
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     struct FwdTiles { d4 FT, GT, KT, Pt, k, Et, Wt; };
     const pdp_mat gKT = {ws_gain, (int64_t)T * gsz, gsz}, gk = {ws_gain + n * M, (int64_t)T * gsz, gsz},
                   wP = {ws_pw, (int64_t)T * pwsz, pwsz}, wW = {(ws_pw && Lo) ? ws_pw + n * n : nullptr, (int64_t)T * pwsz, pwsz};
-    RunPtr qFT = make_run(pr.F, mFT, none, mFT, b, 0), qGT = make_run<1>(pr.G, mGT, none, mGT, b, 0), qKT = make_run(gKT, mNM, none, mNM, b, 0),
+    RunPtr qFT = make_run(pr.F, mFT, none, mFT, b, 0), qGT = make_run<1>(pr.G, mGT, none, mGT, b, 0), qKT = make_run(gKT, mNMrep, none, mNM, b, 0),
            qk = make_run<1>(gk, mMP, none, mMP, b, 0), qE = make_run(pr.E, mNP, none, mNP, b, 0), qP = make_run(wP, mNN, none, mNN, b, 0),
            qW = make_run(wW, mNP, none, mNP, b, 0);
     auto load_fwd = [&](FwdTiles& w) {

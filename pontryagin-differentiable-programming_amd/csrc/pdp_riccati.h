@@ -39,6 +39,7 @@ struct RiccatiGains {
     d4 KT;   // K^T  (n x m) in columns 0..m-1               -> forward: U = -(KT)^T X - k
     d4 IK;   // rows 0..m-1: [ I | k_0 ] (k_0 in columns m..m+p0-1)
     d4 Z;    // Quu^-T (m x m, top-left)
+    double Zrep;   // the same block replicated in the four column blocks (register 0): operand of the 4-row products
     d4 Qux;  // m x n, rows 0..m-1
 };
 
@@ -49,14 +50,16 @@ struct RiccatiGains {
 //
 // scratch: LDS, RICCATI_SCRATCH doubles, private to the wave (one wave per workgroup).  Returns false when the
 // m x m solve meets a vanishing / non-finite pivot.  No barrier and no global-memory wait inside.
+// Grep: G (n x m, m <= 4) replicated in the four column blocks of a tile, the operand form of the 4-row products (mma4_tn).
 template <int M>
-PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Hxx, const d4 HX2, const d4 HU2,
+PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
     d4 PF = mma_tn(P, Ft, z);        // P F        (P symmetric)
     d4 PY2 = mma_tn(P, Y2, W0);      // [P G | P E + W]
     d4 FY = mma_tn(Ft, PY2, HX2);    // [Hxu + F'PG | Hxe + F'(PE+W)] = [Qux' | Wn]
-    d4 Q2 = mma_tn(Y2, PY2, HU2);    // rows<m: [Quu | Que]
+    d4 Q2 = z;
+    Q2[0] = mma4_tn(Grep, PY2, HU2[0]);   // [Quu | Que] = [Huu | Hue] + G' [PG | PE+W]: 4 rows, 4 small MFMAs
     d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
     P_old_out = P;
     // ---- Qux (m x n) = transpose of the first m columns of FY, through LDS (padded stride)
@@ -64,6 +67,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     // ---- m x m system Quu (element (i,j) lives in lane 16 i + j, register 0)
     const int row = lane >> 4, col = lane & 15;
     d4 Z = z;                                   // Z = Quu^-T in the top-left corner
+    double Zrep = 0.0;                          // ... and in every 4-column block
     bool ok = true;
     if constexpr (M == 4) {
         // lane-parallel cofactor inverse: lane (i,j) = (row, col) computes the cofactor C_ij of its own element from the
@@ -89,7 +93,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
             // in front of the gain MFMAs; det is nowhere near the subnormal / overflow ranges that sequence exists for)
             double rdet = __builtin_amdgcn_rcp(det);
             rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
-            Z[0] = (col < 4) ? cof * rdet : 0.0;
+            Zrep = cof * rdet;                   // (the cofactor was computed for j = col & 3: already replicated)
         } else {                                 // ill-conditioned / singular: pivoted Gauss-Jordan, uniform over the wave
             double a[16], ai[16];
 #pragma unroll
@@ -101,8 +105,8 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) zz = (row == ii && col == jj) ? ai[jj * 4 + ii] : zz;
-            Z[0] = zz;
+                for (int jj = 0; jj < 4; ++jj) zz = (row == ii && (col & 3) == jj) ? ai[jj * 4 + ii] : zz;
+            Zrep = zz;
         }
     } else {
         double a[M * M], ai[M * M];
@@ -115,16 +119,20 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int j = 0; j < M; ++j) zz = (row == i && col == j) ? ai[j * M + i] : zz;
-        Z[0] = zz;
+            for (int j = 0; j < M; ++j) zz = (row == i && (col & 3) == j) ? ai[j * M + i] : zz;
+        Zrep = zz;
     }
+    Z[0] = (col < 4) ? Zrep : 0.0;
     wave_lds_sync();
     d4 Qux = z;
     if (row < M) Qux[0] = scratch[col * 17 + row];
-    d4 K = mma_tn_r0(Z, Qux, z);          // Quu^-1 Qux            (m x n)
-    g.IK = mma_tn_r0(Z, Q2, z);           // Quu^-1 [Quu | Que] = [I | k]
+    d4 K = z;
+    K[0] = mma4_blk(Zrep, Qux[0], 0.0);   // Quu^-1 Qux            (m x n)
+    g.IK = z;
+    g.IK[0] = mma4_blk(Zrep, Q2[0], 0.0); // Quu^-1 [Quu | Que] = [I | k]
     g.KT = mma_tn_r0(Qux, Z, z);          // Qux' Quu^-T = K'      (n x m)
     g.Z = Z;
+    g.Zrep = Zrep;
     g.Qux = Qux;
     P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
     tile_to_lds17(scratch + 272, P, lane);
@@ -139,19 +147,21 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
 }
 
 // Extra parameter tile j >= 1 (16 columns of E / Hxe / Hue / W, unshifted).  P_old = P before the update.
-PDP_DEV void riccati_backward_extra(const d4 P_old, d4& Wj, const d4 Ft, const d4 Y2, const d4 Ej, const d4 Hxej, const d4 Huej,
+PDP_DEV void riccati_backward_extra(const d4 P_old, d4& Wj, const d4 Ft, const d4 Grep, const d4 Ej, const d4 Hxej, const d4 Huej,
                                     const RiccatiGains& g, d4& kj) {
-    const d4 z = zero4();
     d4 S1 = mma_tn(P_old, Ej, Wj);        // P E_j + W_j
     d4 Wn = mma_tn(Ft, S1, Hxej);         // Hxe_j + F'(..)
-    d4 Que = mma_tn(Y2, S1, Huej);        // rows<m: Hue_j + G'(..)   (rows >= m: E-related, killed by Z's zero rows)
-    kj = mma_tn_r0(g.Z, Que, z);          // Quu^-1 Que_j
+    const double Que = mma4_tn(Grep, S1, Huej[0]);      // Hue_j + G'(..)  (m rows)
+    kj = zero4();
+    kj[0] = mma4_blk(g.Zrep, Que, 0.0);   // Quu^-1 Que_j
     Wj = mms_tn_r0(g.Qux, kj, Wn);
 }
 
 // Forward step for one parameter tile: U = -K X - k ; X+ = F X + G U + E.   FT = F^T tile, GT = G^T tile (m x n).
-PDP_DEV void riccati_forward(const d4 KTneg, const d4 kneg, const d4 FT, const d4 GT, const d4 Etile, const d4 X, d4& U, d4& Xn) {
-    U = mma_tn(KTneg, X, kneg);           // -(K X) - k   (rows < m)
+// KTrepneg: -K^T (n x m) replicated in the four column blocks (operand form of the 4-row product).
+PDP_DEV void riccati_forward(const d4 KTrepneg, const d4 kneg, const d4 FT, const d4 GT, const d4 Etile, const d4 X, d4& U, d4& Xn) {
+    U = zero4();
+    U[0] = mma4_tn(KTrepneg, X, kneg[0]); // -(K X) - k   (m rows, 4 small MFMAs)
     Xn = mma_tn(FT, X, Etile);            // F X + E
     Xn = mma_tn_r0(GT, U, Xn);            // + G U
 }

@@ -41,6 +41,22 @@ PDP_DEV d4 mms_tn_r0(const d4 x, const d4 y, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(-x[0], y[0], c, 0, 0, 0);
 }
 
+// Products with only 4 output rows (everything multiplied by the m x m control block) run on the 4-block MFMA
+// v_mfma_f64_4x4x4_4b_f64 - four independent 4x4x4 products, 25 cycles dependent-on-C / 32 dependent-on-A against 64 / 90 of the
+// 16x16x4 form (profiles/r01_probe_mfma_f64_4x4.txt; operand layouts probed there: A lane = i + 4 b + 16 k, B lane = j + 4 b + 16 k,
+// D lane = j + 4 b + 16 i).  In the register conventions of this file (lane = 16 row + col):
+//      D[i][c] = C[i][c] + sum_{k<4} X[k][4 (c/4) + i] * Y[k][c]          i < 4;   D, C, X, Y: one register ("rows 0..3") each
+// i.e. C + M^T Y for a 4 x 4 block M when X holds M in each of its four column blocks, X = [M|M|M|M].
+PDP_DEV double mma4_blk(double xrep, double y, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(xrep, y, c, 0, 0, 0); }
+// rows 0..3 of C + X^T Y over the full inner dimension 16 (4 small MFMAs), X column-block replicated: Xrep[k][4 b + i] = X[k][i]
+PDP_DEV double mma4_tn(const d4 xrep, const d4 y, double c) {
+    c = mma4_blk(xrep[0], y[0], c);
+    c = mma4_blk(xrep[1], y[1], c);
+    c = mma4_blk(xrep[2], y[2], c);
+    c = mma4_blk(xrep[3], y[3], c);
+    return c;
+}
+
 // Load a dense row-major R x C matrix (leading dimension ld) into the tile at offset (roff, coff); elements
 // outside the matrix are 0.  TRANS loads the transpose (tile(i,j) = M[j-coff'...]) - see callers.
 template <bool TRANS>
@@ -91,6 +107,16 @@ PDP_DEV TileMap make_dense_map(int R, int C, int ld, int roff, int coff, int lan
     }
     return m;
 }
+// map of an R x C block (C <= 4) replicated into the four column blocks of the tile: element (row, col) <- M[row][col & 3]
+PDP_DEV TileMap make_rep4_map(int R, int C, int ld, int lane) {
+    TileMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tile_row(lane, r), c = tile_col(lane) & 3;
+        m.off[r] = (row < R && c < C) ? row * ld + c : -1;
+    }
+    return m;
+}
 // Loads / stores through a loop-invariant map: the per-step cost is one address add per register (load_dense / store_dense redo the
 // index arithmetic and bound checks of every element on every call).  Loads are branch-free (absent elements read element 0 of the
 // block and are zeroed by a select), stores are predicated.
@@ -107,6 +133,12 @@ PDP_DEV void store_map(double* __restrict__ base, const TileMap& m, const d4 v) 
     for (int r = 0; r < NR; ++r) if (m.off[r] >= 0) base[m.off[r]] = v[r];
 }
 struct TileMapBytes { unsigned off[4]; };   // unsigned BYTE offsets: uniform base (SGPR pair) + 32-bit lane offset addressing, no 64-bit VALU add
+PDP_DEV TileMapBytes to_bytes_sink(const TileMap& m, int sink) {
+    TileMapBytes b;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b.off[r] = 8u * (unsigned)(m.off[r] < 0 ? sink : m.off[r]);
+    return b;
+}
 PDP_DEV TileMapBytes make_tile_map_sink(int R, int C, int ld, int roff, int coff, int lane, int sink) {
     TileMap m = make_tile_map(R, C, ld, roff, coff, lane);
     TileMapBytes b;
