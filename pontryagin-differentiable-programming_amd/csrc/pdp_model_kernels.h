@@ -430,7 +430,7 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
     return v;
 }
 
-// feedback gains of one step in the workspace: K' [NX x NU], k [NU x NP], and one slot that receives (and hands back) the zeros of
+// feedback gains of one step in the workspace: K [NU x NX], k [NU x NP], and one slot that receives (and hands back) the zeros of
 // the tile elements outside those blocks
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
     using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK, M = NU;
-    constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K' [NX x NU] | k [NU x NP] | zero sink
+    constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K [NU x NX] | k [NU x NP] | zero sink
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
@@ -600,7 +600,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
-        const TileMapBytes mKT = make_tile_map_sink(NX, NU, NU, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
+        const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
@@ -703,9 +704,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
-                ok = riccati_backward<M>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
+                ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
-                store_all<4>(gw + t * GSZ, mKT, g.KT);
+                store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
@@ -735,8 +736,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
-        // K' is loaded replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
-        const TileMapBytes mKT = to_bytes_sink(make_rep4_map(NX, NU, NU, lane), GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        // K is read back transposed and replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
+        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         d4 KTn = -load_all<4>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;

@@ -36,7 +36,8 @@ PDP_DEV d4 tile_from_lds17_transposed(const double* s, int lane) {
 }
 
 struct RiccatiGains {
-    d4 KT;   // K^T  (n x m) in columns 0..m-1               -> forward: U = -(KT)^T X - k
+    d4 KT;   // K^T  (n x m) in columns 0..m-1               -> forward: U = -(KT)^T X - k   (only if WANT_KT)
+    d4 K;    // K = Quu^-1 Qux (m x n), rows 0..m-1
     d4 IK;   // rows 0..m-1: [ I | k_0 ] (k_0 in columns m..m+p0-1)
     d4 Z;    // Quu^-T (m x m, top-left)
     double Zrep;   // the same block replicated in the four column blocks (register 0): operand of the 4-row products
@@ -51,7 +52,9 @@ struct RiccatiGains {
 // scratch: LDS, RICCATI_SCRATCH doubles, private to the wave (one wave per workgroup).  Returns false when the
 // m x m solve meets a vanishing / non-finite pivot.  No barrier and no global-memory wait inside.
 // Grep: G (n x m, m <= 4) replicated in the four column blocks of a tile, the operand form of the 4-row products (mma4_tn).
-template <int M>
+// WANT_KT: also form K^T as a tile (one more 16x16x4 MFMA) - callers that store the gains as K^T [n][m]; the fused kernel stores K
+// itself and reads it back transposed, which costs nothing.
+template <int M, bool WANT_KT = true>
 PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
@@ -130,7 +133,8 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     K[0] = mma4_blk(Zrep, Qux[0], 0.0);   // Quu^-1 Qux            (m x n)
     g.IK = z;
     g.IK[0] = mma4_blk(Zrep, Q2[0], 0.0); // Quu^-1 [Quu | Que] = [I | k]
-    g.KT = mma_tn_r0(Qux, Z, z);          // Qux' Quu^-T = K'      (n x m)
+    if constexpr (WANT_KT) g.KT = mma_tn_r0(Qux, Z, z);          // Qux' Quu^-T = K'      (n x m)
+    g.K = K;
     g.Z = Z;
     g.Zrep = Zrep;
     g.Qux = Qux;

@@ -117,6 +117,16 @@ PDP_DEV TileMap make_rep4_map(int R, int C, int ld, int lane) {
     }
     return m;
 }
+// the same replicated tile read from the TRANSPOSED block: element (row, col) <- Mt[col & 3][row], Mt being C x R with leading dim ld
+PDP_DEV TileMap make_rep4_map_transposed(int R, int C, int ld, int lane) {
+    TileMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tile_row(lane, r), c = tile_col(lane) & 3;
+        m.off[r] = (row < R && c < C) ? c * ld + row : -1;
+    }
+    return m;
+}
 // Loads / stores through a loop-invariant map: the per-step cost is one address add per register (load_dense / store_dense redo the
 // index arithmetic and bound checks of every element on every call).  Loads are branch-free (absent elements read element 0 of the
 // block and are zeroed by a select), stores are predicated.
