@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
         }
         RiccatiGains g;
         d4 P_old;
-        ok = riccati_backward<M>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, scratch, lane, p0, g, P_old) && ok;
+        ok = riccati_backward<M, true, true>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, 0.0, scratch, lane, p0, g, P_old) && ok;
         double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
         store_map(gw, mNM, g.KT);
         store_map<1>(gw + n * M, mMP, g.IK);

@@ -593,8 +593,9 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
         make_gather(gY, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= NX ? -1 : (c < M ? codeA(1, r * NU + c) : (c < M + NP ? codeA(2, r * NP + (c - M)) : -1)); });
         make_gather(gCX, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
-        Gather gGr;                                       // G replicated in the four column blocks: operand of the 4-row products
+        Gather gGr, gHux;                                 // G replicated in the four column blocks (operand of the 4-row products); Hux = Hxu'
         make_gather(gGr, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeA(1, r * NU + (c & 3)) : -1; });
+        make_gather(gHux, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < M && c < NX) ? codeB(1, c * NU + r) : -1; });
         make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
         make_gather(gHX, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
@@ -689,7 +690,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             PDP_ACC(2);
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
-                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk);
+                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
             // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The running
             // offsets keep moving down (the last prefetch of a chunk reads below row 0 and is unused).  Two steps per trip with the
@@ -698,13 +699,13 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
-                d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1);
+                d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
                 Fn = gather_run(rF, -1);
                 Yn = gather_run(rY, -1);
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
-                ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, scratch, lane, NP, g, P_old) && ok;
+                ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);

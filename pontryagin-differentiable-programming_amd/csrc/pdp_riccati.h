@@ -22,7 +22,7 @@
 
 namespace pdp {
 
-constexpr int RICCATI_SCRATCH = 272 + 272 + 64;   // FY (stride 17) | P (stride 17) | rows 0..3 of Q2
+constexpr int RICCATI_SCRATCH = 272 + 272 + 64;   // HX2 (stride 17, HUX_FROM_HX2 only) | P (stride 17) | rows 0..3 of Q2
 
 PDP_DEV void tile_to_lds17(double* s, const d4 v, int lane) {
 #pragma unroll
@@ -54,19 +54,28 @@ struct RiccatiGains {
 // Grep: G (n x m, m <= 4) replicated in the four column blocks of a tile, the operand form of the 4-row products (mma4_tn).
 // WANT_KT: also form K^T as a tile (one more 16x16x4 MFMA) - callers that store the gains as K^T [n][m]; the fused kernel stores K
 // itself and reads it back transposed, which costs nothing.
-template <int M, bool WANT_KT = true>
-PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2,
+// Hux0: Hxu^T (m x n) as a "rows 0..3" register.  Qux = Hux + G' (P F) is formed directly as a 4-row product - in exact arithmetic
+// the transpose of the first m columns of FY, which used to be taken through an LDS round trip in the middle of the step.
+// HUX_FROM_HX2: Hux is taken from the Hxu block of HX2 by an LDS transpose issued at the top of the step (off the critical path: it
+// does not depend on P) instead of being passed in - for callers that have no transposed copy of Hxu at hand.
+template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false>
+PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2, double Hux0,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
+    if constexpr (HUX_FROM_HX2) tile_to_lds17(scratch, HX2, lane);
     d4 PF = mma_tn(P, Ft, z);        // P F        (P symmetric)
     d4 PY2 = mma_tn(P, Y2, W0);      // [P G | P E + W]
     d4 FY = mma_tn(Ft, PY2, HX2);    // [Hxu + F'PG | Hxe + F'(PE+W)] = [Qux' | Wn]
     d4 Q2 = z;
     Q2[0] = mma4_tn(Grep, PY2, HU2[0]);   // [Quu | Que] = [Huu | Hue] + G' [PG | PE+W]: 4 rows, 4 small MFMAs
+    if constexpr (HUX_FROM_HX2) {
+        wave_lds_sync();
+        Hux0 = ((lane >> 4) < M) ? scratch[(lane & 15) * 17 + (lane >> 4)] : 0.0;      // Hux[i][c] = Hxu[c][i]
+    }
+    d4 Qux = z;
+    Qux[0] = mma4_tn(Grep, PF, Hux0);     // Qux = Hux + G'PF   (m x n)
     d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
     P_old_out = P;
-    // ---- Qux (m x n) = transpose of the first m columns of FY, through LDS (padded stride)
-    tile_to_lds17(scratch, FY, lane);
     // ---- m x m system Quu (element (i,j) lives in lane 16 i + j, register 0)
     const int row = lane >> 4, col = lane & 15;
     d4 Z = z;                                   // Z = Quu^-T in the top-left corner
@@ -126,9 +135,6 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         Zrep = zz;
     }
     Z[0] = (col < 4) ? Zrep : 0.0;
-    wave_lds_sync();
-    d4 Qux = z;
-    if (row < M) Qux[0] = scratch[col * 17 + row];
     d4 K = z;
     K[0] = mma4_blk(Zrep, Qux[0], 0.0);   // Quu^-1 Qux            (m x n)
     g.IK = z;

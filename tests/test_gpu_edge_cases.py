@@ -126,3 +126,40 @@ def test_sysid_ragged_batch_and_empty_gradient_directions(golden_dir):
     loss, d = sid.step(inputs, states, theta)
     lo, do = ora.step(inputs, states, theta)
     assert abs(loss - lo) < 1e-11 * lo and rel(d, do) < TOL
+
+
+def test_results_do_not_depend_on_stale_device_memory():
+    """every kernel must read only what it was given / what it wrote: the same calls are repeated after the caching allocator's
+    free blocks have been filled with NaNs and scattered differently (an out-of-bounds or uninitialised read then shows up as a NaN,
+    a different number or a memory fault instead of passing by the luck of a fresh process)."""
+    import torch
+    from pdp_amd import runtime as rt, zoo
+    import bench
+    rng = np.random.default_rng(11)
+
+    def lqr_case(n, m, p, T, B):
+        r = np.random.default_rng(1000 * n + p)
+        spd = lambda k, s: (lambda A: s * (A @ A.T / k + 0.5 * np.eye(k)))(r.standard_normal((k, k)))
+        a = dict(F=np.eye(n) + 0.1 * r.standard_normal((B, T, n, n)), G=0.3 * r.standard_normal((B, T, n, m)),
+                 Hxx=np.stack([np.stack([spd(n, 1.0) for _ in range(T)]) for _ in range(B)]),
+                 Huu=np.stack([np.stack([spd(m, 0.5) for _ in range(T)]) for _ in range(B)]), hxx=np.stack([spd(n, 1.0) for _ in range(B)]),
+                 hxe=0.2 * r.standard_normal((B, n, p)))
+        k = dict(E=0.1 * r.standard_normal((B, T, n, p)), Hxu=0.05 * r.standard_normal((B, T, n, m)), Hxe=0.2 * r.standard_normal((B, T, n, p)),
+                 Hue=0.2 * r.standard_normal((B, T, m, p)), X0=r.standard_normal((B, n, p)))
+        return lambda: [t.cpu().numpy() for t in rt.lqr_solve(a["F"], a["G"], a["Hxx"], a["Huu"], a["hxx"], a["hxe"], **k)[:3]]
+
+    mdl = zoo.get("quadrotor", "irl")
+    x0, u, dx, du = bench.synth_inputs(48, 3)
+    cp = zoo.get("quadrotor", "oc")
+    pol = rt.make_policy("mlp", layers=[13, 13, 4])
+    thm = 0.1 * rng.standard_normal(420)
+    calls = [lqr_case(13, 4, 9, 50, 64), lqr_case(7, 2, 40, 11, 5), lqr_case(4, 1, 1, 30, 40),
+             lambda: [npy(v) for v in (lambda o: (o["loss"], o["grad"], o["x"], o["lam"]))(mdl.oc_pdp_grad(u, np.array(bench.THETA), dx, du, x0=x0))],
+             lambda: [npy(v) for v in cp.cp_step(pol, 420, x0[:, :13], thm, 40)]]
+    fresh = [c() for c in calls]
+    junk = [torch.full((int(s),), float("nan"), dtype=torch.float64, device="cuda") for s in (3e5, 1e6, 2e6, 5e6, 3e6, 7e5, 4e6, 1e5)]
+    del junk
+    for c, ref in zip(calls, fresh):
+        again = c()
+        for a, b in zip(again, ref):
+            assert np.array_equal(a, b)
