@@ -122,3 +122,39 @@ def test_aux_integrators_match_numpy():
             x = F[b, t] @ x + G[b, t] @ u
             xs = F[b, t] @ xs + E[b, t]
             assert _rel(U[b, t], u) < 1e-12 and _rel(X[b, t + 1], x) < 1e-12 and _rel(Xs[b, t + 1], xs) < 1e-12
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+@pytest.mark.parametrize("nt", [1, 2, 3, 4])
+def test_lqr_every_kernel_instantiation(m, nt):
+    """all 16 instantiations lqr_solve_kernel<M, NT> (control dimension x number of 16-column parameter tiles), on memory the
+    allocator has handed out before (NaN-filled), against the numpy restatement of PDP.py:557-608"""
+    import torch
+    from oracle import pdp_oracle as po
+    from pdp_amd import runtime as rt
+    n, T, B = 9 + m, 6, 3
+    p = (16 - m) + 16 * (nt - 1) - (3 if nt > 1 else 5)          # last tile partly filled
+    rng = np.random.default_rng(100 * m + nt)
+    junk = [torch.full((int(s),), float("nan"), dtype=torch.float64, device="cuda") for s in (2e5, 7e5, 1e5)]
+    del junk
+
+    def spd(k, s):
+        A = rng.standard_normal((k, k))
+        return s * (A @ A.T / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.1 * rng.standard_normal((B, T, n, n))
+    G = 0.3 * rng.standard_normal((B, T, n, m))
+    E = 0.1 * rng.standard_normal((B, T, n, p))
+    Hxx = np.stack([np.stack([spd(n, 1.0) for _ in range(T)]) for _ in range(B)])
+    Huu = np.stack([np.stack([spd(m, 0.5) for _ in range(T)]) for _ in range(B)])
+    Hxu = 0.05 * rng.standard_normal((B, T, n, m))
+    Hxe, Hue = 0.2 * rng.standard_normal((B, T, n, p)), 0.2 * rng.standard_normal((B, T, m, p))
+    hxx = np.stack([spd(n, 1.0) for _ in range(B)])
+    hxe, X0 = 0.2 * rng.standard_normal((B, n, p)), rng.standard_normal((B, n, p))
+    X, U, Lam, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0)
+    assert int(st.sum()) == 0
+    X, U, Lam = _to_np(X), _to_np(U), _to_np(Lam)
+    for b in range(B):
+        sol = po.lqr_solver(list(F[b]), list(G[b]), list(E[b]), list(Hxx[b]), list(Huu[b]), list(Hxu[b]), list(Hxe[b]), list(Hue[b]),
+                            [hxx[b]], [hxe[b]], X0[b], T)
+        assert _rel(X[b], np.stack(sol["state_traj_opt"])) < TOL and _rel(U[b], np.stack(sol["control_traj_opt"])) < TOL
+        assert _rel(Lam[b], np.stack(sol["costate_traj_opt"])) < TOL
