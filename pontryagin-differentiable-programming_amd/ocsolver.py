@@ -1,11 +1,12 @@
 """Batched optimal-control solve on the GPU - stands where the reference's OCSys.ocSolver hands a multiple-shooting NLP to
 IPOPT (PDP/PDP.py:121-220).  Stagewise Newton / iLQR on the single-shooting problem, every trajectory of the batch in
-parallel, all arithmetic and the iteration loop in the model library (pdp_oc_solve_batched); per iteration:
+parallel; the iteration loop runs inside the model library (pdp_oc_solve_batched, see _solve below), this module adds the
+choice of the starting controls and a batch-level globalisation (solve_batch):
 
-    repeat:  costates  lambda = c_x + f_x' lambda+           (pdp_oc_costate_batched)
-             F, G, Hxx, Hxu, Huu, hxx, H_u along (x,u,lambda) (pdp_oc_auxsys_batched)
-             LQ sub-problem for (dx, du): the same Riccati kernel as LQR.lqrSolver with p = 1, Hue := H_u (pdp_lqr_solve_batched)
-             closed-loop rollout u = ubar - alpha k - K (x - xbar), backtracking on the true cost (pdp_oc_rollout_feedback_batched)
+    repeat:  costates  lambda = c_x + f_x' lambda+ , stationarity residual H_u
+             F, G, Hxx, Hxu, Huu, hxx along (x, u, lambda)
+             LQ sub-problem for (dx, du): the same Riccati kernel as LQR.lqrSolver with p = 1, Hue := H_u
+             closed-loop rollouts u = ubar - alpha k - K (x - xbar), backtracking on the true cost
 
 Hessians: the full Hamiltonian Hessians give Newton's method (quadratic convergence, what makes the multipliers accurate to
 1e-10); where that step fails (indefinite Quu, no decrease) the sample falls back to the Gauss-Newton (iLQR) Hessians

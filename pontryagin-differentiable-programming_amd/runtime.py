@@ -409,7 +409,9 @@ class ModelLib:
         return out
 
     def cp_step(self, pol, p, x0, theta, T, want_traj=False):
-        """ControlPlanning.step: fused kernel for the Lagrange policy; composed from the modular kernels for the MLP policy."""
+        """ControlPlanning.step (pdp_cp_step_batched): forward-sensitivity kernel for the Lagrange policy, adjoint kernel for the MLP
+        policy (its optional activation workspace is allocated here); policies outside the kernels' limits fall back to the
+        reference's materialised route (cp_step_materialised)."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
         B = x0.shape[0]
