@@ -57,6 +57,30 @@ def test_model_info_and_argument_validation_without_gpu(built):
     assert core.pdp_lqr_solve_batched(ctypes.byref(pr), None, None, None, None, None, 0, None) == -1
 
 
+def test_workspace_size_entry_points_are_host_side_and_consistent(built):
+    """the *_workspace_bytes entry points are plain host functions (callable without a GPU) and follow the documented layouts"""
+    codegen, zoo = built
+    from pdp_amd import runtime
+    oc = runtime.load_model(codegen.build_problem(zoo.make_problem("quadrotor", "irl"))[0])
+    B, T, n, m, p = 7, 50, 13, 4, 9
+    assert oc.lib.pdp_oc_pdp_workspace_bytes(B, T) == B * T * (m * n + m * p + 1) * 8          # K, k and the zero sink slot per step
+    small, big = oc.lib.pdp_oc_solve_workspace_bytes(B, T, 4), oc.lib.pdp_oc_solve_workspace_bytes(B, T, 10)
+    assert 0 < small < big and big - small >= 6 * B * ((T + 1) * n + T * m) * 8              # trial trajectories grow with ls_trials
+    assert oc.lib.pdp_oc_solve_workspace_bytes(2 * B, T, 10) > big
+    assert oc.lib.pdp_cp_step_workspace_bytes(B, T, None, 0) == 0                              # not a ControlPlanning model
+    cp = runtime.load_model(codegen.build_problem(zoo.make_problem("quadrotor", "oc"))[0])
+    mlp = runtime.make_policy("mlp", layers=[13, 13, 4])
+    poly = runtime.make_policy("poly", pivots=np.linspace(0, 100, 6))
+    # MLP [13,13]: 26 stored activations per step, offloaded only when the batch does not fit the CUs at once (256 CUs assumed w/o GPU)
+    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(mlp), 420) == 0
+    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(mlp), 420) == 1024 * 100 * 26 * 8
+    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(poly), 24) == 0
+    assert cp.lib.pdp_oc_solve_workspace_bytes(B, T, 10) == 0 and cp.lib.pdp_oc_pdp_workspace_bytes(B, T) == 0
+    # argument validation of the solver entry point happens before any launch
+    assert oc.lib.pdp_oc_solve_batched(0, T, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert cp.lib.pdp_oc_solve_batched(B, T, None, None, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == -4
+
+
 def test_codegen_is_deterministic_and_cached(built):
     codegen, zoo = built
     a = codegen.generate(zoo.make_problem("rocket", "irl"))
