@@ -200,21 +200,21 @@ int cp_auxsys(int B, int T, const pdp_policy* pol, int p, const double* x, const
         return launched();
     } else { return PDP_E_MODE; }
 }
+inline int device_cu_count() {
+    static int n = 0;
+    if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
 template <class Mdl, int NT>
-int cp_step_launch(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,
+int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,
                    double* u, void* st) {
     const size_t lds = sizeof(double) * (1 + Mdl::PATH_NCONST + Mdl::CHUNK * (Mdl::PATH_NVAR | 1) + (size_t)(T + 1) * Mdl::NX + (size_t)T * Mdl::NU +
                                          (size_t)T * pol->n_pivots + Mdl::NX + 8);
     if (lds > 150 * 1024) return PDP_E_SIZE;
     (void)hipFuncSetAttribute((const void*)cp_step_poly_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PDP_CLEAR();
-    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
+    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B, gy), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
     return launched();
-}
-inline int device_cu_count() {
-    static int n = 0;
-    if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
-    return n;
 }
 template <class Mdl>
 int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
@@ -253,12 +253,18 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
         }
         if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
         const int nt = (p + 15) / 16;
-        switch (nt) {
-            case 1: return cp_step_launch<Mdl, 1>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
-            case 2: return cp_step_launch<Mdl, 2>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
-            case 3: return cp_step_launch<Mdl, 3>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
-            case 4: return cp_step_launch<Mdl, 4>(B, T, pol, p, x0, th, tb, loss, grad, x, u, st);
-            default: return PDP_E_SIZE;
+        if (nt > 4) return PDP_E_SIZE;
+        // a batch that leaves SIMDs idle (one wavefront per trajectory, 4 SIMDs per CU) spreads the parameter tiles of a trajectory
+        // over several wavefronts: each repeats the rollout and carries nt / gy of the sensitivity tiles
+        int gy = (int)((int64_t)4 * device_cu_count() / B);
+        gy = gy < 1 ? 1 : (gy > nt ? nt : gy);
+        const int per = (nt + gy - 1) / gy;
+        gy = (nt + per - 1) / per;
+        switch (per) {
+            case 1: return cp_step_launch<Mdl, 1>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            case 2: return cp_step_launch<Mdl, 2>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            case 3: return cp_step_launch<Mdl, 3>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
+            default: return cp_step_launch<Mdl, 4>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
         }
     } else { return Mdl::KIND == PDP_KIND_CP ? PDP_E_SIZE : PDP_E_MODE; }
 }

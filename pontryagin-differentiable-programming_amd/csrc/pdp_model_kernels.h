@@ -900,6 +900,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     double* basis = us + T * NU;             // T x n_pivots
     double* hx = basis + T * pol.n_pivots;   // NX
     const int b = blockIdx.x, lane = threadIdx.x, np = pol.n_pivots;
+    const int tile0 = blockIdx.y * NT;         // a batch smaller than the machine spreads its parameter tiles over grid.y (rollout repeated)
     const double* th = theta + (int64_t)b * tb;
     double pc[Mdl::NPC];
     Mdl::precompute(nullptr, pc);
@@ -947,8 +948,8 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
         }
     }
     __syncthreads();
-    if (xo) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
-    if (uo) for (int i = lane; i < T * NU; i += 64) uo[(int64_t)b * T * NU + i] = us[i];
+    if (xo && blockIdx.y == 0) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
+    if (uo && blockIdx.y == 0) for (int i = lane; i < T * NU; i += 64) uo[(int64_t)b * T * NU + i] = us[i];
     // ---- forward sensitivities
     Gather gFT, gGT, gCX, gCU;
     make_gather(gFT, lane, NC, STRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, c * NX + r) : -1; });
@@ -963,7 +964,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     // d pi/d theta = [b_0 I_m ... b_N I_m]: this lane's element of tile j is b_{piv}(t) where piv is fixed (rows < m live in register 0)
     int piv[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { const int cidx = 16 * j + col; piv[j] = (cidx < p && row0 < M && (cidx % NU) == row0) ? cidx / NU : -1; }
+    for (int j = 0; j < NT; ++j) { const int cidx = 16 * (tile0 + j) + col; piv[j] = (cidx < p && row0 < M && (cidx % NU) == row0) ? cidx / NU : -1; }
     const int nchunk = (T + CH - 1) / CH;
     const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
     for (int c = 0; c < nchunk; ++c) {
@@ -1013,9 +1014,9 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
 #pragma unroll
         for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc[j] += hx[row] * X[j][r]; }
         double a = sum_over_rowgroups(acc[j]);
-        if (lane < 16 && 16 * j + lane < p) grad[(int64_t)b * p + 16 * j + lane] = a;
+        if (lane < 16 && 16 * (tile0 + j) + lane < p) grad[(int64_t)b * p + 16 * (tile0 + j) + lane] = a;
     }
-    if (lane == 0) loss[b] = J;
+    if (lane == 0 && blockIdx.y == 0) loss[b] = J;
 }
 
 // Fused ControlPlanning.step for ANY policy (tanh MLP up to 8 layers x 32 units, or Lagrange), p <= 512, by the adjoint
