@@ -16,7 +16,8 @@ PDP_DEV const double* mat_at(const pdp_mat& M, int b, int t) {
 // word with stride 0.  A load is then the bare global_load - no bound check, select or add behind it - so the tiles of step t-1
 // can be requested while step t computes and the wait lands at their first use (with post-processing next to the load the
 // compiler waits for the data immediately and every step pays an HBM round trip: 2.4 us per step instead of ~1).
-static __device__ const double PDP_ZERO[2] = {0.0, 0.0};
+static __device__ double PDP_ZERO[2] = {0.0, 0.0};      // never written; not `const`: a constant-address-space zero would turn every streamed load
+                                                           // into a FLAT load, which also counts on lgkmcnt and is waited for at each LDS hand-off
 struct RunPtr { const double* p[4]; int step[4]; };
 template <int NR = 4>
 PDP_DEV RunPtr make_run(const pdp_mat& A, const TileMap& mA, const pdp_mat& Bm, const TileMap& mB, int b, int t) {
