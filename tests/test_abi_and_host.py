@@ -89,6 +89,25 @@ def test_codegen_is_deterministic_and_cached(built):
     assert os.path.exists(codegen.lib_path(a[1]["name"]))
 
 
+def test_tracked_generated_headers_are_current_and_chunks_follow_the_lds_budget(built):
+    """the generated headers kept in the tree are what the generator produces today (a stale header would ship old device code),
+    and the chunk lengths follow the documented LDS rule: fused OC models take as many pool rows as fit 40 KB together with the
+    kernel's other LDS, the other kinds a power of two within 34 KB"""
+    codegen, zoo = built
+    for spec in zoo.SPECS:
+        pb = zoo.make_problem(*spec)
+        src, info = codegen.generate(pb)
+        assert open(codegen.header_path(info["name"])).read() == src, spec
+        nv = info["nvar"]
+        if info["kind"] == codegen.KIND_OC:
+            stride = (nv["patha"] + nv["pathb"] + info["n"]) | 1
+            assert 2 <= info["chunk"] <= 64 and info["chunk"] * stride * 8 <= 40 * 1024
+            assert info["chunk"] == 64 or (info["chunk"] + 1) * stride * 8 + 8 * (608 + info["n"] + info["p"] + info["npc"]) > 40 * 1024
+        else:
+            assert info["chunk"] in (2, 4, 8, 16, 32) and info["chunk"] * (nv["path"] | 1) * 8 <= 34 * 1024
+    assert codegen._pick_chunk(181 + 13, 0) == 16 and codegen._pick_chunk(86 + 107, 13, other_doubles=608 + 4 + 13 + 9 + 23 + 8) == 21
+
+
 @pytest.mark.parametrize("system", ["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
 def test_symbolic_engine_derivatives_match_sympy(system):
     """the product's SX engine (used for code generation) against the independent sympy models of the oracle"""
