@@ -153,7 +153,15 @@ def test_results_do_not_depend_on_stale_device_memory():
     cp = zoo.get("quadrotor", "oc")
     pol = rt.make_policy("mlp", layers=[13, 13, 4])
     thm = 0.1 * rng.standard_normal(420)
-    calls = [lqr_case(13, 4, 9, 50, 64), lqr_case(7, 2, 40, 11, 5), lqr_case(4, 1, 1, 30, 40),
+    ocm = zoo.get("cartpole", "irl")
+    xs0 = np.stack([np.zeros(24), rng.uniform(-0.4, 0.4, 24), np.zeros(24), np.zeros(24)], axis=1)
+    ths = np.array([0.5, 0.5, 1, 1, 6, 1, 1.0]) * (1 + 0.05 * rng.uniform(-1, 1, (24, 7)))
+
+    def oc_solve():
+        sol = ocm.oc_solve(xs0, torch.zeros((24, 20, 1), dtype=torch.float64, device="cuda"), ths, max_iter=60, want_gains=True)
+        return [npy(sol[k]) for k in ("state", "control", "costate", "cost", "gains")] + [np.array(sol["iterations"])]
+
+    calls = [lqr_case(13, 4, 9, 50, 64), lqr_case(7, 2, 40, 11, 5), lqr_case(4, 1, 1, 30, 40), oc_solve,
              lambda: [npy(v) for v in (lambda o: (o["loss"], o["grad"], o["x"], o["lam"]))(mdl.oc_pdp_grad(u, np.array(bench.THETA), dx, du, x0=x0))],
              lambda: [npy(v) for v in cp.cp_step(pol, 420, x0[:, :13], thm, 40)]]
     fresh = [c() for c in calls]
