@@ -200,7 +200,7 @@ int cp_auxsys(int B, int T, const pdp_policy* pol, int p, const double* x, const
         return launched();
     } else { return PDP_E_MODE; }
 }
-inline int device_cu_count() {
+[[maybe_unused]] inline int device_cu_count() {
     static int n = 0;
     if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
     return n;
