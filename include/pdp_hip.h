@@ -170,6 +170,37 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                          double* cost, double* grad_norm, int32_t* converged, double* gains, const pdp_oc_solve_opts* opts,
                          int* iterations, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* OCSys.ocSolver (PDP.py:121-220) as the reference poses it: the multiple-shooting NLP
+ *     min sum_t c(x_t,u_t) + h(x_T)  over x_1..x_T, u_0..u_{T-1}   s.t.  f(x_t,u_t) - x_{t+1} = 0,  x_0 = ini_state   (PDP.py:131-179)
+ * solved from the reference's all-zero initial guess (PDP.py:155,166) by IPOPT's algorithm for the equality-constrained case
+ * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search, least-squares initial multipliers;
+ * CPU restatement: oracle/ipopt_ms.py).  One persistent wavefront per trajectory runs ALL iterations inside one launch: the
+ * Newton step is an LQ problem solved on the MFMA Riccati tiles (one affine column), trial points are evaluated with one lane
+ * per stage; no host round trip and no batch-wide synchronisation.
+ *   in    : x0 [B][n], theta;   with PDP_MS_WARM also x, u, lam (starting point, e.g. the solution at a neighbouring theta)
+ *   in/out: x [B][T+1][n], u [B][T][m], lam [B][T][n]  (lam[t] = multiplier of f(x_t,u_t) - x_{t+1} = IPOPT's lam_g = costate_traj_opt[t])
+ *   out   : cost [B], resid [B][2] (max |defect|, max |grad Lagrangian|), converged [B], iterations [B], status [B], optional
+ *           gains [B][T][n m + m] ({K^T, k} of the last Newton step, layout of pdp_oc_rollout_feedback_batched); any may be NULL.
+ * Convergence: max|defect| <= tol (1 + max|x|,|u|) and max|grad L| <= tol (1 + max|lam|).  status bits: PDP_STATUS_NONFINITE,
+ * PDP_MS_RESTORATION (the line search would enter IPOPT's restoration phase, which is not implemented: fall back to
+ * pdp_oc_solve_batched), PDP_MS_MAXITER, PDP_MS_INERTIA (no positive definite reduced Hessian up to dw = 1e20).  n <= 16, m <= 4. */
+#define PDP_MS_WARM 1
+#define PDP_MS_RESTORATION 4
+#define PDP_MS_MAXITER 8
+#define PDP_MS_INERTIA 16
+typedef struct pdp_oc_ms_opts {
+    double tol;
+    int max_iter;
+    int flags;    /* PDP_MS_WARM */
+    int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
+} pdp_oc_ms_opts;
+int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T);
+/* iter_log (optional, [B][opts->log_rows][8]): one row per accepted step, the columns of IPOPT's iteration output (print_level 5):
+ * iteration, objective, inf_pr, inf_du, dw (Hessian shift), alpha, grad(phi)'d, theta = |c|_1. */
+int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta, int theta_bstride, double* x, double* u, double* lam,
+                            double* cost, double* resid, int32_t* converged, int32_t* iterations, int32_t* status, double* gains,
+                            double* iter_log, const pdp_oc_ms_opts* opts, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Fused "forward + Riccati + PDP gradient" unit (the loop body of the IRL drivers,
  * Examples/IRL/cartpole/cartpole_PDP.py:45-74, with ocSolver replaced by the given controls, or by the
  * caller's optimal (x,u,lam) when flags has PDP_OC_GIVEN_TRAJ):

@@ -1,0 +1,200 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) - numpy restatement of what `OCSys.ocSolver` does with the multiple-shooting
+NLP it builds (reference PDP/PDP.py:131-182): hand it to IPOPT with an all-zero initial guess (PDP.py:155,166; the state and
+control bounds default to +-1e20, PDP.py:47-57,81-93, which IPOPT treats as "no bound", so the problem is equality-constrained
+and the barrier machinery is idle).
+
+The algorithm lives in a third-party dependency that is absent from /root/reference: IPOPT 3.x behind CasADi's `nlpsol('solver',
+'ipopt', ...)` (the reference pins neither; CasADi 3.5.x wheels ship IPOPT 3.12/3.14 with MUMPS).  What is restated here is its
+PUBLISHED algorithm - A. Waechter, L. T. Biegler, "On the implementation of an interior-point filter line-search algorithm for
+large-scale nonlinear programming", Math. Program. 106 (2006) - specialised to the equality-constrained case, default options:
+
+  * primal-dual Newton step on the KKT system  [W + dw I, A'; A, 0] [d; dlam] = -[grad f + A' lam; c]          (eq. 13 / 26)
+  * inertia correction: dw = 0 first; on wrong inertia dw = 1e-4 (or dw_last / 3), then x100 (x8 once a correction has been
+    used before) until the reduced Hessian is positive definite                                                 (Algorithm IC)
+  * filter line search on theta = ||c||_1 and phi = f: switching condition (19) with s_phi = 2.3, s_theta = 1.1, delta = 1,
+    Armijo condition (20) with eta = 1e-8, sufficient decrease (18) with gamma_theta = 1e-5, gamma_phi = 1e-8, theta_min /
+    theta_max = 1e-4 / 1e4 x max(1, theta(x0)), filter augmented after every non-f-type step, step halving     (Algorithm A)
+  * equality multipliers move with the primal step length, lam+ = lam + alpha dlam; initial multipliers from the least-squares
+    estimate, set to zero when its max-norm exceeds 1000                                                         (section 3.6)
+Not restated (never active on the reference's problems, checked on all stored demos and IRL traces): second-order correction,
+watchdog, restoration phase (a step that would need it raises).
+
+The KKT system is solved stage by stage: the Newton step is the solution of an LQ problem with affine terms (defects c_t in the
+dynamics, Lagrangian gradients in the cost), i.e. the same backward Riccati / forward rollout as `LQR.lqrSolver`
+(PDP.py:557-608) with one "parameter" column, and its inertia is correct iff every Quu_t of the recursion is positive definite.
+That is also how the HIP kernel (csrc: oc_solve_ms_kernel) is organised, so the per-iteration log of this file is what the
+kernel is debugged against.
+
+Pinned: reproduces the reference's stored IPOPT optima (tests/golden/demos_*.npz: state, control, lam_g, cost) from the zero
+guess on all five systems, and the stored IRL loss traces (irltrace_*.npz) at the reference's iterates - tests/test_oracle_golden.py.
+"""
+import numpy as np
+
+from .pdp_oracle import _vec
+
+# IPOPT default options used by the restatement (option names of the IPOPT documentation)
+OPT = dict(s_phi=2.3, s_theta=1.1, delta=1.0, eta_phi=1e-8, gamma_theta=1e-5, gamma_phi=1e-8, theta_min_fact=1e-4, theta_max_fact=1e4,
+           first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20,
+           perturb_inc_fact_first=100.0, perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0, constr_mult_init_max=1000.0,
+           alpha_red_factor=0.5, alpha_min_frac=0.05)
+
+
+def evaluate(oc, xs, us, lam, e):
+    """Everything one iteration needs at (x, u, lam): per-stage F, G, Hessians of the Hamiltonian at lam_t (= multiplier of
+    f(x_t,u_t) - x_{t+1}), defects, gradients of the Lagrangian, objective and constraint violation."""
+    n, m, T = oc.n, oc.m, us.shape[0]
+    ev = dict(F=[], G=[], Hxx=[], Hxu=[], Huu=[], c=np.zeros((T, n)), rdx=np.zeros((T + 1, n)), rdu=np.zeros((T, m)))
+    f = 0.0
+    for t in range(T):
+        x, u, l = xs[t], us[t], lam[t]
+        ev["F"].append(oc._m(oc.dfx_fn(x, u, e), n, n))
+        ev["G"].append(oc._m(oc.dfu_fn(x, u, e), n, m))
+        ev["Hxx"].append(oc._m(oc.ddHxx_fn(x, u, l, e), n, n))
+        ev["Hxu"].append(oc._m(oc.ddHxu_fn(x, u, l, e), n, m))
+        ev["Huu"].append(oc._m(oc.ddHuu_fn(x, u, l, e), m, m))
+        ev["c"][t] = _vec(oc.dyn_fn(x, u, e)) - xs[t + 1]
+        ev["rdu"][t] = _vec(oc.dHu_fn(x, u, l, e))
+        if t >= 1:                                   # x_0 is fixed (lbw = ubw = ini_state, PDP.py:141-144): no stationarity row
+            ev["rdx"][t] = _vec(oc.dHx_fn(x, u, l, e)) - lam[t - 1]
+        f += float(oc.path_cost_fn(x, u, e))
+    ev["rdx"][T] = _vec(oc.dhx_fn(xs[T], e)) - lam[T - 1]
+    ev["hxx"] = oc._m(oc.ddhxx_fn(xs[T], e), n, n)
+    ev["f"] = f + float(oc.final_cost_fn(xs[T], e))
+    ev["theta"] = float(np.abs(ev["c"]).sum())
+    ev["inf_pr"] = float(np.abs(ev["c"]).max())
+    ev["inf_du"] = float(max(np.abs(ev["rdx"]).max(), np.abs(ev["rdu"]).max()))
+    return ev
+
+
+def objective_and_violation(oc, xs, us, e):
+    T = us.shape[0]
+    c = np.stack([_vec(oc.dyn_fn(xs[t], us[t], e)) - xs[t + 1] for t in range(T)])
+    return oc.cost(xs, us, e), float(np.abs(c).sum())
+
+
+def kkt_step(ev, dw, n, m):
+    """Newton step of the KKT system by the stage-wise recursion.  Returns (dx [T+1,n], du [T,m], dlam [T,n], inertia_ok)."""
+    T = len(ev["F"])
+    P = ev["hxx"] + dw * np.eye(n)
+    W = ev["rdx"][T].copy()
+    Ks, ks, Ps, Ws = [None] * T, [None] * T, [None] * (T + 1), [None] * (T + 1)
+    Ps[T], Ws[T] = P, W
+    ok = True
+    for t in range(T - 1, -1, -1):
+        F, G = ev["F"][t], ev["G"][t]
+        Pc = P @ ev["c"][t] + W
+        Quu = ev["Huu"][t] + dw * np.eye(m) + G.T @ P @ G
+        Qux = ev["Hxu"][t].T + G.T @ P @ F
+        Qu = ev["rdu"][t] + G.T @ Pc
+        Qxx = ev["Hxx"][t] + dw * np.eye(n) + F.T @ P @ F
+        Qx = ev["rdx"][t] + F.T @ Pc
+        Quu = 0.5 * (Quu + Quu.T)
+        if not np.all(np.isfinite(Quu)) or np.linalg.eigvalsh(Quu).min() <= 0.0:
+            return None, None, None, False
+        Ks[t] = np.linalg.solve(Quu, Qux)
+        ks[t] = np.linalg.solve(Quu, Qu)
+        P = Qxx - Qux.T @ Ks[t]
+        P = 0.5 * (P + P.T)
+        W = Qx - Qux.T @ ks[t]
+        Ps[t], Ws[t] = P, W
+    dx, du, dl = np.zeros((T + 1, n)), np.zeros((T, m)), np.zeros((T, n))
+    for t in range(T):
+        du[t] = -Ks[t] @ dx[t] - ks[t]
+        dx[t + 1] = ev["F"][t] @ dx[t] + ev["G"][t] @ du[t] + ev["c"][t]
+        dl[t] = Ps[t + 1] @ dx[t + 1] + Ws[t + 1]
+    return dx, du, dl, ok
+
+
+def least_squares_multipliers(ev, n, m):
+    """min ||grad f + A' lam||: [I A'; A 0][w; lam] = -[grad f; 0] - the same recursion with W = I, no defects."""
+    T = len(ev["F"])
+    ls = dict(ev)
+    ls["Hxx"] = [np.eye(n)] * T
+    ls["Huu"] = [np.eye(m)] * T
+    ls["Hxu"] = [np.zeros((n, m))] * T
+    ls["hxx"] = np.eye(n)
+    ls["c"] = np.zeros((T, n))
+    _, _, dl, ok = kkt_step(ls, 0.0, n, m)
+    return dl
+
+
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None):
+    """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations`.
+    log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type)."""
+    o = OPT
+    e = _vec(auxvar_value)
+    n, m, T = oc.n, oc.m, int(horizon)
+    xs = np.zeros((T + 1, n))
+    xs[0] = _vec(ini_state)
+    us = np.zeros((T, m))                               # w0 = 0.5 (lb + ub) = 0   (PDP.py:155, 166)
+    lam = np.zeros((T, n))
+    ev = evaluate(oc, xs, us, lam, e)
+    # initial multipliers: least-squares estimate from grad f (rdx / rdu at lam = 0)
+    lam0 = least_squares_multipliers(ev, n, m)
+    if np.all(np.isfinite(lam0)) and np.abs(lam0).max() <= o["constr_mult_init_max"]:
+        lam = lam0
+        ev = evaluate(oc, xs, us, lam, e)
+    theta_max = o["theta_max_fact"] * max(1.0, ev["theta"])
+    theta_min = o["theta_min_fact"] * max(1.0, ev["theta"])
+    filt = []
+    dw_last = 0.0
+    it = 0
+    for it in range(max_iter + 1):
+        f, theta = ev["f"], ev["theta"]
+        scale = 1.0 + max(np.abs(xs).max(), np.abs(us).max())
+        lscale = 1.0 + np.abs(lam).max()
+        if ev["inf_pr"] <= tol * scale and ev["inf_du"] <= tol * lscale:
+            break
+        if it == max_iter:
+            raise RuntimeError("ipopt_ms: no convergence in %d iterations" % max_iter)
+        # ---- search direction with inertia correction (Algorithm IC)
+        dw = 0.0
+        while True:
+            dx, du, dl, ok = kkt_step(ev, dw, n, m)
+            if ok:
+                break
+            if dw == 0.0:
+                dw = o["first_hessian_perturbation"] if dw_last == 0.0 else max(o["min_hessian_perturbation"], o["perturb_dec_fact"] * dw_last)
+            else:
+                dw *= o["perturb_inc_fact_first"] if dw_last == 0.0 else o["perturb_inc_fact"]
+            if dw > o["max_hessian_perturbation"]:
+                raise RuntimeError("ipopt_ms: inertia correction failed")
+        if dw > 0.0:
+            dw_last = dw
+        # grad phi' d = rd' d + lam' c   (A d = -c)
+        gd = float((ev["rdx"] * dx).sum() + (ev["rdu"] * du).sum() + (lam * ev["c"]).sum())
+        # ---- backtracking filter line search (Algorithm A, steps A-5)
+        alpha, accepted, ftype = 1.0, False, False
+        if gd < 0.0:
+            amin = min(o["gamma_theta"], o["gamma_phi"] * theta / (-gd))
+            if theta <= theta_min:
+                amin = min(amin, o["delta"] * theta ** o["s_theta"] / (-gd) ** o["s_phi"])
+        else:
+            amin = o["gamma_theta"]
+        amin *= o["alpha_min_frac"]
+        while alpha >= amin:
+            xt, ut = xs + alpha * dx, us + alpha * du
+            ft, tht = objective_and_violation(oc, xt, ut, e)
+            in_filter_ok = np.isfinite(ft) and np.isfinite(tht) and tht <= theta_max and \
+                all(not (tht >= th_f and ft >= f_f) for th_f, f_f in filt)
+            if in_filter_ok:
+                switching = gd < 0.0 and alpha * (-gd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
+                if theta <= theta_min and switching:
+                    if ft <= f + o["eta_phi"] * alpha * gd + 10.0 * np.finfo(float).eps * abs(f):
+                        accepted, ftype = True, True
+                elif tht <= (1.0 - o["gamma_theta"]) * theta or ft <= f - o["gamma_phi"] * theta:
+                    accepted = True
+            if accepted:
+                break
+            alpha *= o["alpha_red_factor"]
+        if not accepted:
+            raise RuntimeError("ipopt_ms: line search would enter the restoration phase (not restated)")
+        if not ftype:
+            filt.append(((1.0 - o["gamma_theta"]) * theta, f - o["gamma_phi"] * theta))
+        if log is not None:
+            log.append(dict(it=it, f=f, inf_pr=ev["inf_pr"], inf_du=ev["inf_du"], dw=dw, alpha=alpha, ftype=ftype, gd=gd, theta=theta,
+                            dx=dx, du=du, dlam=dl))
+        xs, us, lam = xt, ut, lam + alpha * dl
+        ev = evaluate(oc, xs, us, lam, e)
+    return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it,
+            "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"]}

@@ -169,11 +169,18 @@ class OCSys:
 
     # ---- PDP.py:121-220 ----------------------------------------------------------------------------------------
     def ocSolver(self, ini_state, horizon, auxvar_value=1, print_level=0, costate_option=0):
-        """Reference: multiple-shooting NLP solved by IPOPT.  Here: batched Newton-type solve on the GPU (ocsolver.py);
-        returns the reference's dict (state_traj_opt, control_traj_opt, costate_traj_opt, auxvar_value, time, horizon, cost)."""
+        """Reference: multiple-shooting NLP from an all-zero guess, solved by IPOPT.  Here: the same NLP and the same iteration
+        (Newton-KKT step, inertia correction, filter line search) inside one GPU kernel (ocsolver.py, csrc/pdp_ocsolve_kernels.h);
+        returns the reference's dict (state_traj_opt, control_traj_opt, costate_traj_opt, auxvar_value, time, horizon, cost).
+        Finite state / control bounds (which the reference passes to IPOPT as lbw / ubw, PDP.py:141-168) are not supported and
+        raise; a solve that did not converge warns (the reference prints IPOPT's exit status instead)."""
         from . import ocsolver
         self._require()
+        self._check_unbounded()
         sol = ocsolver.solve_batch(self, np.asarray(_vec(ini_state))[None], int(horizon), auxvar_value, print_level=print_level)
+        if not bool(sol["converged"][0]):
+            import warnings
+            warnings.warn("ocSolver: no convergence (|grad| = %.3e); the returned trajectory is the last iterate" % float(sol["grad_norm"][0]), RuntimeWarning)
         x, u, lam = _np(sol["state"])[0], _np(sol["control"])[0], _np(sol["costate"])[0]
         if costate_option != 0:
             lam = _np(self.costate_batch(x[None], u[None], auxvar_value))[0]
@@ -186,7 +193,15 @@ class OCSys:
         costate [B,T,n], cost [B], converged [B], ... (ocsolver.solve_batch; kwargs: u_init, warm_start, want_gains, tol, max_iter)"""
         from . import ocsolver
         self._require()
+        self._check_unbounded()
         return ocsolver.solve_batch(self, ini_state, int(horizon), auxvar_value, **kwargs)
+
+    def _check_unbounded(self):
+        """the batched solvers handle the equality-constrained NLP only; +-1e20 (the reference's defaults) means "no bound" to IPOPT too"""
+        for nm in ("state_lb", "state_ub", "control_lb", "control_ub"):
+            v = getattr(self, nm, None)
+            if v is not None and any(abs(float(b)) < 1e19 for b in v):
+                raise NotImplementedError("OCSys.ocSolver: finite %s is not supported by the GPU solvers (the reference hands bounds to IPOPT)" % nm)
 
 
 def _label(name):

@@ -298,6 +298,10 @@ def generate(problem):
         groups["pathb"] = _Group("pathb", [(k,) + dims[k] + (mats[k],) for k in ("Hxx", "Hxu", "Hxe", "Huu", "Hue")])
         groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD])
         groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN])
+        # the multiple-shooting OC solver (oc_solve_ms_kernel) knows (x, u, lambda) of every stage before its sweep: one group with
+        # the matrices of the KKT system for the backward pass, F and G alone for the forward pass
+        groups["sol"] = _Group("sol", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "Hxx", "Hxu", "Huu")])
+        groups["solf"] = _Group("solf", [(k,) + dims[k] + (mats[k],) for k in ("F", "G")])
         chunk = None                                          # needs the number of hoisted values: decided below
     elif pb.kind == KIND_CP:
         c, h = pb.path_cost, pb.final_cost
@@ -323,6 +327,11 @@ def generate(problem):
         # fused kernel (csrc/pdp_model_kernels.h fused_lds_bytes): Riccati scratch 608 + constants + dl_T + theta + pc + pad
         nconst = 1 + max(len(groups["patha"].consts) + len(groups["pathb"].consts), len(groups["fwd"].consts), len(groups["fin"].consts))
         chunk = _pick_chunk(groups["patha"].nvar + groups["pathb"].nvar, n, other_doubles=608 + nconst + n + p + max(1, npc) + 8)
+        # solver kernel: pool row = sol entries + defect (n) + Lagrangian gradients (n + m); its own constants, theta, pc, filter (2 x 64)
+        nconst_s = 1 + max(len(groups["sol"].consts), len(groups["solf"].consts), len(groups["fin"].consts))
+        ms_chunk = _pick_chunk(groups["sol"].nvar, 2 * n + m, other_doubles=608 + nconst_s + n + p + max(1, npc) + 128 + 16)
+    else:
+        ms_chunk = 0
     L = []
     L.append("    // ---- theta-only sub-expressions, evaluated once per trajectory (pc[NPC])")
     L.append("    static constexpr int NPC = %d;" % max(1, npc))
@@ -346,7 +355,7 @@ def generate(problem):
         "#define PDP_HD __host__ __device__ inline",
         "#endif",
         "struct PdpModel {",
-        "    static constexpr int KIND = %d, NX = %d, NU = %d, NP = %d, CHUNK = %d;" % (pb.kind, n, m, p, chunk),
+        "    static constexpr int KIND = %d, NX = %d, NU = %d, NP = %d, CHUNK = %d, MS_CHUNK = %d;" % (pb.kind, n, m, p, chunk, ms_chunk),
         "    static constexpr const char* NAME = \"%s\";" % name,
     ]
     src = "\n".join(head) + "\n" + body + "\n};\n"
@@ -414,7 +423,7 @@ def _build(out, deps, cmd_tail, force):
 
 def compile_model(name, force=False):
     """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
-    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
+    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
     return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)

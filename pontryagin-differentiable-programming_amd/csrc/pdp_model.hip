@@ -10,6 +10,7 @@
 #include PDP_MODEL_HEADER
 #include "pdp_model_kernels.h"
 #include "pdp_lqr_kernels.h"
+#include "pdp_ocsolve_kernels.h"
 
 using namespace pdp;
 
@@ -80,8 +81,7 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         if (wsb < oc_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
         const size_t lds = fused_lds_bytes<Mdl>(T);
         if (lds > 160 * 1024) return PDP_E_SIZE;
-        static size_t attr = 0;
-        if (lds > attr) { (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+        (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
         hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
                            dudp, status, (double*)ws);
@@ -173,6 +173,27 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
         if (grad_norm) (void)hipMemcpyAsync(grad_norm, w.st.gnorm, sizeof(double) * B, hipMemcpyDeviceToDevice, st);
         if (converged) (void)hipMemcpyAsync(converged, w.st.converged, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st);
         if (iterations) *iterations = it;
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl>
+int64_t oc_solve_ms_ws_bytes(int B, int T) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) return (int64_t)B * MsLayout<Mdl>::ws_doubles(T) * (int64_t)sizeof(double); else return 0;
+}
+template <class Mdl>
+int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double* x, double* u, double* lam, double* cost, double* resid,
+                int32_t* converged, int32_t* iterations, int32_t* status, double* gains, double* iter_log, const pdp_oc_ms_opts* op, void* ws, int64_t wsb,
+                void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
+        if (B <= 0 || T <= 0 || !x0 || !th || !x || !u || !lam || !op || !ws) return PDP_E_ARG;
+        if (wsb < oc_solve_ms_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
+        const size_t lds = ms_lds_bytes<Mdl>();
+        if (lds > 160 * 1024) return PDP_E_SIZE;
+        (void)hipFuncSetAttribute((const void*)oc_solve_ms_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_solve_ms_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *op, x0, th, tb, x, u, lam, cost, resid, converged, iterations,
+                           status, gains, op->log_rows > 0 ? iter_log : (double*)nullptr, (double*)ws);
         return launched();
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
@@ -334,6 +355,13 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                          double* grad_norm, int32_t* converged, double* gains, const pdp_oc_solve_opts* opts, int* iterations, void* workspace,
                          int64_t workspace_bytes, void* stream) {
     return oc_solve<PdpModel>(B, T, x0, theta, tb, u, x, lam, cost, grad_norm, converged, gains, opts, iterations, workspace, workspace_bytes, stream);
+}
+int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T) { return oc_solve_ms_ws_bytes<PdpModel>(B, T); }
+int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta, int tb, double* x, double* u, double* lam, double* cost,
+                            double* resid, int32_t* converged, int32_t* iterations, int32_t* status, double* gains, double* iter_log,
+                            const pdp_oc_ms_opts* opts, void* workspace, int64_t workspace_bytes, void* stream) {
+    return oc_solve_ms<PdpModel>(B, T, x0, theta, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, opts, workspace, workspace_bytes,
+                                 stream);
 }
 int64_t pdp_oc_pdp_workspace_bytes(int B, int T) {
     if constexpr (PdpModel::KIND == PDP_KIND_OC) return oc_ws_bytes<PdpModel>(B, T); else return 0;

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const doubl
     Mdl::precompute(th, pc);
     if (lane == 0) blk[0] = 0.0;
     if (c == nchunk) {                                       // terminal matrices hxx, hxe at x_T (PDP.py:300-301)
-        if (lane < Mdl::FIN_NCONST) blk[1 + lane] = Mdl::fin_const(lane);
+        for (int i_ = lane; i_ < Mdl::FIN_NCONST; i_ += 64) blk[1 + i_] = Mdl::fin_const(i_);
         for (int i = lane; i < NX * NX; i += 64) codes[i] = (short)Mdl::fin_code(0, i);
         for (int i = lane; i < NX * NP; i += 64) codes[NX * NX + i] = (short)Mdl::fin_code(1, i);
         if (lane == 0) {
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64) oc_auxsys_kernel(int B, int T, const doubl
         return;
     }
     const int t0 = c * ch, cnt = min(ch, T - t0);
-    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     {
         int base = 0;
 #pragma unroll
@@ -435,9 +435,22 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }
 
+// experiment hooks (probes/occupancy_variant.py): -DPDP_FUSED_CHUNK=<steps per chunk> shrinks the LDS pool, -DPDP_FUSED_WAVES=<n> asks the
+// register allocator for n waves per SIMD (n = 2: 256 registers per wave, VGPRs + AGPRs together)
+#ifdef PDP_FUSED_CHUNK
+template <class Mdl> struct FusedChunk { static constexpr int value = PDP_FUSED_CHUNK; };
+#else
+template <class Mdl> struct FusedChunk { static constexpr int value = Mdl::CHUNK; };
+#endif
+#ifdef PDP_FUSED_WAVES
+#define PDP_FUSED_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PDP_FUSED_WAVES, PDP_FUSED_WAVES)))
+#else
+#define PDP_FUSED_OCCUPANCY
+#endif
+
 template <class Mdl>
 struct FusedLayout {
-    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = FusedChunk<Mdl>::value;
     static constexpr int NCB = Mdl::PATHA_NCONST + Mdl::PATHB_NCONST;          // constants of the two backward groups, A first
     static constexpr int NC = 1 + (NCB > Mdl::FWD_NCONST ? (NCB > Mdl::FIN_NCONST ? NCB : Mdl::FIN_NCONST)
                                                          : (Mdl::FWD_NCONST > Mdl::FIN_NCONST ? Mdl::FWD_NCONST : Mdl::FIN_NCONST));
@@ -461,13 +474,13 @@ __host__ __device__ inline size_t fused_lds_bytes(int T) {
 }
 
 template <class Mdl>
-__global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
+__global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
                                                            const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
                                                            const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                            double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
     using L = FusedLayout<Mdl>;
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK, M = NU;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = L::CH, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K [NU x NX] | k [NU x NP] | zero sink
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
@@ -560,7 +573,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     d4 P, W2;
     {
         if (lane == 0) blk[0] = 0.0;
-        if (lane < Mdl::FIN_NCONST) blk[1 + lane] = Mdl::fin_const(lane);
+        for (int i_ = lane; i_ < Mdl::FIN_NCONST; i_ += 64) blk[1 + i_] = Mdl::fin_const(i_);
         if (lane == 0) {
             PDP_LOAD_PAR();
             double xT[NX];
@@ -583,8 +596,8 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     // per chunk: (A) lane = time step evaluates F, G, E, c_x  ->  (C) costates through the chunk on MFMA: lambda_t = c_x + F_t' lambda_{t+1}
     //            (B) lane = time step evaluates the lambda-weighted Hessians Hxx, Hxu, Hxe, Huu, Hue  ->  Riccati steps
     {
-        if (lane < Mdl::PATHA_NCONST) blk[1 + lane] = Mdl::patha_const(lane);
-        if (lane < Mdl::PATHB_NCONST) blk[1 + Mdl::PATHA_NCONST + lane] = Mdl::pathb_const(lane);
+        for (int i_ = lane; i_ < Mdl::PATHA_NCONST; i_ += 64) blk[1 + i_] = Mdl::patha_const(i_);
+        for (int i_ = lane; i_ < Mdl::PATHB_NCONST; i_ += 64) blk[1 + Mdl::PATHA_NCONST + i_] = Mdl::pathb_const(i_);
         constexpr int NA = L::NA, NCA = Mdl::PATHA_NCONST;
         auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
         auto codeB = [](int mat, int i) { int c = Mdl::pathb_code(mat, i); return c >= 0 ? c + NA : (c == -1 ? -1 : c - NCA); };
@@ -725,7 +738,7 @@ __global__ void __launch_bounds__(64) oc_pdp_fused_kernel(int B, int T, int flag
     double acc = 0.0, lsum = 0.0;
     {
         wave_lds_sync();
-        if (lane < Mdl::FWD_NCONST) blk[1 + lane] = Mdl::fwd_const(lane);
+        for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blk[1 + i_] = Mdl::fwd_const(i_);
         constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
         Gather gFT, gGT, gE, gDX, gDU;
         make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
@@ -908,7 +921,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     for (int t = lane; t < T; t += 64)
         for (int i = 0; i < np; ++i) basis[t * np + i] = lagrange_basis(pol, i, (double)t);
     if (lane == 0) blk[0] = 0.0;
-    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     __syncthreads();
     // ---- rollout (uniform)
     double J = 0.0;
@@ -1085,7 +1098,7 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
     Mdl::precompute(nullptr, pc);
     for (int i = lane; i < p; i += 64) ths[i] = theta[(int64_t)b * tb + i];
     if (lane == 0) { blk[0] = 0.0; zs[8 * W] = 1.0; }
-    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     // layer tables (uniform): parameter offset, rows, cols, offset of the stored activations
     int loff[8], lrows[8], lcols[8], aoff[8];
     {
@@ -1351,7 +1364,7 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     const double* ub = u + (int64_t)b * T * NU;
     const double* ob = xobs + (int64_t)b * (T + 1) * NX;
     if (lane == 0) blk[0] = 0.0;
-    if (lane < Mdl::PATH_NCONST) blk[1 + lane] = Mdl::path_const(lane);
+    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     {
         double xc[NX], xn[NX], uc[NU];
 #pragma unroll

@@ -42,7 +42,20 @@ struct RiccatiGains {
     d4 Z;    // Quu^-T (m x m, top-left)
     double Zrep;   // the same block replicated in the four column blocks (register 0): operand of the 4-row products
     d4 Qux;  // m x n, rows 0..m-1
+    bool pd; // WANT_PD only: Quu is positive definite (all leading principal minors > 0) - the inertia test of the KKT system
 };
+
+// Sylvester's criterion on a row-major M x M matrix held uniformly by the wave (M <= 3; the M = 4 path has its own form)
+template <int M>
+PDP_DEV bool posdef_small(const double* a) {
+    if constexpr (M == 1) return a[0] > 0.0;
+    else if constexpr (M == 2) return a[0] > 0.0 && a[0] * a[3] - a[1] * a[2] > 0.0;
+    else {
+        const double d2 = a[0] * a[4] - a[1] * a[3];
+        const double d3 = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+        return a[0] > 0.0 && d2 > 0.0 && d3 > 0.0;
+    }
+}
 
 // Symmetry.  P is symmetric in exact arithmetic and the products use P^T in place of P.  Left alone, the
 // skew-symmetric rounding error of P- = Hxx + F'PF - Qux'K is amplified from step to step (measured on the
@@ -58,7 +71,9 @@ struct RiccatiGains {
 // the transpose of the first m columns of FY, which used to be taken through an LDS round trip in the middle of the step.
 // HUX_FROM_HX2: Hux is taken from the Hxu block of HX2 by an LDS transpose issued at the top of the step (off the critical path: it
 // does not depend on P) instead of being passed in - for callers that have no transposed copy of Hxu at hand.
-template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false>
+// WANT_PD: g.pd reports whether Quu is positive definite (multiple-shooting OC solver: the KKT matrix of the Newton step has the
+// right inertia iff every Quu of the sweep is positive definite).
+template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false, bool WANT_PD = false>
 PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2, double Hux0,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
@@ -100,6 +115,10 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         const double ac = Q2[0] * cof;               // lanes 0..3 hold a_0c C_0c (their element is (0, c)): one product, then 4 broadcasts
         const double t0 = readlane_f64(ac, 0), t1 = readlane_f64(ac, 1), t2 = readlane_f64(ac, 2), t3 = readlane_f64(ac, 3);
         const double det = (t0 + t1) + (t2 + t3), mag = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
+        if constexpr (WANT_PD) {      // leading minors: a00, a00 a11 - a01 a10, cofactor C33 (lane 51 = element (3,3)), det
+            const double a00 = readlane_f64(Q2[0], 0), a01 = readlane_f64(Q2[0], 1), a10 = readlane_f64(Q2[0], 16), a11 = readlane_f64(Q2[0], 17);
+            g.pd = a00 > 0.0 && a00 * a11 - a01 * a10 > 0.0 && readlane_f64(cof, 51) > 0.0 && det > 0.0;
+        }
         if (fabs(det) > 1e-10 * mag && fabs(det) <= 1.7e308) {      // uniform branch
             // 1/det: hardware reciprocal + one Newton step (the full IEEE division sequence is a 12-instruction dependent chain
             // in front of the gain MFMAs; det is nowhere near the subnormal / overflow ranges that sequence exists for)
@@ -127,6 +146,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
 #pragma unroll
             for (int j = 0; j < M; ++j) a[i * M + j] = readlane_f64(Q2[0], 16 * i + j);
         ok = inverse_small_fast<M>(a, ai);
+        if constexpr (WANT_PD) g.pd = posdef_small<M>(a);
         double zz = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i)

@@ -1,7 +1,15 @@
 """Batched optimal-control solve on the GPU - stands where the reference's OCSys.ocSolver hands a multiple-shooting NLP to
-IPOPT (PDP/PDP.py:121-220).  Stagewise Newton / iLQR on the single-shooting problem, every trajectory of the batch in
-parallel; the iteration loop runs inside the model library (pdp_oc_solve_batched, see _solve below), this module adds the
-choice of the starting controls and a batch-level globalisation (solve_batch):
+IPOPT (PDP/PDP.py:121-220).
+
+Default path (solve_batch with no starting controls): the reference's own formulation - the multiple-shooting NLP from the
+all-zero initial guess (PDP.py:155,166), iterated the way IPOPT does (primal-dual Newton step, inertia correction, filter line
+search; csrc/pdp_ocsolve_kernels.h, pdp_oc_solve_ms_batched): one persistent wavefront per trajectory, every iteration inside
+one launch.  It reproduces the optima the reference stored from a cold start on all five benchmark systems.  Trajectories whose
+line search would enter IPOPT's restoration phase (not implemented) fall back to the single-shooting solver below.
+
+Single-shooting path (starting controls given, or as the fallback): stagewise Newton / iLQR, every trajectory of the batch in
+parallel; the iteration loop runs inside the model library (pdp_oc_solve_batched, see _solve below), plus the choice of the
+starting controls and a batch-level globalisation (solve_batch_single_shooting):
 
     repeat:  costates  lambda = c_x + f_x' lambda+ , stationarity residual H_u
              F, G, Hxx, Hxu, Huu, hxx along (x, u, lambda)
@@ -59,8 +67,46 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
 
 
 def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,
-                warm_start=None, want_gains=False):
-    """Batched OC solve (see _solve) plus a batch-level globalisation: samples that did not converge (non-convex problems such
+                warm_start=None, want_gains=False, method="auto"):
+    """ocSolver for a batch.  method "auto": the multiple-shooting solver (the reference's formulation, IPOPT's iteration) unless
+    starting controls `u_init` are given; "ms" / "single" force one.  warm_start: a previous solution of the same batch (dict with
+    state, control, costate[, gains]) - the multiple-shooting solver starts from that point.  Samples the multiple-shooting solver
+    returns unconverged (restoration phase needed, iteration limit) are re-solved by the single-shooting path.
+    Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
+    iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
+    torch = runtime.torch_cuda()
+    if method == "single" or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start):
+        return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
+                                           neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)
+    mdl = oc.model()
+    x0 = runtime.dev(ini_state).reshape(-1, mdl.n)
+    B = x0.shape[0]
+    th = oc._theta(auxvar_value, B)
+    warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])
+    ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains)
+    sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
+           "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
+    if want_gains:
+        sol["gains"] = ms["gains"]
+    bad = ~ms["converged"]
+    if print_level > 0:
+        print("  multiple-shooting solve: %d/%d converged, max %d iterations" % (int(ms["converged"].sum()), B, sol["iterations"]))
+    if bool(bad.any()):
+        bi = torch.nonzero(bad).flatten()
+        th_np = np.asarray(th, dtype=np.float64).reshape(-1, oc.n_auxvar)
+        thb = th_np[bi.cpu().numpy()] if th_np.shape[0] == B and B > 1 else th_np[0]
+        u0 = warm_start["control"][bi] if warm_start is not None else None
+        sub = solve_batch_single_shooting(oc, x0[bi], horizon, thb, u_init=u0, tol=tol, max_iter=max_iter, print_level=print_level,
+                                          neighbor_retries=neighbor_retries, want_gains=want_gains)
+        for k in ("state", "control", "costate", "cost", "grad_norm", "converged") + (("gains",) if want_gains else ()):
+            sol[k][bi] = sub[k]
+        sol["iterations"] += int(sub["iterations"])
+    return sol
+
+
+def solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,
+                                warm_start=None, want_gains=False):
+    """Batched single-shooting OC solve (see _solve) plus a batch-level globalisation: samples that did not converge (non-convex problems such
     as the cart-pole swing-up can trap single shooting in a poor basin) are re-solved from a CLOSED-LOOP warm start: the optimal
     trajectory and LQR feedback gains of the nearest converged sample (distance in initial state and parameter) are rolled out
     from the stuck sample's own initial state (open-loop warm starts diverge on unstable systems), up to `neighbor_retries` times."""

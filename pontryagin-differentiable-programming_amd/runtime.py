@@ -40,6 +40,10 @@ class PdpOcSolveOpts(C.Structure):
                 ("straggler_patience", C.c_int), ("print_level", C.c_int)]
 
 
+class PdpOcMsOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("flags", C.c_int), ("log_rows", C.c_int)]
+
+
 class PdpPolicy(C.Structure):
     _fields_ = [("kind", C.c_int), ("n_pivots", C.c_int), ("pivots", C.c_double * 16), ("n_layers", C.c_int), ("sizes", C.c_int * 8)]
 
@@ -47,7 +51,7 @@ class PdpPolicy(C.Structure):
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
                 "pdp_sysid_aux_integrate_batched"]
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
-                 "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched",
+                 "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched", "pdp_oc_solve_ms_workspace_bytes", "pdp_oc_solve_ms_batched",
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
@@ -209,6 +213,8 @@ _MODEL_SIGS = {
     "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
     "pdp_oc_solve_workspace_bytes": (_I64, [_I, _I, _I]),
     "pdp_oc_solve_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcSolveOpts), C.POINTER(C.c_int), _VP, _I64, _VP]),
+    "pdp_oc_solve_ms_workspace_bytes": (_I64, [_I, _I]),
+    "pdp_oc_solve_ms_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcMsOpts), _VP, _I64, _VP]),
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
     "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
@@ -308,6 +314,37 @@ class ModelLib:
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "grad_norm": gnorm, "converged": conv != 0, "iterations": it.value}
         if want_gains:
             out["gains"] = gains
+        return out
+
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0):
+        """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
+        (pdp_oc_solve_ms_batched: one persistent wavefront per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
+        from a given point instead (x[:, 0] is replaced by x0).  Returns dict(state, control, costate, cost, resid [B,2], converged (bool),
+        iterations [B], status [B][, gains])."""
+        torch = torch_cuda()
+        x0 = dev(x0).reshape(-1, self.n)
+        B, T = x0.shape[0], int(T)
+        th, tb = self._theta(theta, B)
+        f64 = dict(dtype=torch.float64, device="cuda")
+        if warm is not None:
+            x, u, lam = (dev(a).clone().contiguous() for a in warm)
+            assert x.shape == (B, T + 1, self.n) and u.shape == (B, T, self.m) and lam.shape == (B, T, self.n)
+        else:
+            x, u, lam = torch.empty((B, T + 1, self.n), **f64), torch.empty((B, T, self.m), **f64), torch.empty((B, T, self.n), **f64)
+        cost, resid = torch.empty((B,), **f64), torch.empty((B, 2), **f64)
+        conv, iters, status = (torch.zeros((B,), dtype=torch.int32, device="cuda") for _ in range(3))
+        gains = torch.empty((B, T, self.n * self.m + self.m), **f64) if want_gains else None
+        nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T)
+        ws = torch.empty((max(nbytes, 8) // 8,), **f64)
+        log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
+        opts = PdpOcMsOpts(float(tol), int(max_iter), 1 if warm is not None else 0, int(log_rows))
+        check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
+                                               ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
+        out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}
+        if want_gains:
+            out["gains"] = gains
+        if log is not None:
+            out["log"] = log            # [B, log_rows, 8]: iteration, objective, inf_pr, inf_du, dw, alpha, grad(phi)'d, theta
         return out
 
     def oc_costate(self, x, u, theta):

@@ -187,3 +187,43 @@ def test_sysid_step_matches_reference_run(golden_dir, name):
     loss, grad = _sysid(name).step(list(io["inputs"]), list(io["states"]), g["theta"])
     assert abs(loss - float(g["loss"])) <= 1e-12 * abs(float(g["loss"]))
     assert np.abs(grad - g["grad"]).max() <= 1e-11 * np.abs(g["grad"]).max()
+
+
+@pytest.mark.parametrize("name,demos", [("pendulum", [0, 1, 2, 3, 4]), ("robotarm", [0, 1, 2]), ("rocket", [0]), ("quadrotor", [0]), ("cartpole", [3])])
+def test_ipopt_restatement_reaches_the_stored_optimum_from_the_zero_guess(golden_dir, name, demos):
+    """oracle/ipopt_ms.py (IPOPT's published algorithm on the reference's multiple-shooting NLP, PDP.py:131-182, all-zero initial
+    guess) is pinned on what the real IPOPT returned on the author's machine: state, control, lam_g and cost of the stored demos."""
+    from oracle import ipopt_ms
+    d = _load(golden_dir, "demos_%s.npz" % name)
+    oc = _oc(name)
+    T = d["control"].shape[1]
+    for i in demos:
+        s = ipopt_ms.solve(oc, d["state"][i, 0], T, d["true_parameter"])
+        sc = lambda a: max(1.0, np.abs(a).max())
+        assert abs(s["cost"] - d["cost"][i]) <= 1e-9 * abs(d["cost"][i])
+        assert np.abs(s["state_traj_opt"] - d["state"][i]).max() <= 1e-7 * sc(d["state"][i])
+        assert np.abs(s["control_traj_opt"] - d["control"][i]).max() <= 1e-7 * sc(d["control"][i])
+        assert np.abs(s["costate_traj_opt"] - d["costate"][i]).max() <= 1e-7 * sc(d["costate"][i])
+
+
+def test_ipopt_restatement_reproduces_the_stored_rocket_irl_trace(golden_dir):
+    """the reference's IRL loop solves the OC problem cold at every iterate (Examples/IRL/rocket/rocket_PDP.py); the restatement lands
+    in the same optimum at iterates far from theta* (loss 980) and near it: stored loss_trace reproduced to 1e-9 relative."""
+    from oracle import ipopt_ms
+    d = _load(golden_dir, "demos_rocket.npz")
+    tr = _load(golden_dir, "irltrace_rocket.npz")
+    oc = _oc("rocket")
+    T = d["control"].shape[1]
+    for j in (0, 4):
+        s = ipopt_ms.solve(oc, d["state"][0, 0], T, tr["param"][j])
+        loss = ((s["state_traj_opt"] - d["state"][0]) ** 2).sum() + ((s["control_traj_opt"] - d["control"][0]) ** 2).sum()
+        assert abs(loss - tr["loss_next"][j]) <= 1e-9 * abs(tr["loss_next"][j])
+
+
+def test_ipopt_restatement_reports_the_restoration_phase(golden_dir):
+    """robot arm demo 3 starts at an equilibrium of the zero guess: IPOPT's line search runs into the restoration phase, which is not
+    restated (the product reports PDP_MS_RESTORATION and falls back to its single-shooting solver)"""
+    from oracle import ipopt_ms
+    d = _load(golden_dir, "demos_robotarm.npz")
+    with pytest.raises(RuntimeError, match="restoration"):
+        ipopt_ms.solve(_oc("robotarm"), d["state"][3, 0], d["control"].shape[1], d["true_parameter"])
