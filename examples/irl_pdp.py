@@ -69,9 +69,15 @@ def main():
     warm = None
     t0 = time.time()
     for k in range(a.iters):
-        sol = ocsolver.solve_batch(oc, demo_x[:, 0], T, theta, u_init=demo_u if warm is None else None, warm_start=warm, want_gains=True)
-        warm = {key: sol[key] for key in ("state", "control", "gains")}
+        # first iterate: cold, the reference's all-zero guess (PDP.py:155,166); afterwards the multiple-shooting solver starts from the
+        # previous iterate's (x, u, lambda) - the parameters move by lr * gradient per step - and needs 2-4 Newton iterations
+        sol = ocsolver.solve_batch(oc, demo_x[:, 0], T, theta, warm_start=warm)
+        if not bool(sol["converged"].all()):
+            print("iter %5d  warning: %d of %d OC solves did not converge" % (k, int((~sol["converged"]).sum()), demo_x.shape[0]))
+        warm = {key: sol[key] for key in ("state", "control", "costate")}
         out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"])
+        if int(out["status"].sum()) != 0:
+            print("iter %5d  warning: Riccati sweep reported numerical trouble on %d trajectories" % (k, int((out["status"] != 0).sum())))
         loss = float(out["loss"].mean())
         dp = out["grad"].mean(dim=0).cpu().numpy()
         theta = theta - a.lr * dp

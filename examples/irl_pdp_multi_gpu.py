@@ -2,7 +2,7 @@
 """Data-parallel PDP iteration over the GPUs of one node (one process per GPU, RCCL over xGMI):
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
-        examples/irl_pdp_multi_gpu.py --system quadrotor --batch 8192 --iters 20
+        examples/irl_pdp_multi_gpu.py --batch 8192 --iters 20
 
 A batch of B trajectories (random initial states, near-hover controls, a demonstration per trajectory) is cut into contiguous
 shards (`pdp_amd.parallel.shard`); every rank runs the fused forward + Riccati + PDP-gradient kernel on its shard with the

@@ -194,7 +194,7 @@ typedef struct pdp_oc_ms_opts {
     int flags;    /* PDP_MS_WARM */
     int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
 } pdp_oc_ms_opts;
-int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T);
+int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T, int max_iter);
 /* iter_log (optional, [B][opts->log_rows][8]): one row per accepted step, the columns of IPOPT's iteration output (print_level 5):
  * iteration, objective, inf_pr, inf_du, dw (Hessian shift), alpha, grad(phi)'d, theta = |c|_1. */
 int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta, int theta_bstride, double* x, double* u, double* lam,
@@ -211,6 +211,7 @@ int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta,
  * Outputs: loss [B], grad [B][p], optional dxdp [B][T+1][n][p], dudp [B][T][m][p] (NULL = not stored),
  *          status [B].  workspace: pdp_oc_pdp_workspace_bytes(B,T). */
 #define PDP_OC_GIVEN_TRAJ 1
+#define PDP_OC_PACKED 2 /* grad is [B][p + 1]: gradient and, in the last column, the loss (the row the multi-GPU iteration all-gathers) */
 int64_t pdp_oc_pdp_workspace_bytes(int B, int T);
 int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta,
                             int theta_bstride, const double* demo_x, const double* demo_u, double* x, double* lam,

@@ -327,9 +327,9 @@ def generate(problem):
         # fused kernel (csrc/pdp_model_kernels.h fused_lds_bytes): Riccati scratch 608 + constants + dl_T + theta + pc + pad
         nconst = 1 + max(len(groups["patha"].consts) + len(groups["pathb"].consts), len(groups["fwd"].consts), len(groups["fin"].consts))
         chunk = _pick_chunk(groups["patha"].nvar + groups["pathb"].nvar, n, other_doubles=608 + nconst + n + p + max(1, npc) + 8)
-        # solver kernel: pool row = sol entries + defect (n) + Lagrangian gradients (n + m); its own constants, theta, pc, filter (2 x 64)
+        # solver kernel: pool row = sol entries + defect (n) + Lagrangian gradients (n + m); its own constants, theta, pc
         nconst_s = 1 + max(len(groups["sol"].consts), len(groups["solf"].consts), len(groups["fin"].consts))
-        ms_chunk = _pick_chunk(groups["sol"].nvar, 2 * n + m, other_doubles=608 + nconst_s + n + p + max(1, npc) + 128 + 16)
+        ms_chunk = _pick_chunk(groups["sol"].nvar, 2 * n + m, other_doubles=608 + nconst_s + n + p + max(1, npc) + 16)
     else:
         ms_chunk = 0
     L = []

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     RunPtr rF = make_run(pr.F, mNN, none, mNN, b, T - 1), rY = make_run(pr.G, mNM, pr.E, mNP, b, T - 1), rHxx = make_run(pr.Hxx, mNN, none, mNN, b, T - 1),
            rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1),
            rGr = make_run(pr.G, mNMrep, none, mNN, b, T - 1);
-    auto load_bwd = [&](BwdTiles& w) {     // (the request after the last step reads one step before the arrays' first: never used)
+    auto load_bwd = [&](BwdTiles& w) {     // (issued for steps t-1 >= 0 only: bstep guards the request of the last step)
         w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Grep = load_run(rGr, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1);
         w.HU2 = load_run<1>(rHU, -1);
     };

@@ -178,8 +178,8 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
 }
 
 template <class Mdl>
-int64_t oc_solve_ms_ws_bytes(int B, int T) {
-    if constexpr (Mdl::KIND == PDP_KIND_OC) return (int64_t)B * MsLayout<Mdl>::ws_doubles(T) * (int64_t)sizeof(double); else return 0;
+int64_t oc_solve_ms_ws_bytes(int B, int T, int max_iter) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) return (int64_t)B * MsLayout<Mdl>::ws_doubles(T, max_iter < 0 ? 0 : max_iter) * (int64_t)sizeof(double); else return 0;
 }
 template <class Mdl>
 int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double* x, double* u, double* lam, double* cost, double* resid,
@@ -187,7 +187,7 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
                 void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
         if (B <= 0 || T <= 0 || !x0 || !th || !x || !u || !lam || !op || !ws) return PDP_E_ARG;
-        if (wsb < oc_solve_ms_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
+        if (op->max_iter < 0 || wsb < oc_solve_ms_ws_bytes<Mdl>(B, T, op->max_iter)) return PDP_E_ARG;
         const size_t lds = ms_lds_bytes<Mdl>();
         if (lds > 160 * 1024) return PDP_E_SIZE;
         (void)hipFuncSetAttribute((const void*)oc_solve_ms_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -356,7 +356,7 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                          int64_t workspace_bytes, void* stream) {
     return oc_solve<PdpModel>(B, T, x0, theta, tb, u, x, lam, cost, grad_norm, converged, gains, opts, iterations, workspace, workspace_bytes, stream);
 }
-int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T) { return oc_solve_ms_ws_bytes<PdpModel>(B, T); }
+int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T, int max_iter) { return oc_solve_ms_ws_bytes<PdpModel>(B, T, max_iter); }
 int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta, int tb, double* x, double* u, double* lam, double* cost,
                             double* resid, int32_t* converged, int32_t* iterations, int32_t* status, double* gains, double* iter_log,
                             const pdp_oc_ms_opts* opts, void* workspace, int64_t workspace_bytes, void* stream) {

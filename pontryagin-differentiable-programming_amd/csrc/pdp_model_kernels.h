@@ -653,9 +653,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             wave_lds_sync();
             PDP_ACC(0);
             if (!given) {                           // (C) costates through the chunk; pool row tl receives lambda_{t+1}
-                // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them.
-                // The running offsets simply keep moving down; the last prefetch of a chunk reads the row below row 0 (scratch
-                // space of this workgroup, or - past the start of LDS - zeros) and is not used.
+                // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
+                // (not below the first row of the pool: the last step of a chunk issues no prefetch).
                 GatherRun cF = gather_at(gF, cnt - 1, blk), cC = gather_at(gCX, cnt - 1, blk), wL;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
@@ -665,8 +664,9 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                     wL.tmul[r] = valid ? 8 * L::BSTRIDE : 0;
                 }
                 d4 Fc = gather_run(cF, -1), CX = gather_run(cC, -1);
-                auto cstep = [&](const d4 Lin, d4& Lout) {
-                    d4 Fc_n = gather_run(cF, -1), CX_n = gather_run(cC, -1);
+                auto cstep = [&](int tl, const d4 Lin, d4& Lout) {
+                    d4 Fc_n = Fc, CX_n = CX;
+                    if (tl > 0) { Fc_n = gather_run(cF, -1); CX_n = gather_run(cC, -1); }
                     scatter_run(wL, Lin, -1);
                     Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
                     Fc = Fc_n; CX = CX_n;
@@ -675,8 +675,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 // its predecessor's tile until its last instruction, so one set would need a copy in the middle of every chain
                 d4 Lam2 = z;
                 int tl = cnt - 1;
-                for (; tl >= 1; tl -= 2) { cstep(Lam, Lam2); cstep(Lam2, Lam); }
-                if (tl == 0) { cstep(Lam, Lam2); Lam = Lam2; }
+                for (; tl >= 1; tl -= 2) { cstep(tl, Lam, Lam2); cstep(tl - 1, Lam2, Lam); }
+                if (tl == 0) { cstep(0, Lam, Lam2); Lam = Lam2; }
                 wave_lds_sync();
             }
             PDP_ACC(1);
@@ -705,16 +705,15 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
                       rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
-            // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The running
-            // offsets keep moving down (the last prefetch of a chunk reads below row 0 and is unused).  Two steps per trip with the
-            // prefetched tiles alternating between two register sets (no copies at the back edge).
-            d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb, Yb;
+            // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The last step
+            // of a chunk prefetches nothing (no LDS read outside the pool).  Two steps per trip with the prefetched tiles alternating
+            // between two register sets (no copies at the back edge).
+            d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
                 d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
-                Fn = gather_run(rF, -1);
-                Yn = gather_run(rY, -1);
+                if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
@@ -813,8 +812,10 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
     }
     acc = sum_over_rowgroups(acc);
     lsum = wave_sum(lsum);
-    if (lane >= M && lane < M + NP) grad[(int64_t)b * NP + (lane - M)] = acc;
-    if (lane == 0) loss[b] = lsum;
+    // PDP_OC_PACKED: grad is [B][NP + 1] with the loss in the last column - the row the data-parallel iteration all-gathers
+    const int gstride = (flags & PDP_OC_PACKED) ? NP + 1 : NP;
+    if (lane >= M && lane < M + NP) grad[(int64_t)b * gstride + (lane - M)] = acc;
+    if (lane == 0) { loss[b] = lsum; if (flags & PDP_OC_PACKED) grad[(int64_t)b * gstride + NP] = lsum; }
     int st = 0;
     if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
     if (!ok) st |= PDP_STATUS_PIVOT;

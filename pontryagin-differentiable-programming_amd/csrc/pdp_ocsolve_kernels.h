@@ -38,14 +38,13 @@ struct MsLayout {
     static constexpr int FSTRIDE = (NF + NX) | 1;
     static constexpr int ROWMAX = BSTRIDE > FSTRIDE ? BSTRIDE : FSTRIDE;
     static constexpr int POOL = CH * ROWMAX > Mdl::FIN_NVAR + 1 ? CH * ROWMAX : Mdl::FIN_NVAR + 1;
-    static constexpr int MAXF = 64;                                // filter entries (one lane checks one entry)
     static constexpr int GSZ = NX * NU + NU + 1;                   // per stage: K [NU x NX] | k [NU] | zero sink
     static constexpr int PWSZ = NX * NX + NX + 1;                  // per stage: P_{t+1} [NX x NX] | W_{t+1} [NX] | zero sink
-    static constexpr int LDS_DOUBLES = RICCATI_SCRATCH + NC + POOL + NX + NP + Mdl::NPC + 2 * MAXF + 8;
-    // workspace per trajectory (doubles): dx | du | dlam | defects | grad_x L | grad_u L | gains | P,W
-    __host__ __device__ static constexpr int64_t ws_doubles(int T) {
+    static constexpr int LDS_DOUBLES = RICCATI_SCRATCH + NC + POOL + NX + NP + Mdl::NPC + 8;
+    // workspace per trajectory (doubles): dx | du | dlam | defects | grad_x L | grad_u L | gains | P,W | filter (theta, phi per iteration)
+    __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
         return (int64_t)(T + 1) * NX + (int64_t)T * NU + (int64_t)T * NX + (int64_t)T * NX + (int64_t)(T + 1) * NX + (int64_t)T * NU +
-               (int64_t)T * GSZ + (int64_t)T * PWSZ;
+               (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
     }
 };
 
@@ -76,8 +75,6 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     double* pool = blk + L::NC;
     double* dlT = pool + L::POOL;                       // terminal gradient (NX)
     double* par = dlT + NX;                             // [theta (NP) | pc (NPC)]
-    double* fth = par + NP + Mdl::NPC;                  // filter: theta entries
-    double* fph = fth + L::MAXF;                        //         phi entries
     const int b = blockIdx.x, lane = threadIdx.x;
     const d4 z = zero4();
     {
@@ -99,7 +96,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     double* xb = x + (int64_t)b * (T + 1) * NX;
     double* ub = u + (int64_t)b * T * NU;
     double* lb = lam + (int64_t)b * T * NX;
-    double* w0 = ws + (int64_t)b * L::ws_doubles(T);
+    double* w0 = ws + (int64_t)b * L::ws_doubles(T, op.max_iter);
     double* dxb = w0;                                   // (T+1) x NX
     double* dub = dxb + (int64_t)(T + 1) * NX;          // T x NU
     double* dlb = dub + (int64_t)T * NU;                // T x NX
@@ -108,6 +105,8 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     double* rus = rxs + (int64_t)(T + 1) * NX;          // grad_u L, T x NU
     double* gw = rus + (int64_t)T * NU;                 // gains, T x GSZ
     double* pw = gw + (int64_t)T * GSZ;                 // P_{t+1}, W_{t+1}, T x PWSZ
+    double* fth = pw + (int64_t)T * PWSZ;               // filter: theta entries (at most one per iteration) ...
+    double* fph = fth + (op.max_iter + 1);              //         ... and phi entries
 
     // ---- starting point: the caller's (x, u, lambda) [PDP_MS_WARM], or IPOPT's: w0 = 0 (PDP.py:155,166), x_0 = ini_state ------
     const bool warm = (op.flags & PDP_MS_WARM) != 0;
@@ -387,7 +386,8 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             trial(alpha, ft, tht);
             bool okf = fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308 && tht <= theta_max;
             if (okf) {
-                const bool dominated = lane < nfilt && tht >= fth[lane] && ft >= fph[lane];
+                bool dominated = false;
+                for (int e = lane; e < nfilt; e += 64) dominated = dominated || (tht >= fth[e] && ft >= fph[e]);
                 okf = !__any(dominated);
             }
             if (okf) {
@@ -404,11 +404,9 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? alpha : 0.0; row[6] = gd; row[7] = theta;
         }
         if (!accepted) { st |= PDP_MS_RESTORATION; break; }
-        if (!ftype) {
-            if (nfilt >= L::MAXF) { st |= PDP_MS_RESTORATION; break; }
+        if (!ftype) {                               // (at most one entry per iteration: the workspace holds max_iter + 1)
             if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
             ++nfilt;
-            wave_lds_sync();
         }
         for (int q = lane; q < T * NX; q += 64) { xb[NX + q] += alpha * dxb[NX + q]; lb[q] += alpha * dlb[q]; }
         for (int q = lane; q < T * NU; q += 64) ub[q] += alpha * dub[q];

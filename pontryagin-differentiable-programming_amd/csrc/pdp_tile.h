@@ -7,8 +7,8 @@
 // So every product of the Riccati recursion is phrased as  C + X^T Y  and never leaves the register file:
 // no LDS traffic, no shuffles.  A transposed operand is obtained by loading the source transposed.
 //
-// v_mfma_f64_16x16x4_f64 on MI355X: 64 cycles issue (= the fp64 vector rate, the DP units are shared), so a
-// 16x16x16 product costs 256 cycles; products whose inner dimension is <= 4 (the control dimension) cost 64.
+// v_mfma_f64_16x16x4_f64 on MI355X: 64 cycles issue, so a 16x16x16 product costs 256 cycles; products with at most 4 OUTPUT rows
+// (everything multiplied by the m x m control block) run on the 4-block form v_mfma_f64_4x4x4_4b (25-32 cycles each, mma4_* below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -59,3 +59,76 @@ def pdp_iteration(unit, shard_inputs, n_total=None):
     out = unit(**shard_inputs)
     loss, grad = (out["loss"], out["grad"]) if isinstance(out, dict) else out
     return mean_loss_grad(loss, grad, n_total)
+
+
+def gather_packed(packed, n_total=None, out=None):
+    """all-gather of the [b, p+1] rows the fused kernel writes with PDP_OC_PACKED (gradient | loss): no packing copies on the way in.
+    Equal shards (n_total divisible by the world size, or None): ONE collective straight into `out` [B, p+1]; ragged shards go
+    through gather_loss_grad's padding.  Returns the [B, p+1] tensor."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return packed
+    world = dist.get_world_size()
+    b, p1 = packed.shape
+    if n_total is not None and n_total % world != 0:
+        L, G = gather_loss_grad(packed[:, p1 - 1].contiguous(), packed[:, :p1 - 1].contiguous(), n_total)
+        return torch.cat([G, L[:, None]], dim=1)
+    if out is None:
+        out = torch.empty((world * b, p1), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out
+
+
+class OverlappedGather:
+    """The exchange step of the data-parallel iteration, off the critical path: the all-gather of step k runs on a side stream
+    while the kernels of step k+1 run on the compute stream (the per-sample rows of step k are consumed one step later - a
+    gradient-descent driver that tolerates one step of staleness, or a benchmark that only needs the exchange done by the end).
+    Double-buffered: `submit(packed_k)` copies nothing - the caller alternates between two packed buffers (see `buffers`) - records
+    an event on the compute stream, and enqueues the collective on the side stream behind it; `wait(k)` makes the compute stream
+    wait for the collective of step k.  On CPU tensors (gloo tests) it degenerates to the blocking collective."""
+
+    def __init__(self, rows, cols, dtype=torch.float64, device="cuda"):
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.cuda = torch.device(device).type == "cuda"
+        self.buffers = [torch.zeros((rows, cols), dtype=dtype, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros((self.world * rows, cols), dtype=dtype, device=device) for _ in range(2)]
+        self.side = torch.cuda.Stream() if self.cuda else None
+        self.done = [None, None]
+        self.k = 0
+
+    def next_buffer(self):
+        """the packed buffer the next step's kernel should write (its previous collective has been waited for)"""
+        i = self.k % 2
+        if self.cuda and self.done[i] is not None:
+            torch.cuda.current_stream().wait_event(self.done[i])
+        return self.buffers[i]
+
+    def submit(self):
+        """enqueue the all-gather of the buffer handed out by the last next_buffer(); returns the index of the gathered tensor"""
+        i = self.k % 2
+        self.k += 1
+        if self.world == 1:
+            self.gathered[i] = self.buffers[i]
+            return i
+        if not self.cuda:
+            dist.all_gather_into_tensor(self.gathered[i], self.buffers[i])
+            return i
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_gather_into_tensor(self.gathered[i], self.buffers[i])
+            self.done[i] = torch.cuda.Event()
+            self.done[i].record(self.side)
+        return i
+
+    def result(self, i):
+        """the [B, p+1] rows of a submitted step (the compute stream waits for its collective)"""
+        if self.cuda and self.done[i] is not None:
+            torch.cuda.current_stream().wait_event(self.done[i])
+        return self.gathered[i]
+
+    def drain(self):
+        if self.cuda:
+            for e in self.done:
+                if e is not None:
+                    torch.cuda.current_stream().wait_event(e)

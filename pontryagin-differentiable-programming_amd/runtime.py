@@ -213,7 +213,7 @@ _MODEL_SIGS = {
     "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
     "pdp_oc_solve_workspace_bytes": (_I64, [_I, _I, _I]),
     "pdp_oc_solve_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcSolveOpts), C.POINTER(C.c_int), _VP, _I64, _VP]),
-    "pdp_oc_solve_ms_workspace_bytes": (_I64, [_I, _I]),
+    "pdp_oc_solve_ms_workspace_bytes": (_I64, [_I, _I, _I]),
     "pdp_oc_solve_ms_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcMsOpts), _VP, _I64, _VP]),
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
@@ -334,7 +334,7 @@ class ModelLib:
         cost, resid = torch.empty((B,), **f64), torch.empty((B, 2), **f64)
         conv, iters, status = (torch.zeros((B,), dtype=torch.int32, device="cuda") for _ in range(3))
         gains = torch.empty((B, T, self.n * self.m + self.m), **f64) if want_gains else None
-        nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T)
+        nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T, int(max_iter))
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
         opts = PdpOcMsOpts(float(tol), int(max_iter), 1 if warm is not None else 0, int(log_rows))
@@ -373,9 +373,10 @@ class ModelLib:
         check(self.lib.pdp_oc_auxsys_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, C.byref(o), current_stream_ptr()), "pdp_oc_auxsys_batched")
         return out
 
-    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None):
+    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None, packed=False):
         """Fused forward + Riccati + PDP gradient.  Give (x, lam) to use an optimal trajectory (PDP_OC_GIVEN_TRAJ),
-        else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp])."""
+        else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp]).
+        packed: the kernel writes gradient and loss as one [B, p+1] tensor (PDP_OC_PACKED; out["packed"], out["grad"] is a view of it)."""
         torch = torch_cuda()
         u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
         B, T = u.shape[0], u.shape[1]
@@ -398,16 +399,23 @@ class ModelLib:
             return t
         if x is None:
             x, lam = buf("x", (B, T + 1, n)), buf("lam", (B, T, n))
-        loss, grad = buf("loss", (B,)), buf("grad", (B, p))
+        loss = buf("loss", (B,))
+        if packed:
+            pk = buf("packed", (B, p + 1))
+            grad, flags = pk[:, :p], flags | 2
+        else:
+            pk = grad = buf("grad", (B, p))
         status = buf("status", (B,), torch.int32)
         dxdp = buf("dxdp", (B, T + 1, n, p)) if want_sens else None
         dudp = buf("dudp", (B, T, m, p)) if want_sens else None
         nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
         ws = buf("ws", (max(nbytes, 8) // 8,))
         rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
-                                              ptr(grad), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+                                              ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
         check(rc, "pdp_oc_pdp_grad_batched")
         out = dict(loss=loss, grad=grad, x=x, lam=lam, status=status)
+        if packed:
+            out["packed"] = pk
         if want_sens:
             out.update(dxdp=dxdp, dudp=dudp)
         return out

@@ -86,6 +86,53 @@ def test_C4_rocket_planning_T100_batch512():
         assert np.abs(fd - grad[:4, k]).max() <= 1e-6 * np.abs(grad[:4, k]).max()
 
 
+def test_C4_rocket_fused_oc_unit_T100_p10_batch512():
+    """C4's OC unit on one GPU's shard: rocket n=13 m=3 p=10, T=100, B=512 through the fused kernel (rollout -> costates -> aux system in
+    LDS -> Riccati -> gradient) at the full horizon.  Inputs: the optimal controls of 512 landing problems (solved on the GPU at T=100),
+    perturbed by 2 %, at per-sample parameters perturbed by 5 %.  Four samples are compared with the oracle (trajectory, costates, and the
+    sensitivities / loss / gradient against the 40-digit evaluation of the reference formulas on the kernel's own trajectory);
+    all samples: clean status, results independent of the batch they are in."""
+    from oracle import pdp_oracle as po
+    from test_gpu_models import oracle_oc, rel, TOL
+    from pdp_amd import zoo
+    mdl = zoo.get("rocket", "irl")
+    oc = oracle_oc("rocket")
+    rng = np.random.default_rng(4)
+    B, T = 512, 100
+    th_star = np.array([0.5, 1, 1, 1, 1, 1, 1, 50, 1, 1.0])
+    x0 = np.zeros((B, 13))
+    x0[:, 0:3] = np.array([10, -8, 5.0]) + 0.5 * rng.standard_normal((B, 3))
+    x0[:, 3] = -0.5
+    ang = 0.5 + 0.1 * rng.standard_normal(B)
+    x0[:, 6], x0[:, 8], x0[:, 9] = np.cos(ang / 2), np.sin(ang / 2) / np.sqrt(2), -np.sin(ang / 2) / np.sqrt(2)
+    sol = mdl.oc_solve_ms(x0, th_star, T)
+    good = npy(sol["converged"])
+    assert good.sum() >= 0.9 * B
+    demo_x, demo_u = npy(sol["state"]), npy(sol["control"])
+    u = demo_u * (1 + 0.02 * rng.standard_normal(demo_u.shape))
+    theta = th_star[None, :] * (1 + 0.05 * rng.standard_normal((B, 10)))
+    out = mdl.oc_pdp_grad(u, theta, demo_x, demo_u, x0=x0, want_sens=True)
+    st = npy(out["status"])
+    assert int(st[good].sum()) == 0 and np.all(np.isfinite(npy(out["grad"])[good]))
+    xg, lg = npy(out["x"]), npy(out["lam"])
+    for i in np.nonzero(good)[0][[0, 1, 100, 400]]:
+        xs = oc.rollout(x0[i], u[i], theta[i])
+        assert rel(xg[i], xs) < 1e-9                      # T = 100 of unstable open-loop dynamics: 1-ulp differences of the products grow
+        assert rel(lg[i], oc.costate(xg[i], u[i], theta[i])) < TOL
+        aux = oc.getAuxSys(xg[i], u[i], lg[i], theta[i])
+        ref64 = po.lqr_from_aux(aux, oc.n, oc.p, T)
+        ex = po.lqr_solver_mp(aux["dynF"], aux["dynG"], aux["dynE"], aux["Hxx"], aux["Huu"], aux["Hxu"], aux["Hxe"], aux["Hue"],
+                              aux["hxx"], aux["hxe"], np.zeros((oc.n, oc.p)), T)
+        Xe, Ue = np.stack(ex["state_traj_opt"]), np.stack(ex["control_traj_opt"])
+        tol_i = max(TOL, 2 * rel(np.stack(ref64["state_traj_opt"]), Xe))
+        assert rel(npy(out["dxdp"])[i], Xe) < tol_i and rel(npy(out["dudp"])[i], Ue) < tol_i
+        l, g = po.irl_loss_grad(xg[i], u[i], demo_x[i], demo_u[i], list(Xe), list(Ue))
+        assert abs(npy(out["loss"])[i] - l) <= 1e-12 * l and rel(npy(out["grad"])[i], g) < tol_i
+    sub = slice(200, 203)
+    o2 = mdl.oc_pdp_grad(u[sub], theta[sub], demo_x[sub], demo_u[sub], x0=x0[sub])
+    assert np.array_equal(npy(o2["grad"]), npy(out["grad"])[sub]) and np.array_equal(npy(o2["loss"]), npy(out["loss"])[sub])
+
+
 def test_C5_quadrotor_sysid_T100_batch1024():
     """C5a per-GPU shard: quadrotor SysID T=100 p=5, 1024 trajectories generated at theta* with inputs U(-10,10):
     loss = 0 and gradient = 0 at theta*; away from it the (half-)gradient matches finite differences."""

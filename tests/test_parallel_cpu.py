@@ -38,6 +38,17 @@ def _worker(rank, world, port, n_total, q):
     L, G = parallel.gather_loss_grad(out["loss"], out["grad"], n_total)
     Lm, Gm = parallel.pdp_iteration(_fake_unit, dict(x=xs, theta=theta), n_total)
     L2, G2 = parallel.gather_loss_grad(out["loss"], out["grad"])        # sizes exchanged instead of given
+    # the packed [b, p+1] rows the fused kernel writes with PDP_OC_PACKED: one collective, no packing copies (ragged: padded route)
+    pk = torch.cat([out["grad"], out["loss"][:, None]], dim=1)
+    rows = parallel.gather_packed(pk, n_total)
+    assert torch.equal(rows[:, :3], G) and torch.equal(rows[:, 3], L)
+    if n_total % world == 0:            # the overlapped, double-buffered exchange of bench.py (on CPU tensors: blocking)
+        og = parallel.OverlappedGather(pk.shape[0], pk.shape[1], device="cpu")
+        for k in range(3):
+            og.next_buffer().copy_(pk * (k + 1))
+            i = og.submit()
+            assert torch.equal(og.result(i), rows * (k + 1))
+        og.drain()
     q.put((rank, L.numpy(), G.numpy(), float(Lm), Gm.numpy(), L2.numpy(), tuple(xs.shape)))
     dist.destroy_process_group()
 
