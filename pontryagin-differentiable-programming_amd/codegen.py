@@ -69,8 +69,11 @@ class Problem:
 
 
 class _Group:
-    def __init__(self, gname, mats):
-        """mats: list of (name, rows, cols, SX).  Builds codes / pools."""
+    def __init__(self, gname, mats, dedup=False):
+        """mats: list of (name, rows, cols, SX).  Builds codes / pools.
+        dedup: entries that are the SAME expression (the two halves of a symmetric Hessian, repeated Jacobian entries) share one
+        variable slot - less arithmetic-free LDS traffic and a shorter pool row (quadrotor: 193 -> 120 entries per step).  Only for
+        groups consumed through their codes (the OC kernels); the dense scatter of the CP / SysID kernels maps slot -> one element."""
         self.gname = gname
         self.names = [m[0] for m in mats]
         self.rows = [m[1] for m in mats]
@@ -80,6 +83,7 @@ class _Group:
         self.var_mat, self.var_off = [], []
         self.consts = []         # c -> value
         cidx = {}
+        slot = {}
         for mi, (name, r, c, M) in enumerate(mats):
             M = sx._lift(M)
             assert M.shape == (r, c), "%s: shape %s, expected %s" % (name, M.shape, (r, c))
@@ -95,7 +99,10 @@ class _Group:
                                 cidx[nd.val] = len(self.consts)
                                 self.consts.append(nd.val)
                             codes.append(-2 - cidx[nd.val])
+                    elif dedup and nd.id in slot:
+                        codes.append(slot[nd.id])
                     else:
+                        slot[nd.id] = len(self.var_nodes)
                         codes.append(len(self.var_nodes))
                         self.var_nodes.append(nd)
                         self.var_mat.append(mi)
@@ -289,19 +296,19 @@ def generate(problem):
         mats = {k: R(v) for k, v in mats.items()}
         dims = {"F": (n, n), "G": (n, m), "E": (n, p), "Hxx": (n, n), "Hxu": (n, m), "Hxe": (n, p), "Huu": (m, m), "Hue": (m, p),
                 "hxx": (n, n), "hxe": (n, p)}
-        groups["path"] = _Group("path", [(k,) + dims[k] + (mats[k],) for k in OC_PATH])
+        groups["path"] = _Group("path", [(k,) + dims[k] + (mats[k],) for k in OC_PATH], dedup=True)
         # the fused kernel evaluates the path matrices in two stages per chunk: lambda-independent (patha: F, G, E, c_x) first,
         # then - once the costates of the chunk have been propagated with F and c_x - the lambda-weighted Hessians (pathb)
         mats["cx"] = R(sx.jacobian(c, x).T)
         dims["cx"] = (n, 1)
-        groups["patha"] = _Group("patha", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "E", "cx")])
-        groups["pathb"] = _Group("pathb", [(k,) + dims[k] + (mats[k],) for k in ("Hxx", "Hxu", "Hxe", "Huu", "Hue")])
-        groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD])
-        groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN])
+        groups["patha"] = _Group("patha", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "E", "cx")], dedup=True)
+        groups["pathb"] = _Group("pathb", [(k,) + dims[k] + (mats[k],) for k in ("Hxx", "Hxu", "Hxe", "Huu", "Hue")], dedup=True)
+        groups["fwd"] = _Group("fwd", [(k,) + dims[k] + (mats[k],) for k in OC_FWD], dedup=True)
+        groups["fin"] = _Group("fin", [(k,) + dims[k] + (mats[k],) for k in OC_FIN], dedup=True)
         # the multiple-shooting OC solver (oc_solve_ms_kernel) knows (x, u, lambda) of every stage before its sweep: one group with
         # the matrices of the KKT system for the backward pass, F and G alone for the forward pass
-        groups["sol"] = _Group("sol", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "Hxx", "Hxu", "Huu")])
-        groups["solf"] = _Group("solf", [(k,) + dims[k] + (mats[k],) for k in ("F", "G")])
+        groups["sol"] = _Group("sol", [(k,) + dims[k] + (mats[k],) for k in ("F", "G", "Hxx", "Hxu", "Huu")], dedup=True)
+        groups["solf"] = _Group("solf", [(k,) + dims[k] + (mats[k],) for k in ("F", "G")], dedup=True)
         chunk = None                                          # needs the number of hoisted values: decided below
     elif pb.kind == KIND_CP:
         c, h = pb.path_cost, pb.final_cost

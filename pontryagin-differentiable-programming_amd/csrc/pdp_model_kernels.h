@@ -708,16 +708,26 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The last step
             // of a chunk prefetches nothing (no LDS read outside the pool).  Two steps per trip with the prefetched tiles alternating
             // between two register sets (no copies at the back edge).
+#ifndef PDP_FUSED_NO_PREFETCH
             d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
+#else
+            d4 Fa = z, Ya = z, Fb = z, Yb = z;
+#endif
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
                 d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
+#ifndef PDP_FUSED_NO_PREFETCH
                 if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }
+                const d4 Fu = Fc, Yu = Yc;
+#else       // two waves per SIMD hide the gather latency behind each other: no one-step-ahead copies of F and [G|E] (16 registers)
+                const d4 Fu = gather_run(rF, -1), Yu = gather_run(rY, -1);
+                (void)Fc; (void)Yc; (void)Fn; (void)Yn;
+#endif
                 RiccatiGains g;
                 d4 P_old;
                 PDP_FINE(1, t == 20);
-                ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
+                ok = riccati_backward<M, false>(P, W2, Fu, Yu, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);

@@ -267,8 +267,10 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1; });
         make_gather(gE, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
         d4 X2 = z;
+        // gains and P_{t+1}, W_{t+1} of step t are requested one step ahead (each lane re-reads what it stored in the backward sweep)
         d4 KTn = -load_all<4>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
+        d4 Pq = load_all<4>(pw, mP), Wq = load_all<4>(pw + NX * NX, mW);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;
         for (int c = 0; c < nchunk; ++c) {
@@ -288,25 +290,26 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             }
             wave_lds_sync();
             GatherRun rFT = gather_at(gFT, 0, blk), rGT = gather_at(gGT, 0, blk), rE = gather_at(gE, 0, blk);
-            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
+            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, const d4 Pc, const d4 Wc, d4& KTnx, d4& knx, d4& Pnx, d4& Wnx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
                 knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                const d4 Pn = load_all<4>(pw + t * PWSZ, mP), Wn = load_all<4>(pw + t * PWSZ + NX * NX, mW);
+                Pnx = load_all<4>(pw + tnx * PWSZ, mP);
+                Wnx = load_all<4>(pw + tnx * PWSZ + NX * NX, mW);
                 d4 FT = gather_run(rFT, 1);
                 d4 GT = gather_run<1>(rGT, 1);
                 d4 E2 = gather_run(rE, 1);
                 d4 U2;
                 riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
-                const d4 Lm = mma_tn(Pn, Xn, Wn);                    // dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (P symmetric)
+                const d4 Lm = mma_tn(Pc, Xn, Wc);                    // dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (P symmetric)
                 store_tile_column(dub + t * NU, U2, NU, M, lane);
                 store_tile_column(dxb + (t + 1) * NX, Xn, NX, M, lane);
                 store_tile_column(dlb + t * NX, Lm, NX, M, lane);
             };
-            d4 Xb, KTb, kb;
+            d4 Xb, KTb, kb, Pb, Wb;
             int tl = 0;
-            for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); fstep(tl + 1, Xb, X2, KTb, kb, KTn, kn); }
-            if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; }
+            for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, Pq, Wq, KTb, kb, Pb, Wb); fstep(tl + 1, Xb, X2, KTb, kb, Pb, Wb, KTn, kn, Pq, Wq); }
+            if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, Pq, Wq, KTb, kb, Pb, Wb); X2 = Xb; KTn = KTb; kn = kb; Pq = Pb; Wq = Wb; }
         }
         __threadfence_block();
         wave_lds_sync();

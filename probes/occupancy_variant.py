@@ -1,13 +1,13 @@
 """Occupancy experiment on the headline kernel: build variants of the quadrotor OC library that fit TWO waves per
-SIMD (LDS pool of PDP_FUSED_CHUNK steps <= 20 KB per wave, amdgpu_waves_per_eu(2): 256 registers per wave) and time B = 1024 / 2048 /
+SIMD (LDS pool of PDP_FUSED_CHUNK = 14 steps: 20 KB per wave, amdgpu_waves_per_eu(2): 256 registers per wave) and time B = 1024 / 2048 /
 4096 against the shipped one-wave-per-SIMD build.  `build` (run where hipcc is: here or on the GPU box) writes probes/variants/*.so,
 `run` times them."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdp_amd import codegen, zoo
-VARIANTS = {"base": [], "chunk9": ["-DPDP_FUSED_CHUNK=9"], "chunk9_w2": ["-DPDP_FUSED_CHUNK=9", "-DPDP_FUSED_WAVES=2"],
-            "chunk13": ["-DPDP_FUSED_CHUNK=13"], "chunk9_w2_agpr": ["-DPDP_FUSED_CHUNK=9", "-DPDP_FUSED_WAVES=2", "-mllvm", "-amdgpu-mfma-vgpr-form=0"]}
+VARIANTS = {"base": [], "chunk14": ["-DPDP_FUSED_CHUNK=14"], "chunk14_w2": ["-DPDP_FUSED_CHUNK=14", "-DPDP_FUSED_WAVES=2"],
+            "chunk14_w2_nopf": ["-DPDP_FUSED_CHUNK=14", "-DPDP_FUSED_WAVES=2", "-DPDP_FUSED_NO_PREFETCH"], "chunk25": ["-DPDP_FUSED_CHUNK=25"]}
 OUT = os.path.join(ROOT, "probes", "variants")
 
 

@@ -206,7 +206,17 @@ def warp_recmat_cases():
     # (system, dt, T, x0, time_grid, modes): kept to what the sympy stand-in composes in about a minute; the recovery matrix of
     # the cart-pole (a whole-horizon symbolic expression, PDP.py:1039-1079) does not finish in an hour there
     specs = [("pendulum", 0.05, 20, [0.0, 0.0], None, ("warp", "recmat")), ("cartpole", 0.05, 25, [0.0, 0.0, 0.0, 0.0], None, ("warp",))]
+    # the systems whose drivers actually use the recovery matrix (Examples/OC/rocket/rocket_PDP_Recmat.py:47-64 and
+    # Examples/OC/quadrotor/uav_PDP_Recmat.py: recmat_init_step(horizon, -1), one cell per time step, initial states of those scripts),
+    # at the horizon the sympy stand-in can still compose symbolically
+    qx0 = [-8.0, -6.0, 9.0, 0.0, 0.0, 0.0] + list(JinEnv.toQuaternion(0, [1, -1, 1])) + [0.0, 0.0, 0.0]
+    rx0 = [10.0, -8.0, 5.0, -0.1, 0.0, 0.0] + list(JinEnv.toQuaternion(1.5, [0, 0, 1])) + [0.0, 0.0, 0.0]
+    hz = int(os.environ.get("PDP_RECMAT_T", "4"))
+    specs += [("rocket", 0.1, hz, rx0, -1, ("recmat",)), ("quadrotor", 0.1, hz, qx0, -1, ("recmat",))]
+    only = os.environ.get("PDP_WARP_ONLY")
     for k, (name, dt, T, x0, grid, modes) in enumerate(specs):
+        if only and name not in only.split(","):
+            continue
         env = make_env(name, "oc")
         for mode in modes:
             cp = PDP.ControlPlanning()

@@ -203,6 +203,65 @@ def test_user_defined_model_is_generated_and_compiled_on_the_fly():
     assert loss > 0 and abs(2 * d[0] - (lp - lm) / (2 * eps)) < 1e-6 * abs(2 * d[0])       # step returns half the gradient (PDP.py:1285-1290)
 
 
+def test_dense_numeric_linear_model_with_more_than_64_constants():
+    """A user model whose Jacobians are all NUMERIC constants (x+ = x + dt (A x + B u), A 10x10 dense): the 120 distinct constants of
+    F = I + dt A and G = dt B live in the kernels' LDS constant pools, which used to be filled by one lane-indexed pass (64 entries).
+    OCSys: aux matrices and the fused gradient against numpy; ControlPlanning: gradient against finite differences."""
+    from oracle import pdp_oracle as po
+    from pdp_amd import PDP
+    from pdp_amd.sx import SX, vertcat, mtimes, dot
+    rng = np.random.default_rng(11)
+    n, m, dt, T, B = 10, 2, 0.05, 12, 5
+    A = rng.standard_normal((n, n)) - 1.5 * np.eye(n)
+    Bm = rng.standard_normal((n, m))
+    X, U, w = SX.sym("x", n), SX.sym("u", m), SX.sym("w", 2)
+    f = X + dt * (mtimes(SX(A), X) + mtimes(SX(Bm), U))
+    oc = PDP.OCSys("dense linear")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(X)
+    oc.setControlVariable(U)
+    oc.setDyn(f)
+    oc.setPathCost(w[0] * dot(X, X) + w[1] * dot(U, U))
+    oc.setFinalCost(w[0] * dot(X, X))
+    th = np.array([0.7, 0.3])
+    x0 = rng.standard_normal((B, n))
+    u = 0.5 * rng.standard_normal((B, T, m))
+    xs, _ = oc.rollout_batch(x0, u, th)
+    lam = oc.costate_batch(xs, u, th)
+    aux = oc.getAuxSys_batch(xs, u, lam, th)
+    F, G = np.eye(n) + dt * A, dt * Bm
+    xn = npy(xs)
+    assert np.abs(npy(aux["dynF"]) - F).max() <= 1e-15 and np.abs(npy(aux["dynG"]) - G).max() <= 1e-15 and float(aux["dynE"].abs().max()) == 0.0
+    assert np.abs(xn[:, 1] - (x0 @ F.T + u[:, 0] @ G.T)).max() <= 1e-14
+    demo_x, demo_u = xn + 0.1 * rng.standard_normal(xn.shape), u + 0.1 * rng.standard_normal(u.shape)
+    out = oc.pdp_grad_batch(u, th, demo_x, demo_u, ini_state=x0, want_sens=True)
+    assert int(out["status"].sum()) == 0
+    for i in range(B):
+        a = {k: [np.asarray(v) for v in npy(aux[k])[i]] for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue")}
+        a["hxx"], a["hxe"] = [npy(aux["hxx"])[i]], [npy(aux["hxe"])[i]]
+        assert np.abs(a["Hxx"][3] - 2 * th[0] * np.eye(n)).max() <= 1e-15 and np.abs(a["Hue"][3] - np.stack([0 * u[i, 3], 2 * u[i, 3]], axis=1)).max() <= 1e-15
+        ref = po.lqr_from_aux(a, n, 2, T)
+        assert rel(npy(out["dxdp"])[i], np.stack(ref["state_traj_opt"])) < 1e-10
+        l, g = po.irl_loss_grad(xn[i], u[i], demo_x[i], demo_u[i], ref["state_traj_opt"], ref["control_traj_opt"])
+        assert abs(npy(out["loss"])[i] - l) <= 1e-12 * l and rel(npy(out["grad"])[i], g) < 1e-10
+    cp = PDP.ControlPlanning("dense linear cp")
+    cp.setStateVariable(X)
+    cp.setControlVariable(U)
+    cp.setDyn(f)
+    cp.setPathCost(0.7 * dot(X, X) + 0.3 * dot(U, U))
+    cp.setFinalCost(0.7 * dot(X, X))
+    cp.init_step(T, n_poly=3)
+    thp = 0.3 * rng.standard_normal(cp.n_auxvar)
+    loss, grad = cp.step(x0[0], T, thp)
+    eps = 1e-6
+    for k in (0, cp.n_auxvar - 1):
+        tp, tm = thp.copy(), thp.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        fd = (cp.step(x0[0], T, tp)[0] - cp.step(x0[0], T, tm)[0]) / (2 * eps)
+        assert abs(fd - grad[k]) <= 1e-6 * max(1.0, abs(fd))
+
+
 @pytest.mark.parametrize("fixture", ["ref_warp_pendulum_0", "ref_recmat_pendulum_0", "ref_warp_cartpole_1"])
 def test_warp_and_recmat_variants_match_reference_run(golden_dir, fixture):
     """ControlPlanning.warp_step / recmat_step / *_unwarp (PDP.py:882-1141): the reference composes the dynamics symbolically over
