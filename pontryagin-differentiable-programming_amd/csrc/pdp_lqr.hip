@@ -161,6 +161,17 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
     double* wg = (double*)workspace;
     double* wpw = Lam ? wg + (int64_t)pr.B * pr.T * (pr.n * pr.m + pr.m * pr.p) : nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (pr.n <= 4 && pr.m + pr.p <= 16) {          // small systems: four trajectories per wavefront, block-diagonal in the tile
+        const dim3 grid((pr.B + 3) / 4), block(64);
+        PDP_CLEAR();
+        switch (pr.m) {
+            case 1: hipLaunchKernelGGL((lqr_solve_small_kernel<1>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+            case 2: hipLaunchKernelGGL((lqr_solve_small_kernel<2>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+            case 3: hipLaunchKernelGGL((lqr_solve_small_kernel<3>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+            default: hipLaunchKernelGGL((lqr_solve_small_kernel<4>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+        }
+        return launched();
+    }
     switch (pr.m) {
         case 1: return launch_lqr<1>(pr, nt, X, U, Lam, status, wg, wpw, s);
         case 2: return launch_lqr<2>(pr, nt, X, U, Lam, status, wg, wpw, s);

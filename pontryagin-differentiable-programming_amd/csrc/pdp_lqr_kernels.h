@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/pdp_hip.h"
 #include "pdp_riccati.h"
+#include "pdp_riccati_small.h"
 
 namespace pdp {
 
@@ -179,5 +180,144 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     if (lane == 0 && status) status[b] = st;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Small systems (n <= 4, m + p <= 16): FOUR trajectories per wavefront, block-diagonal in the tile (pdp_riccati_small.h).  Same inputs,
+// outputs and workspace layout as lqr_solve_kernel.  A lane addresses ITS element of every operand by one 32-bit offset that is the
+// same for the four trajectories (their bases differ by the batch stride: scalar registers); absent elements are zeros.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct SmallOp { int offA, offB; };      // element offset in the first / second source matrix, -1 = absent
+PDP_DEV double small_load(const double* __restrict__ A, const double* __restrict__ Bm, const SmallOp& o) {
+    double v = 0.0;
+    if (o.offA >= 0 && A) v = A[o.offA];
+    else if (o.offB >= 0 && Bm) v = Bm[o.offB];
+    return v;
+}
+
+template <int M>
+__global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
+                                                              double* __restrict__ Lo, int32_t* __restrict__ status,
+                                                              double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
+    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15, ci = col & 3;
+    const int n = pr.n, p = pr.p, T = pr.T, B = pr.B;
+    const int tlane = small_transpose_lane(lane);
+    const int gsz = n * M + M * p, pwsz = n * n + n * p;
+    int br[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) br[r] = min(4 * (int)blockIdx.x + r, B - 1);      // the last wave may repeat the last trajectory (stores are guarded)
+    const bool pc = col >= M && col < M + p;                // a parameter column of the tile
+    // per-lane operand offsets (loop invariant)
+    const SmallOp oRep = {(row < n && ci < n) ? row * n + ci : -1, -1};                             // n x n, rep form
+    const SmallOp oRepT = {(row < n && ci < n) ? ci * n + row : -1, -1};                            // its transpose, rep form
+    const SmallOp oY = {(row < n && col < M) ? row * M + col : -1, (row < n && pc) ? row * p + (col - M) : -1};     // [G | E], [Hxu | Hxe]
+    const SmallOp oU = {(row < M && col < M) ? row * M + col : -1, (row < M && pc) ? row * p + (col - M) : -1};     // [Huu | Hue]
+    const SmallOp oGr = {(row < n && ci < M) ? row * M + ci : -1, -1};                              // G rep
+    const SmallOp oGT = {(row < M && ci < n) ? ci * M + row : -1, -1};                              // G' rep  (also Hxu' rep = Hux rep)
+    const SmallOp oNP = {-1, (row < n && pc) ? row * p + (col - M) : -1};                           // n x p block behind the control columns
+    const SmallOp oMP = {-1, (row < M && pc) ? row * p + (col - M) : -1};
+    const SmallOp oKT = {(row < n && ci < M) ? row * M + ci : -1, -1};                              // stored K' [n][m] -> lane (k, 4b+i) = K[i][k]
+    bool ok[4] = {true, true, true, true}, finite[4] = {true, true, true, true};
+    d4 P, W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        P[r] = small_load(mat_at(pr.hxx, br[r], 0), nullptr, oRep);
+        W[r] = small_load(nullptr, mat_at(pr.hxe, br[r], 0), oNP);
+    }
+    struct Bwd { d4 F, Y, Gr, Hxx, HX, HU, Hux; };
+    auto load_bwd = [&](int t, Bwd& w) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double *F = mat_at(pr.F, br[r], t), *G = mat_at(pr.G, br[r], t), *E = mat_at(pr.E, br[r], t), *Hxx = mat_at(pr.Hxx, br[r], t),
+                         *Hxu = mat_at(pr.Hxu, br[r], t), *Hxe = mat_at(pr.Hxe, br[r], t), *Huu = mat_at(pr.Huu, br[r], t), *Hue = mat_at(pr.Hue, br[r], t);
+            w.F[r] = small_load(F, nullptr, oRep); w.Y[r] = small_load(G, E, oY); w.Gr[r] = small_load(G, nullptr, oGr);
+            w.Hxx[r] = small_load(Hxx, nullptr, oRep); w.HX[r] = small_load(Hxu, Hxe, oY); w.HU[r] = small_load(Huu, Hue, oU);
+            w.Hux[r] = small_load(Hxu, nullptr, oGT);
+        }
+    };
+    auto bstep = [&](int t, const Bwd& c, Bwd& nx) {
+        if (t > 0) load_bwd(t - 1, nx);                 // the operands of step t-1 are requested before step t computes
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool mine = 4 * (int)blockIdx.x + r < B;
+            if (ws_pw && mine) {                        // P_{t+1}, W_{t+1} for the costate output (PDP.py:604)
+                double* pw = ws_pw + ((int64_t)br[r] * T + t) * pwsz;
+                if (oRep.offA >= 0 && col < 4) pw[oRep.offA] = P[r];
+                if (oNP.offB >= 0) pw[n * n + oNP.offB] = W[r];
+            }
+            SmallGains g;
+            double Pr = P[r], Wr = W[r];
+            ok[r] = riccati_small_backward<M>(Pr, Wr, c.F[r], c.Y[r], c.Gr[r], c.Hxx[r], c.HX[r], c.HU[r], c.Hux[r], lane, tlane, p, g) && ok[r];
+            P[r] = Pr; W[r] = Wr;
+            if (mine) {
+                double* gw = ws_gain + ((int64_t)br[r] * T + t) * gsz;
+                if (row < M && col < n) gw[col * M + row] = g.K;                    // K' [n][m]
+                if (oMP.offB >= 0) gw[n * M + oMP.offB] = g.IK;                     // k [m][p]
+            }
+            finite[r] = finite[r] && fabs(P[r]) <= 1.7e308 && fabs(W[r]) <= 1.7e308;
+        }
+    };
+    {
+        Bwd ta, tb;
+        load_bwd(T - 1, ta);
+        int t = T - 1;
+        for (; t >= 1; t -= 2) { bstep(t, ta, tb); bstep(t - 1, tb, ta); }
+        if (t == 0) bstep(0, ta, tb);
+    }
+    // ---- forward rollout (PDP.py:582-608)
+    d4 X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        X[r] = small_load(nullptr, mat_at(pr.X0, br[r], 0), oNP);
+        if (4 * (int)blockIdx.x + r < B && oNP.offB >= 0) Xo[(int64_t)br[r] * (T + 1) * n * p + oNP.offB] = X[r];
+    }
+    __threadfence_block();
+    struct Fwd { d4 FT, GT, KT, k, E, Pt, Wt; };
+    auto load_fwd = [&](int t, Fwd& w) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* gw = ws_gain + ((int64_t)br[r] * T + t) * gsz;
+            const double* pw = (ws_pw && Lo) ? ws_pw + ((int64_t)br[r] * T + t) * pwsz : nullptr;
+            w.FT[r] = small_load(mat_at(pr.F, br[r], t), nullptr, oRepT);
+            w.GT[r] = small_load(mat_at(pr.G, br[r], t), nullptr, oGT);
+            w.KT[r] = small_load(gw, nullptr, oKT);
+            w.k[r] = small_load(nullptr, gw + n * M, oMP);
+            w.E[r] = small_load(nullptr, mat_at(pr.E, br[r], t), oNP);
+            w.Pt[r] = small_load(pw, nullptr, oRep);
+            w.Wt[r] = small_load(nullptr, pw ? pw + n * n : nullptr, oNP);
+        }
+    };
+    auto fstep = [&](int t, const Fwd& c, Fwd& nx) {
+        if (t + 1 < T) load_fwd(t + 1, nx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double U, Xn;
+            riccati_small_forward(-c.KT[r], -c.k[r], c.FT[r], c.GT[r], c.E[r], X[r], U, Xn);
+            X[r] = Xn;
+            const bool mine = 4 * (int)blockIdx.x + r < B;
+            if (mine) {
+                if (oMP.offB >= 0) Uo[((int64_t)br[r] * T + t) * M * p + oMP.offB] = U;
+                if (oNP.offB >= 0) Xo[((int64_t)br[r] * (T + 1) + t + 1) * n * p + oNP.offB] = Xn;
+                if (Lo) {
+                    const double L = mma4_blk(c.Pt[r], Xn, c.Wt[r]);           // lambda_{t+1} = P x_{t+1} + W   (P symmetric)
+                    if (oNP.offB >= 0) Lo[((int64_t)br[r] * T + t) * n * p + oNP.offB] = L;
+                }
+            }
+            finite[r] = finite[r] && fabs(Xn) <= 1.7e308;
+        }
+    };
+    {
+        Fwd ta, tb;
+        load_fwd(0, ta);
+        int t = 0;
+        for (; t + 1 < T; t += 2) { fstep(t, ta, tb); fstep(t + 1, tb, ta); }
+        if (t < T) fstep(t, ta, tb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int st = 0;
+        if (!__all(finite[r])) st |= PDP_STATUS_NONFINITE;
+        if (!ok[r]) st |= PDP_STATUS_PIVOT;
+        if (lane == 0 && status && 4 * (int)blockIdx.x + r < B) status[br[r]] = st;
+    }
+}
 
 }  // namespace pdp

@@ -136,7 +136,12 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
         pr.F = {w.F, (int64_t)T * n * n, n * n}; pr.G = {w.G, (int64_t)T * n * m, n * m}; pr.Hxx = {w.Hxx, (int64_t)T * n * n, n * n};
         pr.Hxu = {w.Hxu, (int64_t)T * n * m, n * m}; pr.Huu = {w.Huu, (int64_t)T * m * m, m * m}; pr.Hue = {w.dHu, (int64_t)T * m, m};
         pr.hxx = {w.hxx, n * n, 0}; pr.hxe = {w.hxe0, n, 0};
-        auto lq = [&]() { hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr); };
+        auto lq = [&]() {
+            if constexpr (n <= 4)       // small systems: four trajectories per wavefront (pdp_riccati_small.h)
+                hipLaunchKernelGGL((lqr_solve_small_kernel<m>), dim3((B + 3) / 4), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
+            else
+                hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
+        };
         pdp_oc_auxsys only_hu{}, hess{};
         only_hu.dHu = w.dHu;
         hess.dynF = w.F; hess.dynG = w.G; hess.Hxx = w.Hxx; hess.Hxu = w.Hxu; hess.Huu = w.Huu; hess.hxx = w.hxx; hess.Huu_damp = w.st.mu;

@@ -163,6 +163,18 @@ def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0
         mat, t = _mat(val, B, tv)
         setattr(pr, name, mat)
         keep.append(t)
+    pmax = 64 - m                      # parameter columns one launch of the kernel carries (4 tiles of 16, the first shared with the controls)
+    if p > pmax:
+        # more columns than the kernel's tiles hold (a neural policy's auxvar, a wide X0): the columns of (E, Hxe, Hue, hxe, X0) -> (X, U, Lam)
+        # are independent given the gains, so the problem is solved in column blocks (each launch repeats the n x n backward recursion)
+        cut = lambda a, c0, c1: None if a is None else dev(a)[..., c0:c1].contiguous()
+        parts = [lqr_solve(F_t, G_t, Hxx, Huu, hxx, cut(hxe_t, c0, min(p, c0 + pmax)), E=cut(E, c0, min(p, c0 + pmax)), Hxu=Hxu, Hxe=cut(Hxe, c0, min(p, c0 + pmax)),
+                           Hue=cut(Hue, c0, min(p, c0 + pmax)), X0=cut(X0, c0, min(p, c0 + pmax)), T=T, want_costate=want_costate) for c0 in range(0, p, pmax)]
+        status = parts[0][3]
+        for q in parts[1:]:
+            status = status | q[3]
+        return (torch.cat([q[0] for q in parts], dim=-1), torch.cat([q[1] for q in parts], dim=-1),
+                torch.cat([q[2] for q in parts], dim=-1) if want_costate else None, status)
     X = torch.empty((B, T + 1, n, p), dtype=torch.float64, device="cuda")
     U = torch.empty((B, T, m, p), dtype=torch.float64, device="cuda")
     Lam = torch.empty((B, T, n, p), dtype=torch.float64, device="cuda") if want_costate else None
@@ -412,6 +424,32 @@ class ModelLib:
         ws = buf("ws", (max(nbytes, 8) // 8,))
         rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
                                               ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+        if rc == -2 and self.n <= 16 and self.m <= 4:
+            # m + p > 16: beyond the fused kernel's single parameter tile.  The reference's own route, kernel by kernel (PDP.py:272-314,
+            # 557-608 and the chain rule of cartpole_PDP.py:63-74): trajectory and costates, aux matrices to HBM, lqrSolver (column blocks
+            # for any p), contraction with (x - x_demo, u - u_demo)
+            if not (flags & 1):
+                x.copy_(self.oc_rollout(x0, u, theta, want_cost=False)[0])
+                lam.copy_(self.oc_costate(x, u, theta))
+            aux = self.oc_auxsys(x, u, lam, theta)
+            X, U, _, st = lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], aux["hxe"], E=aux["dynE"], Hxu=aux["Hxu"], Hxe=aux["Hxe"],
+                                    Hue=aux["Hue"], want_costate=False)
+            ex, eu = x - demo_x, u - demo_u
+            loss.copy_((ex ** 2).sum(dim=(1, 2)) + (eu ** 2).sum(dim=(1, 2)))
+            g = torch.empty((B, p), dtype=torch.float64, device="cuda")
+            core = load_core()
+            core.pdp_cp_grad_contract_batched.restype = C.c_int
+            core.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
+            check(core.pdp_cp_grad_contract_batched(B, T, n, m, p, ptr(ex[:, :T].contiguous()), ptr(eu.contiguous()), ptr(ex[:, T].contiguous()), ptr(X), ptr(U),
+                                                    ptr(g), current_stream_ptr()), "pdp_cp_grad_contract_batched")
+            grad.copy_(g)
+            if packed:
+                pk[:, p].copy_(loss)
+            status.copy_(st)
+            if want_sens:
+                dxdp.copy_(X)
+                dudp.copy_(U)
+            rc = 0
         check(rc, "pdp_oc_pdp_grad_batched")
         out = dict(loss=loss, grad=grad, x=x, lam=lam, status=status)
         if packed:

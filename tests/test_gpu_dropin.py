@@ -15,6 +15,10 @@ def rel(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
 def load(golden_dir, f):
     return np.load(os.path.join(golden_dir, f))
 

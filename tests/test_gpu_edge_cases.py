@@ -86,7 +86,8 @@ def test_nonfinite_input_raises_status_flag_only_for_that_sample():
 
 
 def test_lqr_maximum_sizes_and_limits():
-    """n = 16, m = 4, p = 60 (= 64 - m) is the largest problem of pdp_lqr_solve_batched; beyond it the C entry point returns PDP_E_SIZE"""
+    """n = 16, m = 4, p = 60 (= 64 - m) is the largest problem of ONE launch of pdp_lqr_solve_batched; more parameter columns are solved in
+    column blocks by the class surface; n > 16 / m > 4 return PDP_E_SIZE"""
     from oracle import pdp_oracle as po
     from pdp_amd import runtime as rt
     rng = np.random.default_rng(2)
@@ -104,8 +105,20 @@ def test_lqr_maximum_sizes_and_limits():
     Z = T * [np.zeros((n, m))]
     sol = po.lqr_solver(list(F[1]), list(G[1]), list(E[1]), list(Hxx[1]), list(Huu[1]), Z, list(Hxe[1]), list(Hue[1]), [hxx[1]], [hxe[1]], np.zeros((n, p)), T)
     assert rel(npy(X)[1], np.stack(sol["state_traj_opt"])) < TOL and rel(npy(Lam)[1], np.stack(sol["costate_traj_opt"])) < TOL
-    with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
-        rt.lqr_solve(F, G, Hxx, Huu, hxx, np.zeros((B, n, 61)), E=np.zeros((B, T, n, 61)))
+    # p beyond the 4 parameter tiles of one launch: the class surface solves it in column blocks (any p, like the reference, PDP.py:446-555)
+    p2 = 150
+    E2, Hxe2, Hue2, hxe2 = 0.1 * rng.standard_normal((B, T, n, p2)), 0.2 * rng.standard_normal((B, T, n, p2)), 0.2 * rng.standard_normal((B, T, m, p2)), 0.2 * rng.standard_normal((B, n, p2))
+    X0 = rng.standard_normal((B, n, p2))
+    X2, U2, L2, st2 = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe2, E=E2, Hxe=Hxe2, Hue=Hue2, X0=X0)
+    assert int(st2.sum()) == 0 and X2.shape == (B, T + 1, n, p2) and U2.shape == (B, T, m, p2)
+    sol2 = po.lqr_solver(list(F[0]), list(G[0]), list(E2[0]), list(Hxx[0]), list(Huu[0]), Z, list(Hxe2[0]), list(Hue2[0]), [hxx[0]], [hxe2[0]], X0[0], T)
+    assert rel(npy(X2)[0], np.stack(sol2["state_traj_opt"])) < TOL and rel(npy(U2)[0], np.stack(sol2["control_traj_opt"])) < TOL
+    assert rel(npy(L2)[0], np.stack(sol2["costate_traj_opt"])) < TOL
+    # the C entry point itself reports what one launch cannot hold
+    core = rt.load_core()
+    pr = rt.PdpLqrProblem()
+    pr.B, pr.T, pr.n, pr.m, pr.p = 1, 2, 4, 1, 64
+    assert core.pdp_lqr_solve_batched(__import__("ctypes").byref(pr), None, None, None, None, None, 0, None) in (-1, -2)
     with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
         rt.lqr_solve(np.zeros((1, 2, 17, 17)), np.zeros((1, 2, 17, 1)), np.zeros((1, 2, 17, 17)), np.ones((1, 2, 1, 1)), np.zeros((1, 17, 17)), np.zeros((1, 17, 1)))
 
@@ -171,3 +184,42 @@ def test_results_do_not_depend_on_stale_device_memory():
         again = c()
         for a, b in zip(again, ref):
             assert np.array_equal(a, b)
+
+
+def test_fused_unit_beyond_one_parameter_tile_takes_the_materialised_kernel_route():
+    """m + p > 16 (here m = 2, p = 16): the fused kernel holds the control and parameter columns in ONE tile and returns PDP_E_SIZE; the
+    class surface then runs the reference's own route kernel by kernel on the GPU (getAuxSys -> lqrSolver -> chain rule).  Checked against
+    the numpy oracle on the kernels' aux matrices."""
+    from oracle import pdp_oracle as po
+    from pdp_amd import PDP
+    from pdp_amd.sx import SX, mtimes, dot
+    rng = np.random.default_rng(12)
+    n, m, dt, T, B = 6, 2, 0.1, 9, 3
+    A, Bm = rng.standard_normal((n, n)) - np.eye(n), rng.standard_normal((n, m))
+    X, U, w = SX.sym("x", n), SX.sym("u", m), SX.sym("w", 16)
+    f = X + dt * (mtimes(SX(A), X) + mtimes(SX(Bm), U) + w[8:14] * X * X)              # 6 dynamics parameters
+    cost = sum(w[i] * X[i] * X[i] for i in range(n)) + w[6] * U[0] * U[0] + w[7] * U[1] * U[1] + w[14] * X[0] * U[0] + w[15] * X[1] * U[1]
+    oc = PDP.OCSys("wide auxvar")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(X)
+    oc.setControlVariable(U)
+    oc.setDyn(f)
+    oc.setPathCost(cost)
+    oc.setFinalCost(sum(w[i] * X[i] * X[i] for i in range(n)))
+    th = np.concatenate([1 + rng.random(8), 0.05 * rng.standard_normal(6), 0.1 * rng.standard_normal(2)])
+    x0, u = 0.5 * rng.standard_normal((B, n)), 0.3 * rng.standard_normal((B, T, m))
+    xs, _ = oc.rollout_batch(x0, u, th)
+    demo_x, demo_u = npy(xs) + 0.1 * rng.standard_normal(xs.shape), u + 0.1 * rng.standard_normal(u.shape)
+    out = oc.pdp_grad_batch(u, th, demo_x, demo_u, ini_state=x0, want_sens=True)
+    assert int(out["status"].sum()) == 0 and out["grad"].shape == (B, 16)
+    aux = oc.getAuxSys_batch(out["x"], u, out["lam"], th)
+    for i in range(B):
+        a = {k: [np.asarray(v) for v in npy(aux[k])[i]] for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue")}
+        a["hxx"], a["hxe"] = [npy(aux["hxx"])[i]], [npy(aux["hxe"])[i]]
+        ref = po.lqr_from_aux(a, n, 16, T)
+        assert rel(npy(out["dxdp"])[i], np.stack(ref["state_traj_opt"])) < TOL and rel(npy(out["dudp"])[i], np.stack(ref["control_traj_opt"])) < TOL
+        l, g = po.irl_loss_grad(npy(out["x"])[i], u[i], demo_x[i], demo_u[i], ref["state_traj_opt"], ref["control_traj_opt"])
+        assert abs(npy(out["loss"])[i] - l) <= 1e-12 * l and rel(npy(out["grad"])[i], g) < TOL
+    # and the gradient is the derivative of the loss through the trajectory only where theta enters the rollout: finite difference on a
+    # dynamics parameter with the controls fixed differs (the PDP gradient differentiates the OPTIMAL control problem), so only shapes / finiteness here
+    assert np.all(np.isfinite(npy(out["grad"])))

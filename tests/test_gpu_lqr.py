@@ -158,3 +158,52 @@ def test_lqr_every_kernel_instantiation(m, nt):
                             [hxx[b]], [hxe[b]], X0[b], T)
         assert _rel(X[b], np.stack(sol["state_traj_opt"])) < TOL and _rel(U[b], np.stack(sol["control_traj_opt"])) < TOL
         assert _rel(Lam[b], np.stack(sol["costate_traj_opt"])) < TOL
+
+
+@pytest.mark.parametrize("n,m,p,B", [(4, 1, 7, 9), (2, 1, 5, 4), (4, 2, 8, 6), (3, 3, 13, 5), (4, 4, 12, 7), (4, 1, 15, 2), (1, 1, 1, 1)])
+def test_lqr_small_systems_four_trajectories_per_wavefront(n, m, p, B):
+    """n <= 4, m + p <= 16: lqr_solve_small_kernel<M> packs four trajectories block-diagonally into one tile (pdp_riccati_small.h).
+    Every M, batches that do not fill the last wavefront, full / minimal parameter widths, on NaN-dirtied memory, against the numpy
+    restatement of PDP.py:557-608; then the optional-input and broadcast (time-invariant, shared-over-batch) forms."""
+    import torch
+    from oracle import pdp_oracle as po
+    from pdp_amd import runtime as rt
+    T = 11
+    rng = np.random.default_rng(1000 * n + 100 * m + p)
+    junk = [torch.full((int(s),), float("nan"), dtype=torch.float64, device="cuda") for s in (2e5, 7e5, 1e5)]
+    del junk
+
+    def spd(k, s):
+        A = rng.standard_normal((k, k))
+        return s * (A @ A.T / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.2 * rng.standard_normal((B, T, n, n))
+    G = 0.5 * rng.standard_normal((B, T, n, m))
+    E = 0.1 * rng.standard_normal((B, T, n, p))
+    Hxx = np.stack([np.stack([spd(n, 1.0) for _ in range(T)]) for _ in range(B)])
+    Huu = np.stack([np.stack([spd(m, 0.5) for _ in range(T)]) for _ in range(B)])
+    Hxu = 0.05 * rng.standard_normal((B, T, n, m))
+    Hxe, Hue = 0.2 * rng.standard_normal((B, T, n, p)), 0.2 * rng.standard_normal((B, T, m, p))
+    hxx = np.stack([spd(n, 1.0) for _ in range(B)])
+    hxe, X0 = 0.2 * rng.standard_normal((B, n, p)), rng.standard_normal((B, n, p))
+    X, U, Lam, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0)
+    assert int(st.sum()) == 0
+    X, U, Lam = _to_np(X), _to_np(U), _to_np(Lam)
+    for b in range(B):
+        sol = po.lqr_solver(list(F[b]), list(G[b]), list(E[b]), list(Hxx[b]), list(Huu[b]), list(Hxu[b]), list(Hxe[b]), list(Hue[b]),
+                            [hxx[b]], [hxe[b]], X0[b], T)
+        assert _rel(X[b], np.stack(sol["state_traj_opt"])) < TOL and _rel(U[b], np.stack(sol["control_traj_opt"])) < TOL
+        assert _rel(Lam[b], np.stack(sol["costate_traj_opt"])) < TOL
+    # without the costate output; optional families omitted; time-invariant matrices shared over the batch
+    X2, U2, L2, _ = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0, want_costate=False)
+    assert L2 is None and np.array_equal(_to_np(X2), X) and np.array_equal(_to_np(U2), U)
+    X3, U3, _, st3 = rt.lqr_solve(F[0, 0], G[0, 0], Hxx[0, 0], Huu[0, 0], hxx, hxe, T=T)
+    Z = lambda r, c: T * [np.zeros((r, c))]
+    for b in (0, B - 1):
+        sol = po.lqr_solver(T * [F[0, 0]], T * [G[0, 0]], Z(n, p), T * [Hxx[0, 0]], T * [Huu[0, 0]], Z(n, m), Z(n, p), Z(m, p), [hxx[b]], [hxe[b]], np.zeros((n, p)), T)
+        assert _rel(_to_np(X3)[b], np.stack(sol["state_traj_opt"])) < TOL and _rel(_to_np(U3)[b], np.stack(sol["control_traj_opt"])) < TOL
+    # a singular control block raises the pivot flag of that trajectory only
+    Gz, Huz = G.copy(), Huu.copy()
+    Gz[B - 1], Huz[B - 1] = 0.0, 0.0
+    _, _, _, st4 = rt.lqr_solve(F, Gz, Hxx, Huz, hxx, hxe, E=E, Hxe=Hxe, Hue=Hue)
+    st4 = _to_np(st4)
+    assert st4[B - 1] & 2 and (B == 1 or int(st4[:B - 1].sum()) == 0)
