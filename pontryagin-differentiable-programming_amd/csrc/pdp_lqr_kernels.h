@@ -70,17 +70,29 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     }
     // The matrices of step t-1 are requested from HBM before the Riccati step of t runs (one step = ~3k cycles of MFMA / VALU work,
     // an HBM round trip ~2k): two steps per trip, the operand tiles alternating between two register sets.
-    struct BwdTiles { d4 Ft, Y2, Grep, Hxx, HX2, HU2; };
+    struct BwdTiles { d4 Ft, Y2, Grep, Hxx, HX2, HU2, Hux; };
     const pdp_mat none = {nullptr, 0, 0};
     RunPtr rF = make_run(pr.F, mNN, none, mNN, b, T - 1), rY = make_run(pr.G, mNM, pr.E, mNP, b, T - 1), rHxx = make_run(pr.Hxx, mNN, none, mNN, b, T - 1),
            rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1),
            rGr = make_run(pr.G, mNMrep, none, mNN, b, T - 1);
+    // experiment hooks of probes/lqr_oob_probe.py (root cause of the round-1 out-of-bounds reads): PDP_LQR_STREAM_HUX streams
+    // Hxu' as a seventh operand instead of transposing HX2 through LDS; PDP_LQR_UNGUARDED restores the round-1 prefetch after the last step
+#ifdef PDP_LQR_STREAM_HUX
+    RunPtr rHux = make_run<1>(pr.Hxu, make_dense_map<true>(n, M, M, 0, 0, lane), none, mNN, b, T - 1);
+#endif
     auto load_bwd = [&](BwdTiles& w) {     // (issued for steps t-1 >= 0 only: bstep guards the request of the last step)
         w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Grep = load_run(rGr, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1);
         w.HU2 = load_run<1>(rHU, -1);
+#ifdef PDP_LQR_STREAM_HUX
+        w.Hux = load_run<1>(rHux, -1);
+#endif
     };
     auto bstep = [&](int t, const BwdTiles& c, BwdTiles& nx) {
+#ifdef PDP_LQR_UNGUARDED
+        load_bwd(nx);
+#else
         if (t > 0) load_bwd(nx);
+#endif
         if (ws_pw) {   // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
             double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
             store_map(pw, mNN, P);
@@ -90,7 +102,11 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
         }
         RiccatiGains g;
         d4 P_old;
+#ifdef PDP_LQR_STREAM_HUX
+        ok = riccati_backward<M, true, false>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, c.Hux[0], scratch, lane, p0, g, P_old) && ok;
+#else
         ok = riccati_backward<M, true, true>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, 0.0, scratch, lane, p0, g, P_old) && ok;
+#endif
         double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
         store_map(gw, mNM, g.KT);
         store_map<1>(gw + n * M, mMP, g.IK);
@@ -187,10 +203,9 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct SmallOp { int offA, offB; };      // element offset in the first / second source matrix, -1 = absent
 PDP_DEV double small_load(const double* __restrict__ A, const double* __restrict__ Bm, const SmallOp& o) {
-    double v = 0.0;
-    if (o.offA >= 0 && A) v = A[o.offA];
-    else if (o.offB >= 0 && Bm) v = Bm[o.offB];
-    return v;
+    // branch-free: absent elements read a zero word, so every load of a step is in flight before the first is waited for
+    const double* q = (o.offA >= 0 && A) ? A + o.offA : ((o.offB >= 0 && Bm) ? Bm + o.offB : (const double*)PDP_ZERO);
+    return *q;
 }
 
 template <int M>
@@ -233,26 +248,33 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
             w.Hux[r] = small_load(Hxu, nullptr, oGT);
         }
     };
+    bool mine[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[r] = 4 * (int)blockIdx.x + r < B;
     auto bstep = [&](int t, const Bwd& c, Bwd& nx) {
         if (t > 0) load_bwd(t - 1, nx);                 // the operands of step t-1 are requested before step t computes
+        if (ws_pw) {                                    // P_{t+1}, W_{t+1} for the costate output (PDP.py:604)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* pw = ws_pw + ((int64_t)br[r] * T + t) * pwsz;
+                if (mine[r] && oRep.offA >= 0 && col < 4) pw[oRep.offA] = P[r];
+                if (mine[r] && oNP.offB >= 0) pw[n * n + oNP.offB] = W[r];
+            }
+        }
+        // the four Riccati steps are straight-line code on separate registers: four independent MFMA chains the scheduler interleaves
+        SmallGains g[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool mine = 4 * (int)blockIdx.x + r < B;
-            if (ws_pw && mine) {                        // P_{t+1}, W_{t+1} for the costate output (PDP.py:604)
-                double* pw = ws_pw + ((int64_t)br[r] * T + t) * pwsz;
-                if (oRep.offA >= 0 && col < 4) pw[oRep.offA] = P[r];
-                if (oNP.offB >= 0) pw[n * n + oNP.offB] = W[r];
-            }
-            SmallGains g;
             double Pr = P[r], Wr = W[r];
-            ok[r] = riccati_small_backward<M>(Pr, Wr, c.F[r], c.Y[r], c.Gr[r], c.Hxx[r], c.HX[r], c.HU[r], c.Hux[r], lane, tlane, p, g) && ok[r];
+            ok[r] = riccati_small_backward<M>(Pr, Wr, c.F[r], c.Y[r], c.Gr[r], c.Hxx[r], c.HX[r], c.HU[r], c.Hux[r], lane, tlane, p, g[r]) && ok[r];
             P[r] = Pr; W[r] = Wr;
-            if (mine) {
-                double* gw = ws_gain + ((int64_t)br[r] * T + t) * gsz;
-                if (row < M && col < n) gw[col * M + row] = g.K;                    // K' [n][m]
-                if (oMP.offB >= 0) gw[n * M + oMP.offB] = g.IK;                     // k [m][p]
-            }
-            finite[r] = finite[r] && fabs(P[r]) <= 1.7e308 && fabs(W[r]) <= 1.7e308;
+            finite[r] = finite[r] && fabs(Pr) <= 1.7e308 && fabs(Wr) <= 1.7e308;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* gw = ws_gain + ((int64_t)br[r] * T + t) * gsz;
+            if (mine[r] && row < M && col < n) gw[col * M + row] = g[r].K;           // K' [n][m]
+            if (mine[r] && oMP.offB >= 0) gw[n * M + oMP.offB] = g[r].IK;            // k [m][p]
         }
     };
     {
@@ -287,21 +309,20 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
     };
     auto fstep = [&](int t, const Fwd& c, Fwd& nx) {
         if (t + 1 < T) load_fwd(t + 1, nx);
+        double U[4], L[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double U, Xn;
-            riccati_small_forward(-c.KT[r], -c.k[r], c.FT[r], c.GT[r], c.E[r], X[r], U, Xn);
+            double Xn;
+            riccati_small_forward(-c.KT[r], -c.k[r], c.FT[r], c.GT[r], c.E[r], X[r], U[r], Xn);
             X[r] = Xn;
-            const bool mine = 4 * (int)blockIdx.x + r < B;
-            if (mine) {
-                if (oMP.offB >= 0) Uo[((int64_t)br[r] * T + t) * M * p + oMP.offB] = U;
-                if (oNP.offB >= 0) Xo[((int64_t)br[r] * (T + 1) + t + 1) * n * p + oNP.offB] = Xn;
-                if (Lo) {
-                    const double L = mma4_blk(c.Pt[r], Xn, c.Wt[r]);           // lambda_{t+1} = P x_{t+1} + W   (P symmetric)
-                    if (oNP.offB >= 0) Lo[((int64_t)br[r] * T + t) * n * p + oNP.offB] = L;
-                }
-            }
+            L[r] = Lo ? mma4_blk(c.Pt[r], Xn, c.Wt[r]) : 0.0;                      // lambda_{t+1} = P x_{t+1} + W   (P symmetric)
             finite[r] = finite[r] && fabs(Xn) <= 1.7e308;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (mine[r] && oMP.offB >= 0) Uo[((int64_t)br[r] * T + t) * M * p + oMP.offB] = U[r];
+            if (mine[r] && oNP.offB >= 0) Xo[((int64_t)br[r] * (T + 1) + t + 1) * n * p + oNP.offB] = X[r];
+            if (Lo && mine[r] && oNP.offB >= 0) Lo[((int64_t)br[r] * T + t) * n * p + oNP.offB] = L[r];
         }
     };
     {

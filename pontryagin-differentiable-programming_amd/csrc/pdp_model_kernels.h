@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/pdp_hip.h"
 #include "pdp_riccati.h"
+#include "pdp_riccati_small.h"
 #include "pdp_policy.h"
 
 namespace pdp {
@@ -482,12 +483,18 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
     using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = L::CH, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K [NU x NX] | k [NU x NP] | zero sink
+    // SMALL (n <= 4: pendulum, cart-pole, robot arm): every matrix of the recursion fits the rows-0..3 register of its tile and every
+    // product is ONE v_mfma_f64_4x4x4_4b (pdp_riccati_small.h) instead of four 64-cycle 16x16x4 MFMAs on a tile that is 94 % padding:
+    // left operands are gathered in "rep" form (the 4 x 4 block replicated in the four column blocks), only register 0 of a tile is live
+    constexpr bool SMALL = NX <= 4;
+    constexpr int NRT = SMALL ? 1 : 4;                  // live registers of an n-row tile
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
     double* pool = blk + L::NC;
     double* dlT = pool + fused_pool_doubles<Mdl>(T);    // x_T - xdemo_T (NX)
     const int b = blockIdx.x, lane = threadIdx.x;
+    const int tlane = small_transpose_lane(lane);
     const d4 z = zero4();
     // theta and the theta-only precomputed values are parked in LDS and re-read inside every block of generated scalar code:
     // kept in registers they would occupy 2 (NP + NPC) VGPRs for the whole kernel, which sits at the 256-VGPR ceiling
@@ -584,7 +591,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         }
         wave_lds_sync();
         Gather gP, gW;
-        make_gather(gP, lane, L::NC, 0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1; });
+        make_gather(gP, lane, L::NC, 0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::fin_code(0, r * NX + (c & 3)) : -1)
+                                                                         : ((r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1); });
         make_gather(gW, lane, L::NC, 0, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fin_code(1, r * NP + (c - M)) : -1; });
         P = gather_tile(blk, gP, 0);
         W2 = gather_tile(blk, gW, 0);
@@ -602,14 +610,17 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
         auto codeB = [](int mat, int i) { int c = Mdl::pathb_code(mat, i); return c >= 0 ? c + NA : (c == -1 ? -1 : c - NCA); };
         Gather gF, gY, gHxx, gHX, gHU, gCX;
-        make_gather(gF, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+        make_gather(gF, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeA(0, r * NX + (c & 3)) : -1)
+                                                                                  : ((r < NX && c < NX) ? codeA(0, r * NX + c) : -1); });
         make_gather(gY, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= NX ? -1 : (c < M ? codeA(1, r * NU + c) : (c < M + NP ? codeA(2, r * NP + (c - M)) : -1)); });
         make_gather(gCX, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
         Gather gGr, gHux;                                 // G replicated in the four column blocks (operand of the 4-row products); Hux = Hxu'
         make_gather(gGr, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeA(1, r * NU + (c & 3)) : -1; });
-        make_gather(gHux, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < M && c < NX) ? codeB(1, c * NU + r) : -1; });
-        make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
+        make_gather(gHux, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? codeB(1, (c & 3) * NU + r) : -1)
+                                                                                    : ((r < M && c < NX) ? codeB(1, c * NU + r) : -1); });
+        make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeB(0, r * NX + (c & 3)) : -1)
+                                                                                    : ((r < NX && c < NX) ? codeB(0, r * NX + c) : -1); });
         make_gather(gHX, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
@@ -663,12 +674,13 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                     wL.cur[r] = lds_addr(lds) + (valid ? 8u * (unsigned)((pool - lds) + (cnt - 1) * L::BSTRIDE + L::LAM + row) : 0u);     // scratch[0]: idle here
                     wL.tmul[r] = valid ? 8 * L::BSTRIDE : 0;
                 }
-                d4 Fc = gather_run(cF, -1), CX = gather_run(cC, -1);
+                d4 Fc = gather_run<NRT>(cF, -1), CX = gather_run<NRT>(cC, -1);
                 auto cstep = [&](int tl, const d4 Lin, d4& Lout) {
                     d4 Fc_n = Fc, CX_n = CX;
-                    if (tl > 0) { Fc_n = gather_run(cF, -1); CX_n = gather_run(cC, -1); }
+                    if (tl > 0) { Fc_n = gather_run<NRT>(cF, -1); CX_n = gather_run<NRT>(cC, -1); }
                     scatter_run(wL, Lin, -1);
-                    Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                    if constexpr (SMALL) { Lout = z; Lout[0] = mma4_blk(Fc[0], Lin[0], CX[0]); }
+                    else Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
                     Fc = Fc_n; CX = CX_n;
                 };
                 // two steps per trip with the costate tile alternating between two register sets: the MFMA chain of a step reads
@@ -709,28 +721,40 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             // of a chunk prefetches nothing (no LDS read outside the pool).  Two steps per trip with the prefetched tiles alternating
             // between two register sets (no copies at the back edge).
 #ifndef PDP_FUSED_NO_PREFETCH
-            d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
+            d4 Fa = gather_run<NRT>(rF, -1), Ya = gather_run<NRT>(rY, -1), Fb = z, Yb = z;
 #else
             d4 Fa = z, Ya = z, Fb = z, Yb = z;
 #endif
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
                 PDP_FINE(0, t == 20);
-                d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
+                d4 Hxx = gather_run<NRT>(rHxx, -1), HX2 = gather_run<NRT>(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run<NRT>(rGr, -1), Hux = gather_run<1>(rHux, -1);
 #ifndef PDP_FUSED_NO_PREFETCH
-                if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }
+                if (tl > 0) { Fn = gather_run<NRT>(rF, -1); Yn = gather_run<NRT>(rY, -1); }
                 const d4 Fu = Fc, Yu = Yc;
 #else       // two waves per SIMD hide the gather latency behind each other: no one-step-ahead copies of F and [G|E] (16 registers)
-                const d4 Fu = gather_run(rF, -1), Yu = gather_run(rY, -1);
+                const d4 Fu = gather_run<NRT>(rF, -1), Yu = gather_run<NRT>(rY, -1);
                 (void)Fc; (void)Yc; (void)Fn; (void)Yn;
 #endif
+                PDP_FINE(1, t == 20);
+                if constexpr (SMALL) {
+                    SmallGains g;
+                    double Pr = P[0], Wr = W2[0];
+                    ok = riccati_small_backward<M>(Pr, Wr, Fu[0], Yu[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux[0], lane, tlane, NP, g) && ok;
+                    P[0] = Pr; W2[0] = Wr;
+                    d4 Kt = z, IKt = z;
+                    Kt[0] = (lane & 12) == 0 ? g.K : 0.0;      // K arrives in rep form: its first column block is K [NU x NX]; the replicas must not
+                    IKt[0] = g.IK;                              // reach the zero sink slot the forward sweep reads back for absent elements
+                    store_all<1>(gw + t * GSZ, mK, Kt);
+                    store_all<1>(gw + t * GSZ + NX * NU, mIK, IKt);
+                } else {
                 RiccatiGains g;
                 d4 P_old;
-                PDP_FINE(1, t == 20);
                 ok = riccati_backward<M, false>(P, W2, Fu, Yu, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
+                }
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
             };
@@ -750,8 +774,10 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blk[1 + i_] = Mdl::fwd_const(i_);
         constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
         Gather gFT, gGT, gE, gDX, gDU;
-        make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
-        make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1; });
+        make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::fwd_code(0, (c & 3) * NX + r) : -1)
+                                                                               : ((r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1); });
+        make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? Mdl::fwd_code(1, (c & 3) * NU + r) : -1)
+                                                                               : ((r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1); });
         make_gather(gE, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fwd_code(2, r * NP + (c - M)) : -1; });
         make_gather(gDX, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
         make_gather(gDU, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M) ? DLU + r : -1; });
@@ -761,7 +787,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
         // K is read back transposed and replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
         const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
-        d4 KTn = -load_all<4>(gw, mKT);
+        d4 KTn = -load_all<NRT>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
@@ -787,15 +813,21 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                 PDP_FINE(8, t == 20);
-                KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
+                KTnx = -load_all<NRT>(gw + tnx * GSZ, mKT);
                 knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                d4 FT = gather_run(rFT, 1);
+                d4 FT = gather_run<NRT>(rFT, 1);
                 d4 GT = gather_run<1>(rGT, 1);
-                d4 E2 = gather_run(rE, 1);
-                d4 DX = gather_run(rDX, 1);            // (x_t - xd_t)[row] broadcast over columns
+                d4 E2 = gather_run<NRT>(rE, 1);
+                d4 DX = gather_run<NRT>(rDX, 1);            // (x_t - xd_t)[row] broadcast over columns
                 d4 DU = gather_run<1>(rDU, 1);
                 d4 U2;
                 PDP_FINE(9, t == 20);
+                if constexpr (SMALL) {
+                    U2 = z; Xn = z;
+                    double u0, x1;
+                    riccati_small_forward(KTc[0], kc[0], FT[0], GT[0], E2[0], Xc[0], u0, x1);
+                    U2[0] = u0; Xn[0] = x1;
+                } else
                 riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                 PDP_FINE(10, t == 20);
                 acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];

@@ -69,6 +69,10 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     using L = MsLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = L::CH, M = NU;
     constexpr int GSZ = L::GSZ, PWSZ = L::PWSZ;
+    // SMALL (n <= 4): the whole recursion on the rows-0..3 register of each tile, every product ONE 4-block MFMA (pdp_riccati_small.h);
+    // left operands are gathered / loaded in "rep" form (the 4 x 4 block replicated in the four column blocks)
+    constexpr bool SMALL = NX <= 4;
+    constexpr int NRT = SMALL ? 1 : 4;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [constants (NC) | pool]
@@ -76,6 +80,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     double* dlT = pool + L::POOL;                       // terminal gradient (NX)
     double* par = dlT + NX;                             // [theta (NP) | pc (NPC)]
     const int b = blockIdx.x, lane = threadIdx.x;
+    const int tlane = small_transpose_lane(lane);
     const d4 z = zero4();
     {
         double th0[NP > 0 ? NP : 1], pc0[Mdl::NPC];
@@ -122,21 +127,25 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     // ---- loop-invariant gather / store maps ---------------------------------------------------------------------------------------
     auto codeS = [](int mat, int i) { return Mdl::sol_code(mat, i); };       // 0 F, 1 G, 2 Hxx, 3 Hxu, 4 Huu
     Gather gF, gY, gHxx, gHX, gHU, gGr, gHux;
-    make_gather(gF, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeS(0, r * NX + c) : -1; });
+    make_gather(gF, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(0, r * NX + (c & 3)) : -1)
+                                                                              : ((r < NX && c < NX) ? codeS(0, r * NX + c) : -1); });
     make_gather(gY, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(1, r * NU + c) : (c == M ? L::C0 + r : -1)); });
     make_gather(gGr, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
-    make_gather(gHux, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < M && c < NX) ? codeS(3, c * NU + r) : -1; });
-    make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (r < NX && c < NX) ? codeS(2, r * NX + c) : -1; });
+    make_gather(gHux, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? codeS(3, (c & 3) * NU + r) : -1)
+                                                                                : ((r < M && c < NX) ? codeS(3, c * NU + r) : -1); });
+    make_gather(gHxx, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(2, r * NX + (c & 3)) : -1)
+                                                                                : ((r < NX && c < NX) ? codeS(2, r * NX + c) : -1); });
     make_gather(gHX, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(3, r * NU + c) : (c == M ? L::RX + r : -1)); });
     make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return r >= M ? -1 : (c < M ? codeS(4, r * NU + c) : (c == M ? L::RU + r : -1)); });
     const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, 1, 1, 0, M, lane, NU),
                        mP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, PWSZ - 1), mW = make_tile_map_sink(NX, 1, 1, 0, M, lane, NX),
+                       mPld = SMALL ? to_bytes_sink(make_rep4_map(NX, NX, NX, lane), PWSZ - 1) : mP,      // P read back for the multiplier step (rep form when SMALL)
                        mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ - 1);
     const int col = tile_col(lane);
     // per-lane tile masks: diagonal of the n x n / m x m blocks, control columns, the affine column
     d4 dgN, dgM0 = z;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dgN[r] = (tile_row(lane, r) == col && col < NX) ? 1.0 : 0.0;
+    for (int r = 0; r < 4; ++r) dgN[r] = SMALL ? ((r == 0 && (lane >> 4) == (col & 3) && (col & 3) < NX) ? 1.0 : 0.0) : ((tile_row(lane, r) == col && col < NX) ? 1.0 : 0.0);
     dgM0[0] = ((lane >> 4) == col && col < M) ? 1.0 : 0.0;
 
     // ---- per-sweep reductions over the stages (complete after a sweep that was not aborted) ------------------------------------------
@@ -174,7 +183,8 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         d4 P, W2 = z;
         {
             Gather gP;
-            make_gather(gP, lane, L::NC, 0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1; });
+            make_gather(gP, lane, L::NC, 0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::fin_code(0, r * NX + (c & 3)) : -1)
+                                                                             : ((r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1); });
             P = gather_tile(blk, gP, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -226,17 +236,33 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             wave_lds_sync();
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
                       rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
-            d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
+            d4 Fa = gather_run<NRT>(rF, -1), Ya = gather_run<NRT>(rY, -1), Fb = z, Yb = z;
             auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                 const int t = t0 + tl;
-                d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
-                if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }      // (no prefetch below the first row of the pool)
+                d4 Hxx = gather_run<NRT>(rHxx, -1), HX2 = gather_run<NRT>(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run<NRT>(rGr, -1), Hux = gather_run<1>(rHux, -1);
+                if (tl > 0) { Fn = gather_run<NRT>(rF, -1); Yn = gather_run<NRT>(rY, -1); }      // (no prefetch below the first row of the pool)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { Hxx[r] = hs * Hxx[r] + dw * dgN[r]; HX2[r] *= sU; }
                 HU2[0] = sU * HU2[0] + dw * dgM0[0];
                 const d4 Ys = Yc * sC;
                 const double Hux0 = hs * Hux[0];
                 // P_{t+1}, W_{t+1}: the multiplier step of the forward pass needs them (dlam_t = P_{t+1} dx_{t+1} + W_{t+1})
+                if constexpr (SMALL) {
+                    d4 Pst = z;
+                    Pst[0] = (lane & 12) == 0 ? P[0] : 0.0;      // P is in rep form: only its first column block goes to the workspace (the zero sink stays zero)
+                    store_all<1>(pw + t * PWSZ, mP, Pst);
+                    store_all<1>(pw + t * PWSZ + NX * NX, mW, W2);
+                    SmallGains g;
+                    double Pr = P[0], Wr = W2[0];
+                    ok = riccati_small_backward<M>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, g) && ok;
+                    P[0] = Pr; W2[0] = Wr;
+                    pdall = pdall && g.pd;
+                    d4 Kt = z, IKt = z;
+                    Kt[0] = (lane & 12) == 0 ? g.K : 0.0;
+                    IKt[0] = g.IK;
+                    store_all<1>(gw + t * GSZ, mK, Kt);
+                    store_all<1>(gw + t * GSZ + NX * NU, mIK, IKt);
+                } else {
                 store_all(pw + t * PWSZ, mP, P);
                 store_all(pw + t * PWSZ + NX * NX, mW, W2);
                 RiccatiGains g;
@@ -245,6 +271,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                 pdall = pdall && g.pd;
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
+                }
             };
             int tl = cnt - 1;
             for (; tl >= 1 && pdall; tl -= 2) { bstep(tl, Fa, Ya, Fb, Yb); if (pdall) bstep(tl - 1, Fb, Yb, Fa, Ya); else break; }
@@ -263,14 +290,16 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         wave_lds_sync();
         for (int i = lane; i < Mdl::SOLF_NCONST; i += 64) blk[1 + i] = Mdl::solf_const(i);
         Gather gFT, gGT, gE;
-        make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::solf_code(0, c * NX + r) : -1; });
-        make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1; });
+        make_gather(gFT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::solf_code(0, (c & 3) * NX + r) : -1)
+                                                                               : ((r < NX && c < NX) ? Mdl::solf_code(0, c * NX + r) : -1); });
+        make_gather(gGT, lane, L::NC, L::FSTRIDE, [](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? Mdl::solf_code(1, (c & 3) * NU + r) : -1)
+                                                                               : ((r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1); });
         make_gather(gE, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
         d4 X2 = z;
         // gains and P_{t+1}, W_{t+1} of step t are requested one step ahead (each lane re-reads what it stored in the backward sweep)
-        d4 KTn = -load_all<4>(gw, mKT);
+        d4 KTn = -load_all<NRT>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
-        d4 Pq = load_all<4>(pw, mP), Wq = load_all<4>(pw + NX * NX, mW);
+        d4 Pq = load_all<NRT>(pw, mPld), Wq = load_all<NRT>(pw + NX * NX, mW);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;
         for (int c = 0; c < nchunk; ++c) {
@@ -292,16 +321,24 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             GatherRun rFT = gather_at(gFT, 0, blk), rGT = gather_at(gGT, 0, blk), rE = gather_at(gE, 0, blk);
             auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, const d4 Pc, const d4 Wc, d4& KTnx, d4& knx, d4& Pnx, d4& Wnx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
-                KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
+                KTnx = -load_all<NRT>(gw + tnx * GSZ, mKT);
                 knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                Pnx = load_all<4>(pw + tnx * PWSZ, mP);
-                Wnx = load_all<4>(pw + tnx * PWSZ + NX * NX, mW);
-                d4 FT = gather_run(rFT, 1);
+                Pnx = load_all<NRT>(pw + tnx * PWSZ, mPld);
+                Wnx = load_all<NRT>(pw + tnx * PWSZ + NX * NX, mW);
+                d4 FT = gather_run<NRT>(rFT, 1);
                 d4 GT = gather_run<1>(rGT, 1);
-                d4 E2 = gather_run(rE, 1);
-                d4 U2;
+                d4 E2 = gather_run<NRT>(rE, 1);
+                d4 U2, Lm;
+                if constexpr (SMALL) {
+                    U2 = z; Xn = z; Lm = z;
+                    double u0, x1;
+                    riccati_small_forward(KTc[0], kc[0], FT[0], GT[0], E2[0], Xc[0], u0, x1);
+                    U2[0] = u0; Xn[0] = x1;
+                    Lm[0] = mma4_blk(Pc[0], x1, Wc[0]);
+                } else {
                 riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
-                const d4 Lm = mma_tn(Pc, Xn, Wc);                    // dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (P symmetric)
+                Lm = mma_tn(Pc, Xn, Wc);                             // dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (P symmetric)
+                }
                 store_tile_column(dub + t * NU, U2, NU, M, lane);
                 store_tile_column(dxb + (t + 1) * NX, Xn, NX, M, lane);
                 store_tile_column(dlb + t * NX, Lm, NX, M, lane);

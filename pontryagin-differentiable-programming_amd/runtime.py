@@ -440,8 +440,9 @@ class ModelLib:
             core = load_core()
             core.pdp_cp_grad_contract_batched.restype = C.c_int
             core.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
-            check(core.pdp_cp_grad_contract_batched(B, T, n, m, p, ptr(ex[:, :T].contiguous()), ptr(eu.contiguous()), ptr(ex[:, T].contiguous()), ptr(X), ptr(U),
-                                                    ptr(g), current_stream_ptr()), "pdp_cp_grad_contract_batched")
+            ex_path, ex_fin, eu_c = ex[:, :T].contiguous(), ex[:, T].contiguous(), eu.contiguous()      # (named: they must outlive the launch)
+            check(core.pdp_cp_grad_contract_batched(B, T, n, m, p, ptr(ex_path), ptr(eu_c), ptr(ex_fin), ptr(X), ptr(U), ptr(g), current_stream_ptr()),
+                  "pdp_cp_grad_contract_batched")
             grad.copy_(g)
             if packed:
                 pk[:, p].copy_(loss)
