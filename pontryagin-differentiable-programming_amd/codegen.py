@@ -30,6 +30,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: let the fp64 MFMA accumulators live in VGPRs (the kernels sit at the 256-VGPR ceiling; with AGPR accumulators every
 # VALU/LDS use of a product costs v_accvgpr moves - measured +4% on the headline kernel)
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("PDP_HIP_EXTRA_FLAGS", "").split()
+# The core library (16 instantiations of lqr_solve_kernel at 256 VGPRs + up to 180 AGPRs) is built WITHOUT -amdgpu-mfma-vgpr-form: with that
+# (hidden, experimental) LLVM option a variant of lqr_solve_kernel<2,3> that streams one more operand is miscompiled at -O3 - deterministic
+# out-of-bounds global reads on guard-banded operands, gone at -O1 and gone without the option (probes/lqr_oob_probe.py, DESIGN.md section 8;
+# profiles/r02_lqr_oob_root_cause.txt).  The kernel is HBM-bound: the option bought nothing there.
+CORE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("PDP_HIP_EXTRA_FLAGS", "").split()
 # OC models (the fused kernel): loop strength reduction rewrites the running LDS addresses of the step loops as (induction variable + 0)
 # and leaves a `v_add_u32 v, 0, v` in front of every ds_read (39 VALU instructions per time step); the loops already carry their own
 # running addresses.  Measured: fused kernel +5 % without LSR; the SysID / ControlPlanning kernels lose up to 12 % -> OC models only.
@@ -411,16 +416,17 @@ def _stamp_of(deps, flags):
     return h.hexdigest()
 
 
-def _build(out, deps, cmd_tail, force):
+def _build(out, deps, cmd_tail, force, flags=None):
+    flags = HIP_FLAGS if flags is None else flags
     os.makedirs(LIB_DIR, exist_ok=True)
     stamp_path = out + ".stamp"
-    stamp = _stamp_of(deps, HIP_FLAGS + cmd_tail[:-1])
+    stamp = _stamp_of(deps, flags + cmd_tail[:-1])
     if not force and os.path.exists(out) and os.path.exists(stamp_path) and open(stamp_path).read().strip() == stamp:
         return out
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s: cannot build %s" % (HIPCC, out))
     tmp = "%s.%d.tmp" % (out, os.getpid())           # several ranks may build the same library at once: write aside, rename atomically
-    _run([HIPCC] + HIP_FLAGS + cmd_tail + ["-o", tmp])
+    _run([HIPCC] + flags + cmd_tail + ["-o", tmp])
     os.replace(tmp, out)
     with open(stamp_path + ".%d.tmp" % os.getpid(), "w") as f:
         f.write(stamp)
@@ -438,7 +444,7 @@ def compile_model(name, force=False):
 
 def compile_core(force=False):
     deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
-    return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force)
+    return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force, flags=CORE_FLAGS)
 
 
 def build_problem(problem, force=False):

@@ -202,8 +202,19 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
 // same for the four trajectories (their bases differ by the batch stride: scalar registers); absent elements are zeros.
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct SmallOp { int offA, offB; };      // element offset in the first / second source matrix, -1 = absent
+// one running pointer per trajectory of the wave (RunPtr slot r = trajectory r): the loads of a step are bare global_loads with nothing
+// behind them - no bound check, select or branch - so all of them are in flight before the first is waited for
+PDP_DEV RunPtr make_run_small(const pdp_mat& A, const pdp_mat& Bm, const SmallOp& o, const int* br, int t) {
+    RunPtr r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r.p[k] = PDP_ZERO; r.step[k] = 0;
+        if (A.ptr && o.offA >= 0) { r.p[k] = mat_at(A, br[k], t) + o.offA; r.step[k] = (int)(A.tstride * 8); }
+        else if (Bm.ptr && o.offB >= 0) { r.p[k] = mat_at(Bm, br[k], t) + o.offB; r.step[k] = (int)(Bm.tstride * 8); }
+    }
+    return r;
+}
 PDP_DEV double small_load(const double* __restrict__ A, const double* __restrict__ Bm, const SmallOp& o) {
-    // branch-free: absent elements read a zero word, so every load of a step is in flight before the first is waited for
     const double* q = (o.offA >= 0 && A) ? A + o.offA : ((o.offB >= 0 && Bm) ? Bm + o.offB : (const double*)PDP_ZERO);
     return *q;
 }
@@ -238,21 +249,19 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
         W[r] = small_load(nullptr, mat_at(pr.hxe, br[r], 0), oNP);
     }
     struct Bwd { d4 F, Y, Gr, Hxx, HX, HU, Hux; };
-    auto load_bwd = [&](int t, Bwd& w) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double *F = mat_at(pr.F, br[r], t), *G = mat_at(pr.G, br[r], t), *E = mat_at(pr.E, br[r], t), *Hxx = mat_at(pr.Hxx, br[r], t),
-                         *Hxu = mat_at(pr.Hxu, br[r], t), *Hxe = mat_at(pr.Hxe, br[r], t), *Huu = mat_at(pr.Huu, br[r], t), *Hue = mat_at(pr.Hue, br[r], t);
-            w.F[r] = small_load(F, nullptr, oRep); w.Y[r] = small_load(G, E, oY); w.Gr[r] = small_load(G, nullptr, oGr);
-            w.Hxx[r] = small_load(Hxx, nullptr, oRep); w.HX[r] = small_load(Hxu, Hxe, oY); w.HU[r] = small_load(Huu, Hue, oU);
-            w.Hux[r] = small_load(Hxu, nullptr, oGT);
-        }
+    const pdp_mat none = {nullptr, 0, 0};
+    RunPtr rF = make_run_small(pr.F, none, oRep, br, T - 1), rY = make_run_small(pr.G, pr.E, oY, br, T - 1), rGr = make_run_small(pr.G, none, oGr, br, T - 1),
+           rHxx = make_run_small(pr.Hxx, none, oRep, br, T - 1), rHX = make_run_small(pr.Hxu, pr.Hxe, oY, br, T - 1),
+           rHU = make_run_small(pr.Huu, pr.Hue, oU, br, T - 1), rHux = make_run_small(pr.Hxu, none, oGT, br, T - 1);
+    auto load_bwd = [&](Bwd& w) {       // reads the current step's operands, moves the pointers one step down
+        w.F = load_run(rF, -1); w.Y = load_run(rY, -1); w.Gr = load_run(rGr, -1); w.Hxx = load_run(rHxx, -1); w.HX = load_run(rHX, -1);
+        w.HU = load_run(rHU, -1); w.Hux = load_run(rHux, -1);
     };
     bool mine[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) mine[r] = 4 * (int)blockIdx.x + r < B;
     auto bstep = [&](int t, const Bwd& c, Bwd& nx) {
-        if (t > 0) load_bwd(t - 1, nx);                 // the operands of step t-1 are requested before step t computes
+        if (t > 0) load_bwd(nx);                        // the operands of step t-1 are requested before step t computes
         if (ws_pw) {                                    // P_{t+1}, W_{t+1} for the costate output (PDP.py:604)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -279,7 +288,7 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
     };
     {
         Bwd ta, tb;
-        load_bwd(T - 1, ta);
+        load_bwd(ta);
         int t = T - 1;
         for (; t >= 1; t -= 2) { bstep(t, ta, tb); bstep(t - 1, tb, ta); }
         if (t == 0) bstep(0, ta, tb);
@@ -293,22 +302,17 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
     }
     __threadfence_block();
     struct Fwd { d4 FT, GT, KT, k, E, Pt, Wt; };
-    auto load_fwd = [&](int t, Fwd& w) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double* gw = ws_gain + ((int64_t)br[r] * T + t) * gsz;
-            const double* pw = (ws_pw && Lo) ? ws_pw + ((int64_t)br[r] * T + t) * pwsz : nullptr;
-            w.FT[r] = small_load(mat_at(pr.F, br[r], t), nullptr, oRepT);
-            w.GT[r] = small_load(mat_at(pr.G, br[r], t), nullptr, oGT);
-            w.KT[r] = small_load(gw, nullptr, oKT);
-            w.k[r] = small_load(nullptr, gw + n * M, oMP);
-            w.E[r] = small_load(nullptr, mat_at(pr.E, br[r], t), oNP);
-            w.Pt[r] = small_load(pw, nullptr, oRep);
-            w.Wt[r] = small_load(nullptr, pw ? pw + n * n : nullptr, oNP);
-        }
+    const pdp_mat gKT = {ws_gain, (int64_t)T * gsz, gsz}, gk = {ws_gain + n * M, (int64_t)T * gsz, gsz},
+                  wP = {(ws_pw && Lo) ? ws_pw : nullptr, (int64_t)T * pwsz, pwsz}, wW = {(ws_pw && Lo) ? ws_pw + n * n : nullptr, (int64_t)T * pwsz, pwsz};
+    RunPtr qFT = make_run_small(pr.F, none, oRepT, br, 0), qGT = make_run_small(pr.G, none, oGT, br, 0), qKT = make_run_small(gKT, none, oKT, br, 0),
+           qk = make_run_small(none, gk, oMP, br, 0), qE = make_run_small(none, pr.E, oNP, br, 0), qP = make_run_small(wP, none, oRep, br, 0),
+           qW = make_run_small(none, wW, oNP, br, 0);
+    auto load_fwd = [&](Fwd& w) {
+        w.FT = load_run(qFT, 1); w.GT = load_run(qGT, 1); w.KT = load_run(qKT, 1); w.k = load_run(qk, 1); w.E = load_run(qE, 1);
+        w.Pt = load_run(qP, 1); w.Wt = load_run(qW, 1);
     };
     auto fstep = [&](int t, const Fwd& c, Fwd& nx) {
-        if (t + 1 < T) load_fwd(t + 1, nx);
+        if (t + 1 < T) load_fwd(nx);
         double U[4], L[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -327,7 +331,7 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
     };
     {
         Fwd ta, tb;
-        load_fwd(0, ta);
+        load_fwd(ta);
         int t = 0;
         for (; t + 1 < T; t += 2) { fstep(t, ta, tb); fstep(t + 1, tb, ta); }
         if (t < T) fstep(t, ta, tb);

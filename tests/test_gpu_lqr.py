@@ -207,3 +207,14 @@ def test_lqr_small_systems_four_trajectories_per_wavefront(n, m, p, B):
     _, _, _, st4 = rt.lqr_solve(F, Gz, Hxx, Huz, hxx, hxe, E=E, Hxe=Hxe, Hue=Hue)
     st4 = _to_np(st4)
     assert st4[B - 1] & 2 and (B == 1 or int(st4[:B - 1].sum()) == 0)
+
+
+def test_lqr_guard_banded_operands_every_instantiation():
+    """Bounds check by construction (probes/lqr_oob_probe.py): every operand of all 16 lqr_solve_kernel<M, NT> instantiations is a view
+    into ONE NaN-filled allocation with NaN words directly before and after it, outputs and workspace come from NaN-dirtied allocator
+    blocks; a read outside an operand that reaches the result is a NaN / mismatch against the numpy restatement.  (Round 1's unguarded
+    prefetch after the last step, and a miscompiled streamed-operand variant, both fail this probe: DESIGN.md section 8.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-u", os.path.join(root, "probes", "lqr_oob_probe.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "RESULT libpdp_hip.so: 0 of 16 instantiations mismatch" in r.stdout, r.stdout[-3000:]
