@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define PDP_E_ARG (-1)      /* null pointer / non-positive size */
-#define PDP_E_SIZE (-2)     /* dimension outside what the kernels are built for (n<=16, m<=4, p<=64 ...) */
+#define PDP_E_SIZE (-2)     /* dimension outside what the kernels are built for (see each entry point) */
 #define PDP_E_LAUNCH (-3)   /* HIP launch error (hipGetLastError() has the detail) */
 #define PDP_E_MODE (-4)     /* entry point not provided by this model kind */
 
@@ -74,7 +74,10 @@ int64_t pdp_lqr_workspace_bytes(int B, int T, int n, int m, int p, int want_cost
 
 /* Batched LQR.lqrSolver (PDP/PDP.py:446-615): backward Riccati sweep (557-580) and forward rollout of
  * X [B][T+1][n][p], U [B][T][m][p], Lam [B][T][n][p] (582-608; Lam may be NULL).  One wavefront per
- * trajectory, 16x16 fp64 MFMA tiles held in registers.  Limits: n <= 16, m <= 4, p <= 64 - m. */
+ * trajectory.  n <= 16, m <= 4, p <= 64 - m: 16x16 fp64 MFMA tiles held in registers; n <= 4 and m + p <= 16: FOUR trajectories per
+ * wavefront, block-diagonal in the tile, every product on the 4-block MFMA v_mfma_f64_4x4x4 (pdp_riccati_small.h); 16 < n <= 32 or
+ * 4 < m <= 8 with p <= 32: a generic LDS kernel (plain fp64 loops).  Beyond those limits PDP_E_SIZE; more parameter columns than one
+ * launch carries are solved in column blocks by the caller (the columns are independent given the gains; runtime.lqr_solve does it). */
 int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, double* Lam, int32_t* status,
                           void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -151,7 +151,17 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
     const pdp_lqr_problem& pr = *prob;
     if (pr.B <= 0 || pr.T <= 0 || pr.n <= 0 || pr.m <= 0 || pr.p <= 0) return PDP_E_ARG;
     if (!pr.F.ptr || !pr.G.ptr || !pr.Hxx.ptr || !pr.Huu.ptr || !pr.hxx.ptr) return PDP_E_ARG;
-    if (pr.n > 16 || pr.m > 4) return PDP_E_SIZE;
+    if (pr.n > 16 || pr.m > 4) {                   // beyond one tile per matrix: the generic LDS kernel (n <= 32, m <= 8, p <= 32 per launch)
+        if (pr.n > GEN_NMAX || pr.m > GEN_MMAX || pr.p > GEN_PMAX) return PDP_E_SIZE;
+        if (workspace_bytes < pdp_lqr_workspace_bytes(pr.B, pr.T, pr.n, pr.m, pr.p, Lam != nullptr)) return PDP_E_ARG;
+        double* wg = (double*)workspace;
+        double* wpw = Lam ? wg + (int64_t)pr.B * pr.T * (pr.n * pr.m + pr.m * pr.p) : nullptr;
+        const size_t lds = sizeof(double) * lqr_generic_lds_doubles(pr.n, pr.m, pr.p);
+        (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        PDP_CLEAR();
+        hipLaunchKernelGGL(lqr_solve_generic_kernel, dim3(pr.B), dim3(64), lds, (hipStream_t)stream, pr, X, U, Lam, status, wg, wpw);
+        return launched();
+    }
     for (const pdp_mat* mt : {&pr.F, &pr.G, &pr.E, &pr.Hxx, &pr.Hxu, &pr.Hxe, &pr.Huu, &pr.Hue})       // per-lane byte strides are 32-bit
         if (mt->tstride < 0 || mt->tstride > (INT32_MAX >> 3)) return PDP_E_SIZE;
     const int p0 = pr.p < 16 - pr.m ? pr.p : 16 - pr.m;

@@ -345,4 +345,142 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Larger systems (16 < n <= 32 or 4 < m <= 8; p <= 32 per launch): the reference accepts any size (PDP.py:446-555).  Beyond one 16x16 tile
+// per matrix the recursion runs as plain lane-parallel fp64 loops over LDS-resident P, W and products - one wavefront per trajectory, every
+// output element of a product owned by one lane, the m x m system solved by Gauss-Jordan with partial pivoting on the augmented block
+// [Quu | Qux | Que].  Same Schur-complement algebra, inputs, outputs and workspace layout as lqr_solve_kernel; not tuned - it exists so
+// that models outside the tile kernels' limits run on the GPU at all.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int GEN_NMAX = 32, GEN_MMAX = 8, GEN_PMAX = 32;
+__host__ __device__ inline size_t lqr_generic_lds_doubles(int n, int m, int p) {
+    return (size_t)3 * n * n + (size_t)2 * n * p + (size_t)n * m + (size_t)m * (m + n + p) + (size_t)m * n + (size_t)m * p + 2 * (size_t)n * p + 8;
+}
+
+__global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo, double* __restrict__ Lo,
+                                                                int32_t* __restrict__ status, double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
+    extern __shared__ __attribute__((aligned(16))) double gl[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = pr.n, m = pr.m, p = pr.p, T = pr.T, wa = m + n + p;
+    double* P = gl;                  // n x n
+    double* PF = P + n * n;          // n x n
+    double* Pn = PF + n * n;         // n x n
+    double* W = Pn + n * n;          // n x p
+    double* PEW = W + n * p;         // n x p   (P E + W)
+    double* PG = PEW + n * p;        // n x m
+    double* A = PG + n * m;          // m x (m + n + p): [Quu | Qux | Que] -> [I | K | k]
+    double* Kk = A + m * wa;         // m x n  (forward: K), then m x p (k)
+    double* kk = Kk + m * n;
+    double* Xc = kk + m * p;         // n x p  (forward state)
+    double* Xn = Xc + n * p;
+    const int gsz = n * m + m * p, pwsz = n * n + n * p;
+    bool ok = true, finite = true;
+    const double* hxx = mat_at(pr.hxx, b, 0);
+    const double* hxe = mat_at(pr.hxe, b, 0);
+    for (int q = lane; q < n * n; q += 64) P[q] = hxx[q];
+    for (int q = lane; q < n * p; q += 64) W[q] = hxe ? hxe[q] : 0.0;
+    wave_lds_sync();
+    for (int t = T - 1; t >= 0; --t) {
+        const double *F = mat_at(pr.F, b, t), *G = mat_at(pr.G, b, t), *E = mat_at(pr.E, b, t), *Hxx = mat_at(pr.Hxx, b, t), *Hxu = mat_at(pr.Hxu, b, t),
+                     *Hxe = mat_at(pr.Hxe, b, t), *Huu = mat_at(pr.Huu, b, t), *Hue = mat_at(pr.Hue, b, t);
+        if (ws_pw) {
+            double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
+            for (int q = lane; q < n * n; q += 64) pw[q] = P[q];
+            for (int q = lane; q < n * p; q += 64) pw[n * n + q] = W[q];
+        }
+        for (int q = lane; q < n * n; q += 64) { const int i = q / n, j = q - i * n; double s = 0.0; for (int k = 0; k < n; ++k) s += P[i * n + k] * F[k * n + j]; PF[q] = s; }
+        for (int q = lane; q < n * m; q += 64) { const int i = q / m, j = q - i * m; double s = 0.0; for (int k = 0; k < n; ++k) s += P[i * n + k] * G[k * m + j]; PG[q] = s; }
+        for (int q = lane; q < n * p; q += 64) { const int i = q / p, j = q - i * p; double s = W[q]; if (E) for (int k = 0; k < n; ++k) s += P[i * n + k] * E[k * p + j]; PEW[q] = s; }
+        wave_lds_sync();
+        for (int q = lane; q < m * wa; q += 64) {           // [Quu | Qux | Que] = [Huu | Hxu' | Hue] + G' [PG | PF | PEW]
+            const int i = q / wa, c = q - i * wa;
+            double s;
+            if (c < m) { s = Huu[i * m + c]; for (int k = 0; k < n; ++k) s += G[k * m + i] * PG[k * m + c]; }
+            else if (c < m + n) { const int j = c - m; s = Hxu ? Hxu[j * m + i] : 0.0; for (int k = 0; k < n; ++k) s += G[k * m + i] * PF[k * n + j]; }
+            else { const int j = c - m - n; s = Hue ? Hue[i * p + j] : 0.0; for (int k = 0; k < n; ++k) s += G[k * m + i] * PEW[k * p + j]; }
+            A[q] = s;
+        }
+        // Pn = Hxx + F' PF ; Wn = Hxe + F' PEW   (before the elimination overwrites nothing they need; the rank-m corrections follow)
+        for (int q = lane; q < n * n; q += 64) { const int i = q / n, j = q - i * n; double s = Hxx[q]; for (int k = 0; k < n; ++k) s += F[k * n + i] * PF[k * n + j]; Pn[q] = s; }
+        wave_lds_sync();
+        // keep Qux' for the corrections: PG is free now -> Qux (m x n) copy in Kk ... the elimination turns A's Qux block into K
+        for (int q = lane; q < m * n; q += 64) Kk[q] = A[(q / n) * wa + m + (q % n)];
+        wave_lds_sync();
+        for (int c = 0; c < m; ++c) {                       // Gauss-Jordan with partial pivoting (uniform control flow)
+            int piv = c;
+            double best = fabs(A[c * wa + c]);
+            for (int r = c + 1; r < m; ++r) { const double v = fabs(A[r * wa + c]); if (v > best) { best = v; piv = r; } }
+            if (!(best > 1e-300) || !(best <= 1.7e308)) ok = false;
+            if (piv != c) { for (int q = lane; q < wa; q += 64) { const double tv = A[c * wa + q]; A[c * wa + q] = A[piv * wa + q]; A[piv * wa + q] = tv; } }
+            wave_lds_sync();
+            const double ip = 1.0 / A[c * wa + c];
+            wave_lds_sync();
+            for (int q = lane; q < wa; q += 64) A[c * wa + q] *= ip;
+            wave_lds_sync();
+            for (int r = 0; r < m; ++r) {
+                if (r == c) continue;
+                const double f = A[r * wa + c];
+                wave_lds_sync();
+                for (int q = lane; q < wa; q += 64) A[r * wa + q] -= f * A[c * wa + q];
+                wave_lds_sync();
+            }
+        }
+        // A = [I | K | k];  Kk holds Qux (m x n)
+        double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
+        for (int q = lane; q < n * m; q += 64) gw[q] = A[(q % m) * wa + m + q / m];                  // K' [n][m]
+        for (int q = lane; q < m * p; q += 64) gw[n * m + q] = A[(q / p) * wa + m + n + (q % p)];    // k [m][p]
+        // P- = Pn - Qux' K ; W- = Hxe + F' PEW - Qux' k
+        for (int q = lane; q < n * n; q += 64) { const int i = q / n, j = q - i * n; double s = Pn[q]; for (int r = 0; r < m; ++r) s -= Kk[r * n + i] * A[r * wa + m + j]; PF[q] = s; }
+        for (int q = lane; q < n * p; q += 64) {
+            const int i = q / p, j = q - i * p;
+            double s = Hxe ? Hxe[q] : 0.0;
+            for (int k = 0; k < n; ++k) s += F[k * n + i] * PEW[k * p + j];
+            for (int r = 0; r < m; ++r) s -= Kk[r * n + i] * A[r * wa + m + n + j];
+            W[q] = s;
+            finite = finite && fabs(s) <= 1.7e308;
+        }
+        wave_lds_sync();
+        for (int q = lane; q < n * n; q += 64) { const int i = q / n, j = q - i * n; const double s = 0.5 * (PF[q] + PF[j * n + i]); P[q] = s; finite = finite && fabs(s) <= 1.7e308; }
+        wave_lds_sync();
+    }
+    __threadfence_block();
+    // ---- forward rollout
+    const double* X0 = mat_at(pr.X0, b, 0);
+    for (int q = lane; q < n * p; q += 64) { const double v = X0 ? X0[q] : 0.0; Xc[q] = v; Xo[(int64_t)b * (T + 1) * n * p + q] = v; }
+    wave_lds_sync();
+    for (int t = 0; t < T; ++t) {
+        const double *F = mat_at(pr.F, b, t), *G = mat_at(pr.G, b, t), *E = mat_at(pr.E, b, t);
+        const double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
+        double* uo = Uo + ((int64_t)b * T + t) * m * p;
+        for (int q = lane; q < m * p; q += 64) {            // U = -K X - k
+            const int i = q / p, j = q - i * p;
+            double s = -gw[n * m + q];
+            for (int k = 0; k < n; ++k) s -= gw[k * m + i] * Xc[k * p + j];
+            kk[q] = s; uo[q] = s;
+        }
+        wave_lds_sync();
+        double* xo = Xo + ((int64_t)b * (T + 1) + t + 1) * n * p;
+        for (int q = lane; q < n * p; q += 64) {            // X+ = F X + G U + E
+            const int i = q / p, j = q - i * p;
+            double s = E ? E[q] : 0.0;
+            for (int k = 0; k < n; ++k) s += F[i * n + k] * Xc[k * p + j];
+            for (int r = 0; r < m; ++r) s += G[i * m + r] * kk[r * p + j];
+            Xn[q] = s; xo[q] = s;
+            finite = finite && fabs(s) <= 1.7e308;
+        }
+        wave_lds_sync();
+        if (Lo) {
+            const double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
+            double* lo = Lo + ((int64_t)b * T + t) * n * p;
+            for (int q = lane; q < n * p; q += 64) { const int i = q / p, j = q - i * p; double s = pw[n * n + q]; for (int k = 0; k < n; ++k) s += pw[i * n + k] * Xn[k * p + j]; lo[q] = s; }
+        }
+        for (int q = lane; q < n * p; q += 64) Xc[q] = Xn[q];
+        wave_lds_sync();
+    }
+    int st = 0;
+    if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
+    if (!ok) st |= PDP_STATUS_PIVOT;
+    if (lane == 0 && status) status[b] = st;
+}
+
 }  // namespace pdp

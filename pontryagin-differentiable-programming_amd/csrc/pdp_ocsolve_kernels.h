@@ -376,13 +376,59 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         tht = wave_sum(st);
     };
 
+    // KKT residuals of the current point with one lane per stage (no matrices, no sweep): what the convergence test needs.  The
+    // iteration tests convergence BEFORE it pays for a sweep (IPOPT's order), so a solve costs one sweep per Newton step, not one more.
+    auto residuals = [&]() {
+        PDP_MS_PAR();
+        double a_f = 0.0, a_th = 0.0, a_pr = 0.0, a_du = 0.0, a_z = 0.0, a_l = 0.0;
+        bool fin = true;
+        for (int t = lane; t < T; t += 64) {
+            double xc[NX], uc[NU], lc[NX], v[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; lc[i] = lb[t * NX + i]; a_z = fmax(a_z, fabs(xc[i])); a_l = fmax(a_l, fabs(lc[i])); }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; a_z = fmax(a_z, fabs(uc[i])); }
+            Mdl::dyn(xc, uc, th, pc, v);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double ci = v[i] - xb[(t + 1) * NX + i]; a_th += fabs(ci); a_pr = fmax(a_pr, fabs(ci)); fin = fin && fabs(ci) <= 1.7e308; }
+            Mdl::costate_step(xc, uc, lc, th, pc, v);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double g = t > 0 ? v[i] - lb[(t - 1) * NX + i] : 0.0; a_du = fmax(a_du, fabs(g)); fin = fin && fabs(g) <= 1.7e308; }
+            double hu[NU];
+            Mdl::dHu(xc, uc, lc, th, pc, hu);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { a_du = fmax(a_du, fabs(hu[i])); fin = fin && fabs(hu[i]) <= 1.7e308; }
+            a_f += Mdl::path_cost(xc, uc, th, pc);
+            if (t == T - 1) {
+                double xT[NX], hx[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { xT[i] = xb[T * NX + i]; a_z = fmax(a_z, fabs(xT[i])); }
+                Mdl::dhx(xT, th, pc, hx);
+                a_f += Mdl::final_cost(xT, th, pc);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { const double g = hx[i] - lc[i]; a_du = fmax(a_du, fabs(g)); fin = fin && fabs(g) <= 1.7e308; }
+            }
+        }
+        f_cur = wave_sum(a_f); th_cur = wave_sum(a_th);
+        inf_pr = wave_max(a_pr); inf_du = wave_max(a_du); zmax = wave_max(a_z); lmax = wave_max(a_l);
+        finite = __all(fin);
+    };
+
     // ---- main loop.  Every trip runs ONE backward sweep (the lambdas above have a single call site each: one copy of the sweep code).
     // phase 0 (cold start only): IPOPT's least-squares multiplier estimate (constr_mult_init_max = 1000),
     //     [I A'; A 0] [w; lambda] = -[grad f; 0]  - the same sweep with W = I and no defects; phase 1: the iteration.
     int st = 0, it = 0, nfilt = 0, conv = 0, phase = warm ? 1 : 0;
     double hs = warm ? 1.0 : 0.0, dw = warm ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
     for (;;) {
+        if (phase == 1 && dw == 0.0) {              // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
+            residuals();
+            if (!finite) { st |= PDP_STATUS_NONFINITE; break; }
+            if (it == 0) { theta_max = 1e4 * fmax(1.0, th_cur); theta_min = 1e-4 * fmax(1.0, th_cur); }
+            if (inf_pr <= op.tol * (1.0 + zmax) && inf_du <= op.tol * (1.0 + lmax)) { conv = 1; if (!gains_out) break; }
+            else if (it >= op.max_iter) { st |= PDP_MS_MAXITER; break; }
+        }
         const bool pd = backward(hs, dw);
+        if (conv) break;                            // (the sweep at the solution left the LQR gains in the workspace)
         if (phase == 0) {
             if (!(pd && finite)) { phase = 1; hs = 1.0; dw = 0.0; continue; }
         } else {
@@ -393,9 +439,6 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                 if (dw > 1e20) { st |= PDP_MS_INERTIA; break; }
                 continue;
             }
-            if (it == 0) { theta_max = 1e4 * fmax(1.0, th_cur); theta_min = 1e-4 * fmax(1.0, th_cur); }
-            if (inf_pr <= op.tol * (1.0 + zmax) && inf_du <= op.tol * (1.0 + lmax)) { conv = 1; break; }
-            if (it >= op.max_iter) { st |= PDP_MS_MAXITER; break; }
             if (dw > 0.0) dw_last = dw;
         }
         const double gd = forward(hs);

@@ -163,7 +163,8 @@ def lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=None, Hxu=None, Hxe=None, Hue=None, X0
         mat, t = _mat(val, B, tv)
         setattr(pr, name, mat)
         keep.append(t)
-    pmax = 64 - m                      # parameter columns one launch of the kernel carries (4 tiles of 16, the first shared with the controls)
+    # parameter columns one launch carries: 4 tiles of 16 (the first shared with the controls) in the tile kernels, 32 in the generic one
+    pmax = 64 - m if (n <= 16 and m <= 4) else 32
     if p > pmax:
         # more columns than the kernel's tiles hold (a neural policy's auxvar, a wide X0): the columns of (E, Hxe, Hue, hxe, X0) -> (X, U, Lam)
         # are independent given the gains, so the problem is solved in column blocks (each launch repeats the n x n backward recursion)

@@ -87,7 +87,7 @@ def test_nonfinite_input_raises_status_flag_only_for_that_sample():
 
 def test_lqr_maximum_sizes_and_limits():
     """n = 16, m = 4, p = 60 (= 64 - m) is the largest problem of ONE launch of pdp_lqr_solve_batched; more parameter columns are solved in
-    column blocks by the class surface; n > 16 / m > 4 return PDP_E_SIZE"""
+    column blocks by the class surface; 16 < n <= 32 / 4 < m <= 8 take the generic kernel (test below), beyond that PDP_E_SIZE"""
     from oracle import pdp_oracle as po
     from pdp_amd import runtime as rt
     rng = np.random.default_rng(2)
@@ -120,7 +120,37 @@ def test_lqr_maximum_sizes_and_limits():
     pr.B, pr.T, pr.n, pr.m, pr.p = 1, 2, 4, 1, 64
     assert core.pdp_lqr_solve_batched(__import__("ctypes").byref(pr), None, None, None, None, None, 0, None) in (-1, -2)
     with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
-        rt.lqr_solve(np.zeros((1, 2, 17, 17)), np.zeros((1, 2, 17, 1)), np.zeros((1, 2, 17, 17)), np.ones((1, 2, 1, 1)), np.zeros((1, 17, 17)), np.zeros((1, 17, 1)))
+        rt.lqr_solve(np.zeros((1, 2, 33, 33)), np.zeros((1, 2, 33, 1)), np.zeros((1, 2, 33, 33)), np.ones((1, 2, 1, 1)), np.zeros((1, 33, 33)), np.zeros((1, 33, 1)))
+    with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
+        rt.lqr_solve(np.zeros((1, 2, 12, 12)), np.zeros((1, 2, 12, 9)), np.zeros((1, 2, 12, 12)), np.ones((1, 2, 9, 9)), np.zeros((1, 12, 12)), np.zeros((1, 12, 1)))
+
+
+@pytest.mark.parametrize("n,m,p", [(20, 3, 11), (17, 1, 5), (12, 6, 45), (32, 8, 32), (9, 5, 70)])
+def test_lqr_beyond_one_tile_per_matrix(n, m, p):
+    """16 < n <= 32 or 4 < m <= 8: the generic LDS kernel (lqr_solve_generic_kernel), any p through column blocks - the reference's
+    lqrSolver accepts any size (PDP.py:446-555).  Against the numpy restatement, incl. costates, broadcast and optional inputs."""
+    from oracle import pdp_oracle as po
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(7 * n + m)
+    T, B = 7, 3
+
+    def spd(k, s):
+        A = rng.standard_normal((k, k))
+        return s * (A @ A.T / k + 0.5 * np.eye(k))
+    F = np.eye(n) + 0.1 * rng.standard_normal((B, T, n, n)); G = 0.3 * rng.standard_normal((B, T, n, m)); E = 0.1 * rng.standard_normal((B, T, n, p))
+    Hxx = np.stack([np.stack([spd(n, 1.0) for _ in range(T)]) for _ in range(B)]); Huu = np.stack([np.stack([spd(m, 0.5) for _ in range(T)]) for _ in range(B)])
+    Hxu = 0.05 * rng.standard_normal((B, T, n, m)); Hxe, Hue = 0.2 * rng.standard_normal((B, T, n, p)), 0.2 * rng.standard_normal((B, T, m, p))
+    hxx = np.stack([spd(n, 1.0) for _ in range(B)]); hxe, X0 = 0.2 * rng.standard_normal((B, n, p)), rng.standard_normal((B, n, p))
+    X, U, Lam, st = rt.lqr_solve(F, G, Hxx, Huu, hxx, hxe, E=E, Hxu=Hxu, Hxe=Hxe, Hue=Hue, X0=X0)
+    assert int(st.sum()) == 0
+    for b in range(B):
+        sol = po.lqr_solver(list(F[b]), list(G[b]), list(E[b]), list(Hxx[b]), list(Huu[b]), list(Hxu[b]), list(Hxe[b]), list(Hue[b]), [hxx[b]], [hxe[b]], X0[b], T)
+        assert rel(npy(X)[b], np.stack(sol["state_traj_opt"])) < TOL and rel(npy(U)[b], np.stack(sol["control_traj_opt"])) < TOL
+        assert rel(npy(Lam)[b], np.stack(sol["costate_traj_opt"])) < TOL
+    X3, U3, _, st3 = rt.lqr_solve(F[0, 0], G[0, 0], Hxx[0, 0], Huu[0, 0], hxx, hxe, T=T, want_costate=False)
+    Z = lambda r, c: T * [np.zeros((r, c))]
+    sol = po.lqr_solver(T * [F[0, 0]], T * [G[0, 0]], Z(n, p), T * [Hxx[0, 0]], T * [Huu[0, 0]], Z(n, m), Z(n, p), Z(m, p), [hxx[1]], [hxe[1]], np.zeros((n, p)), T)
+    assert int(st3.sum()) == 0 and rel(npy(X3)[1], np.stack(sol["state_traj_opt"])) < TOL and rel(npy(U3)[1], np.stack(sol["control_traj_opt"])) < TOL
 
 
 def test_sysid_ragged_batch_and_empty_gradient_directions(golden_dir):
