@@ -436,7 +436,7 @@ def _build(out, deps, cmd_tail, force, flags=None):
 
 def compile_model(name, force=False):
     """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
-    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
+    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_fused2_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
     return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)

@@ -11,8 +11,14 @@
 #include "pdp_model_kernels.h"
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"
+#include "pdp_fused2_kernels.h"
+#include <cstdlib>
 
 using namespace pdp;
+
+#ifndef PDP_FUSED_DEFAULT_VARIANT
+#define PDP_FUSED_DEFAULT_VARIANT 1
+#endif
 
 namespace {
 
@@ -81,8 +87,17 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         if (wsb < oc_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
         const size_t lds = fused_lds_bytes<Mdl>(T);
         if (lds > 160 * 1024) return PDP_E_SIZE;
-        (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // PDP_FUSED_VARIANT=2 (environment): two wavefronts per trajectory (pdp_fused2_kernels.h); systems with n <= 4 always take the
+        // one-wave kernel (its small-system algebra has nothing to split)
+        static const int variant = [] { const char* e = std::getenv("PDP_FUSED_VARIANT"); return e ? std::atoi(e) : PDP_FUSED_DEFAULT_VARIANT; }();
         PDP_CLEAR();
+        if (variant == 2 && Mdl::NX > 4) {
+            (void)hipFuncSetAttribute((const void*)oc_pdp_fused2_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((oc_pdp_fused2_kernel<Mdl>), dim3(B), dim3(128), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
+                               dudp, status, (double*)ws);
+            return launched();
+        }
+        (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
                            dudp, status, (double*)ws);
         return launched();
