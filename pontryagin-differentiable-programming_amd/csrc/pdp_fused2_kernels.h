@@ -125,6 +125,21 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
     const double* ub = u + (int64_t)b * T * NU;
     double* gw = ws_gain + (int64_t)b * T * GSZ;
     const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
+#ifdef PDP_PHASE_TIMING     // debug builds (probes/phase_timing2.py): cycle stamps of workgroup 0 behind loss[B]
+    long long ts[8], fs[8], acc_t[4] = {0, 0, 0, 0};
+    int nts = 0;
+    for (int i = 0; i < 8; ++i) { ts[i] = 0; fs[i] = 0; }
+#define F2_STAMP() ts[nts++] = __builtin_readcyclecounter()
+#define F2_FINE(i, cond) if (cond) fs[i] = __builtin_readcyclecounter()
+#define F2_ACC(k, t_) acc_t[k] += __builtin_readcyclecounter() - (t_)
+#define F2_NOW() __builtin_readcyclecounter()
+#else
+#define F2_STAMP()
+#define F2_FINE(i, cond)
+#define F2_ACC(k, t_)
+#define F2_NOW() 0
+#endif
+    F2_STAMP();
 
     // ---------------- rollout (wave A), staged in the still unused pool, written out coalesced --------------------------------
     if (!given && waveA) {
@@ -161,6 +176,7 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // x is re-read below by both waves
     }
     wg_sync();
+    F2_STAMP();
 
     // ---------------- terminal condition: P = hxx(x_T) (both waves), W = hxe(x_T) (wave B), lambda_T (wave A) -------------------
     bool ok = true;
@@ -194,6 +210,7 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
         wg_sync();
     }
 
+    F2_STAMP();
     // ---------------- backward sweep ------------------------------------------------------------------------------------------------
     {
         if (waveA) {
@@ -224,6 +241,7 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
         for (int c = nchunk - 1; c >= 0; --c) {
             const int t0 = c * ch, cnt = min(ch, T - t0);
             wg_sync();                                  // the pool of the previous chunk is no longer read
+            [[maybe_unused]] const long long tc0 = F2_NOW();
             if (waveA && lane < cnt) {                  // (A) lane = time step: F, G, E, c_x at (x_t, u_t)
                 PDP_F2_PAR();
                 const int t = t0 + lane;
@@ -246,6 +264,8 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
                 }
             }
             wg_sync();
+            F2_ACC(0, tc0);
+            [[maybe_unused]] const long long tc1 = F2_NOW();
             if (!waveA && lane < cnt) {                 // (B) lane = time step (wave B): Hamiltonian Hessians at (x_t, u_t, lambda_{t+1})
                 PDP_F2_PAR();
                 const int t = t0 + lane;
@@ -266,39 +286,47 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
                 Mdl::eval_pathb(xc, uc, lc, th, pc, s);
             }
             wg_sync();
+            F2_ACC(1, tc1);
+            [[maybe_unused]] const long long tc2 = F2_NOW();
             // Riccati steps: two halves per step, meeting at the Z / Qux mailboxes and at the symmetrisation buffer
             GatherRun rF = gather_at(gF, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), r3 = gather_at(g3, cnt - 1, blk), r4 = gather_at(g4, cnt - 1, blk),
                       r5 = gather_at(g5, cnt - 1, blk);
+            // operand tiles of step tl-1 are gathered while step tl waits at its mailboxes (the pool is read-only inside the chunk)
+            d4 Ft = gather_run(rF, -1), Grep = gather_run(rGr, -1), O3 = waveA ? gather_run<1>(r3, -1) : gather_run(r3, -1), O4 = gather_run(r4, -1),
+               O5 = waveA ? z : gather_run<1>(r5, -1);
             for (int tl = cnt - 1; tl >= 0; --tl) {
                 const int t = t0 + tl;
-                const d4 Ft = gather_run(rF, -1), Grep = gather_run(rGr, -1);
-                d4 Pn = z, FY = z;
+                F2_FINE(0, t == 20);
+                d4 Pn = z, PY2 = z, Pm = z;
                 double Qux0 = 0.0, IK0 = 0.0;
+                const d4 Fc = Ft, Gc = Grep, C3 = O3, C4 = O4, C5 = O5;
                 if (waveA) {
-                    const d4 Hux = gather_run<1>(r3, -1), Hxx = gather_run(r4, -1);
-                    const d4 PF = mma_tn(P, Ft, z);                     // P F
-                    Qux0 = mma4_tn(Grep, PF, Hux[0]);                   // Qux = Hux + G' P F
-                    Pn = mma_tn(Ft, PF, Hxx);                           // Hxx + F' P F
+                    const d4 PF = mma_tn(P, Fc, z);                     // P F
+                    Qux0 = mma4_tn(Gc, PF, C3[0]);                      // Qux = Hux + G' P F
+                    Pn = mma_tn(Fc, PF, C4);                            // Hxx + F' P F
                     Qx[lane] = Qux0;
-                } else {
-                    const d4 Y2 = gather_run(r3, -1), HX2 = gather_run(r4, -1), HU2 = gather_run<1>(r5, -1);
-                    const d4 PY2 = mma_tn(P, Y2, W2);                   // [P G | P E + W]
-                    FY = mma_tn(Ft, PY2, HX2);                          // [Qux' | Wn]
-                    const double Q20 = mma4_tn(Grep, PY2, HU2[0]);      // [Quu | Que]
+                } else {                                                // the m x m solve is the critical path of a step: nothing else in front of it
+                    PY2 = mma_tn(P, C3, W2);                            // [P G | P E + W]
+                    const double Q20 = mma4_tn(Gc, PY2, C5[0]);         // [Quu | Que]
+                    F2_FINE(6, t == 20);
                     const double Zrep = quu_inverse_rep<M>(Q20, scratch, lane, ok);
+                    F2_FINE(7, t == 20);
                     IK0 = mma4_blk(Zrep, Q20, 0.0);                     // [I | k]
                     Zx[lane] = Zrep;
                 }
+                F2_FINE(1, t == 20);
                 wg_sync();
+                F2_FINE(2, t == 20);
                 if (waveA) {
                     const double Zrep = Zx[lane];
                     d4 Qux = z, K = z;
                     Qux[0] = Qux0;
                     K[0] = mma4_blk(Zrep, Qux0, 0.0);                   // K = Quu^-1 Qux
-                    const d4 Pm = mms_tn_r0(Qux, K, Pn);                // Hxx + F'PF - Qux'K
+                    Pm = mms_tn_r0(Qux, K, Pn);                         // Hxx + F'PF - Qux'K
                     tile_to_lds17(Pbuf, Pm, lane);
                     store_all<1>(gw + t * GSZ, mK, K);
                 } else {
+                    const d4 FY = mma_tn(Fc, PY2, C4);                  // [Qux' | Wn]   (off the path to Z: after the mailbox)
                     d4 Qux = z, IK = z;
                     Qux[0] = Qx[lane];
                     IK[0] = IK0;
@@ -307,11 +335,24 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
                     IK = keep_cols(IK, M, M + NP, lane);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, IK);
                 }
+                if (tl > 0) {                                           // next step's operands (no LDS read below the first pool row)
+                    Ft = gather_run(rF, -1); Grep = gather_run(rGr, -1); O4 = gather_run(r4, -1);
+                    if (waveA) O3 = gather_run<1>(r3, -1); else { O3 = gather_run(r3, -1); O5 = gather_run<1>(r5, -1); }
+                }
+                F2_FINE(3, t == 20);
                 wg_sync();
-                P = 0.5 * (tile_from_lds17(Pbuf, lane) + tile_from_lds17_transposed(Pbuf, lane));     // both waves: P <- (P + P')/2
+                F2_FINE(4, t == 20);
+                // both waves: P <- (P + P')/2   (wave A still holds P- in registers and reads only the transpose back)
+                P = 0.5 * ((waveA ? Pm : tile_from_lds17(Pbuf, lane)) + tile_from_lds17_transposed(Pbuf, lane));
+                F2_FINE(5, t == 20);
             }
+            F2_ACC(2, tc2);
         }
     }
+    F2_STAMP();
+#ifdef PDP_PHASE_TIMING
+    if (!waveA && lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 32; for (int i = 0; i < 8; ++i) o[i] = fs[i]; }
+#endif
     bool finite = tile_finite(P) && tile_finite(W2);
     if (!waveA && lane == 0) { fl[0] = ok ? 1.0 : 0.0; }
     if (!waveA) { const bool f = __all(finite); if (lane == 0) fl[1] = f ? 1.0 : 0.0; }
@@ -390,6 +431,15 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
     if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
     if (!ok) st |= PDP_STATUS_PIVOT;
     if (lane == 0 && status) status[b] = st;
+#ifdef PDP_PHASE_TIMING
+    F2_STAMP();
+    if (lane == 0 && b == 0) {
+        long long* o = (long long*)(loss + B);
+        for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        for (int i = 0; i < 8; ++i) o[8 + i] = fs[i];
+        for (int i = 0; i < 4; ++i) o[16 + i] = acc_t[i];
+    }
+#endif
 #undef PDP_F2_PAR
 }
 
