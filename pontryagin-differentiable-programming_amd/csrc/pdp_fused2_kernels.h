@@ -235,7 +235,7 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
             make_gather(g5, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
                 return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });                      // [Huu|Hue]
         }
-        const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, fused_gain0_doubles<Mdl>() - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;
         for (int c = nchunk - 1; c >= 0; --c) {
@@ -378,7 +378,7 @@ oc_pdp_fused2_kernel(int B, int T, int flags, const double* __restrict__ x0, con
         const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
         const double* dub = demo_u + (int64_t)b * T * NU;
         d4 X2 = z;
-        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), fused_gain0_doubles<Mdl>() - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         d4 KTn = -load_all<4>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;

@@ -433,8 +433,21 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
 
 // feedback gains of one step in the workspace: K [NU x NX], k [NU x NP], and one slot that receives (and hands back) the zeros of
 // the tile elements outside those blocks
+// Closed-loop forward sweep (systems with n > 4): the backward step also leaves Acl = F - G K and ecl = E - G k in the workspace, so the
+// forward recursion is X+ = Acl X + ecl - ONE 16x16x16 product per step on the critical path instead of U = -K X - k followed by
+// X+ = F X + G U + E, and no evaluation pass of F, G, E at all (U is still formed, off the chain, for the gradient).  Costs two rank-m
+// MFMAs and 8 stores per backward step and 2.3 KB instead of 0.7 KB of scratch per step; -DPDP_FUSED_NO_CLOSED_LOOP restores the open-loop form.
+#ifdef PDP_FUSED_NO_CLOSED_LOOP
+template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return false; }
+#else
+template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return Mdl::NX > 4; }
+#endif
 template <class Mdl>
-__host__ __device__ constexpr int fused_gain_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }
+__host__ __device__ constexpr int fused_gain0_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }      // K | k | zero sink
+template <class Mdl>
+__host__ __device__ constexpr int fused_gain_doubles() {
+    return fused_gain0_doubles<Mdl>() + (fused_closed_loop<Mdl>() ? Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1 : 0);              // + Acl | ecl | zero sink
+}
 
 // experiment hooks (probes/occupancy_variant.py): -DPDP_FUSED_CHUNK=<steps per chunk> shrinks the LDS pool, -DPDP_FUSED_WAVES=<n> asks the
 // register allocator for n waves per SIMD (n = 2: 256 registers per wave, VGPRs + AGPRs together)
@@ -488,6 +501,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
     // left operands are gathered in "rep" form (the 4 x 4 block replicated in the four column blocks), only register 0 of a tile is live
     constexpr bool SMALL = NX <= 4;
     constexpr int NRT = SMALL ? 1 : 4;                  // live registers of an n-row tile
+    constexpr bool CLF = fused_closed_loop<Mdl>();      // closed-loop forward sweep (see fused_closed_loop)
+    constexpr int GSZ0 = fused_gain0_doubles<Mdl>();
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
     double* blk = lds + RICCATI_SCRATCH;                // [cpool (NC) | pool]
@@ -626,7 +641,11 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         make_gather(gHU, lane, L::NC, L::BSTRIDE, [&](int r, int c) {
             return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
         // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
-        const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        // closed-loop matrices behind the gains: Acl [NX x NX] | ecl [NX x NP] | zero sink
+        const TileMapBytes mAcl = make_tile_map_sink(NX, NX, NX, 0, 0, lane, NX * NX + NX * NP), mEcl = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
+        Gather gGTb;                                      // G' (m x n, rows 0..3): left operand of the rank-m products G K and G k
+        make_gather(gGTb, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (CLF && r < M && c < NX) ? codeA(1, c * NU + r) : -1; });
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
@@ -715,7 +734,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             PDP_ACC(2);
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
-                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
+                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk),
+                      rGTb = gather_at(gGTb, cnt - 1, blk);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
             // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The last step
             // of a chunk prefetches nothing (no LDS read outside the pool).  Two steps per trip with the prefetched tiles alternating
@@ -750,10 +770,18 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 } else {
                 RiccatiGains g;
                 d4 P_old;
+                [[maybe_unused]] d4 GTb = z;
+                if constexpr (CLF) GTb = gather_run<1>(rGTb, -1);
                 ok = riccati_backward<M, false>(P, W2, Fu, Yu, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
+                if constexpr (CLF) {                     // Acl = F - G K, ecl = E - G k for the forward sweep (off this step's critical path)
+                    const d4 Acl = mms_tn_r0(GTb, g.K, Fu);
+                    const d4 Ecl = keep_cols(mms_tn_r0(GTb, g.IK, Yu), M, M + NP, lane);
+                    store_all(gw + t * GSZ + GSZ0, mAcl, Acl);
+                    store_all(gw + t * GSZ + GSZ0 + NX * NX, mEcl, Ecl);
+                }
                 }
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
@@ -769,7 +797,63 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
 
     // ---------------- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, loss and gradient -----------
     double acc = 0.0, lsum = 0.0;
-    {
+    if constexpr (CLF) {
+        // closed-loop form: X+ = Acl X + ecl with the matrices the backward sweep left in the workspace; the pool only carries
+        // x - x_demo, u - u_demo per step (one lane-per-step pass per 64 steps, no model evaluation)
+        wave_lds_sync();
+        if (lane == 0) blk[0] = 0.0;
+        constexpr int FS2 = (NX + NU) | 1;
+        Gather gDX, gDU;
+        make_gather(gDX, lane, L::NC, FS2, [](int r, int c) { return (r < NX) ? r : -1; });
+        make_gather(gDU, lane, L::NC, FS2, [](int r, int c) { return (r < M) ? NX + r : -1; });
+        const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
+        const double* dub = demo_u + (int64_t)b * T * NU;
+        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP),
+                           mAT = to_bytes_sink(make_dense_map<true>(NX, NX, NX, 0, 0, lane), NX * NX + NX * NP), mEc = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
+        d4 X2 = z;
+        d4 KTn = -load_all<4>(gw, mKT), kn = -load_all<1>(gw + NX * NU, mIK), An = load_all<4>(gw + GSZ0, mAT), En = load_all<4>(gw + GSZ0 + NX * NX, mEc);
+        const int cap = fused_pool_doubles<Mdl>(T) / FS2;
+        const int ch2 = cap < 64 ? cap : 64;
+        for (int t0 = 0; t0 < T; t0 += ch2) {
+            const int cnt = min(ch2, T - t0);
+            wave_lds_sync();
+            if (lane < cnt) {
+                const int t = t0 + lane;
+                double* row = pool + lane * FS2;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { const double d = xb[t * NX + i] - dxb[t * NX + i]; row[i] = d; lsum += d * d; }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { const double d = ub[t * NU + i] - dub[t * NU + i]; row[NX + i] = d; lsum += d * d; }
+            }
+            wave_lds_sync();
+            GatherRun rDX = gather_at(gDX, 0, blk), rDU = gather_at(gDU, 0, blk);
+            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, const d4 Ac, const d4 Ec, d4& KTnx, d4& knx, d4& Anx, d4& Enx) {
+                const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
+                KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
+                knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
+                Anx = load_all<4>(gw + tnx * GSZ + GSZ0, mAT);
+                Enx = load_all<4>(gw + tnx * GSZ + GSZ0 + NX * NX, mEc);
+                const d4 DX = gather_run(rDX, 1), DU = gather_run<1>(rDU, 1);
+                Xn = mma_tn(Ac, Xc, Ec);                  // X+ = Acl X + ecl: the only product on the chain
+                d4 U2 = z;
+                U2[0] = mma4_tn(KTc, Xc, kc[0]);          // U = -K X - k (for the gradient and the dudp output)
+                acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
+                if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
+                if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+            };
+            d4 Xb, KTb, kb, Ab, Eb;
+            int tl = 0;
+            for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, An, En, KTb, kb, Ab, Eb); fstep(tl + 1, Xb, X2, KTb, kb, Ab, Eb, KTn, kn, An, En); }
+            if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, An, En, KTb, kb, Ab, Eb); X2 = Xb; KTn = KTb; kn = kb; An = Ab; En = Eb; }
+        }
+        wave_lds_sync();
+        if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
+        if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + T) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+        finite = finite && tile_finite(X2);
+    } else {
         wave_lds_sync();
         for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blk[1 + i_] = Mdl::fwd_const(i_);
         constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
@@ -786,7 +870,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         d4 X2 = z;
         // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored)
         // K is read back transposed and replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
-        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         d4 KTn = -load_all<NRT>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
         const int nchunk = (T + CH - 1) / CH;
