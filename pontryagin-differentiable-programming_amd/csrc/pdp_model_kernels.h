@@ -433,14 +433,17 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
 
 // feedback gains of one step in the workspace: K [NU x NX], k [NU x NP], and one slot that receives (and hands back) the zeros of
 // the tile elements outside those blocks
-// Closed-loop forward sweep (systems with n > 4): the backward step also leaves Acl = F - G K and ecl = E - G k in the workspace, so the
-// forward recursion is X+ = Acl X + ecl - ONE 16x16x16 product per step on the critical path instead of U = -K X - k followed by
-// X+ = F X + G U + E, and no evaluation pass of F, G, E at all (U is still formed, off the chain, for the gradient).  Costs two rank-m
-// MFMAs and 8 stores per backward step and 2.3 KB instead of 0.7 KB of scratch per step; -DPDP_FUSED_NO_CLOSED_LOOP restores the open-loop form.
-#ifdef PDP_FUSED_NO_CLOSED_LOOP
-template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return false; }
-#else
+// Closed-loop forward sweep - an EXPERIMENT, off by default (-DPDP_FUSED_CLOSED_LOOP enables it for n > 4): the backward step also leaves
+// Acl = F - G K and ecl = E - G k in the workspace, so that the forward recursion is X+ = Acl X + ecl - one 16x16x16 product per step on the
+// critical path instead of U = -K X - k followed by X+ = F X + G U + E, and no evaluation pass of F, G, E in the forward sweep.  Parity-green,
+// but slower (C3: 0.134 - 0.137 ms against 0.119 ms): the two rank-m MFMAs and 8 stores cost 350 cycles per backward step, and the forward
+// sweep then has to pull 114 KB per trajectory (117 MB per launch) through L2 / HBM in ~25 us - it runs AT the memory system's limit
+// (~4.5 TB/s) whatever the prefetch distance (profiles/r02_closed_loop_forward.txt).  The open-loop form recomputes F, G, E from 1.3 KB of
+// x, u per trajectory instead, which is why it wins.
+#ifdef PDP_FUSED_CLOSED_LOOP
 template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return Mdl::NX > 4; }
+#else
+template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return false; }
 #endif
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain0_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }      // K | k | zero sink
@@ -811,7 +814,19 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP),
                            mAT = to_bytes_sink(make_dense_map<true>(NX, NX, NX, 0, 0, lane), NX * NX + NX * NP), mEc = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
         d4 X2 = z;
-        d4 KTn = -load_all<4>(gw, mKT), kn = -load_all<1>(gw + NX * NU, mIK), An = load_all<4>(gw + GSZ0, mAT), En = load_all<4>(gw + GSZ0 + NX * NX, mEc);
+        // a step is one product (~350 cycles) but its operands come from HBM / L2 (~1000 cycles away): they are requested THREE steps ahead,
+        // four register sets in rotation, four steps per trip
+        struct FSet { d4 KT, k, A, E; };
+        auto request = [&](int t) {
+            const int tc = t < T ? t : T - 1;
+            FSet f;
+            f.KT = -load_all<4>(gw + tc * GSZ, mKT);
+            f.k = -load_all<1>(gw + tc * GSZ + NX * NU, mIK);
+            f.A = load_all<4>(gw + tc * GSZ + GSZ0, mAT);
+            f.E = load_all<4>(gw + tc * GSZ + GSZ0 + NX * NX, mEc);
+            return f;
+        };
+        FSet s0 = request(0), s1 = request(1), s2 = request(2), s3 = s2;
         const int cap = fused_pool_doubles<Mdl>(T) / FS2;
         const int ch2 = cap < 64 ? cap : 64;
         for (int t0 = 0; t0 < T; t0 += ch2) {
@@ -827,24 +842,21 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             }
             wave_lds_sync();
             GatherRun rDX = gather_at(gDX, 0, blk), rDU = gather_at(gDU, 0, blk);
-            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, const d4 Ac, const d4 Ec, d4& KTnx, d4& knx, d4& Anx, d4& Enx) {
-                const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
-                KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
-                knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                Anx = load_all<4>(gw + tnx * GSZ + GSZ0, mAT);
-                Enx = load_all<4>(gw + tnx * GSZ + GSZ0 + NX * NX, mEc);
+            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const FSet& f, FSet& far) {
+                const int t = t0 + tl;
+                far = request(t + 3);
                 const d4 DX = gather_run(rDX, 1), DU = gather_run<1>(rDU, 1);
-                Xn = mma_tn(Ac, Xc, Ec);                  // X+ = Acl X + ecl: the only product on the chain
+                Xn = mma_tn(f.A, Xc, f.E);                // X+ = Acl X + ecl: the only product on the chain
                 d4 U2 = z;
-                U2[0] = mma4_tn(KTc, Xc, kc[0]);          // U = -K X - k (for the gradient and the dudp output)
+                U2[0] = mma4_tn(f.KT, Xc, f.k[0]);        // U = -K X - k (for the gradient and the dudp output)
                 acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
                 if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                 if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
             };
-            d4 Xb, KTb, kb, Ab, Eb;
+            d4 Xb;
             int tl = 0;
-            for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, An, En, KTb, kb, Ab, Eb); fstep(tl + 1, Xb, X2, KTb, kb, Ab, Eb, KTn, kn, An, En); }
-            if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, An, En, KTb, kb, Ab, Eb); X2 = Xb; KTn = KTb; kn = kb; An = Ab; En = Eb; }
+            for (; tl + 3 < cnt; tl += 4) { fstep(tl, X2, Xb, s0, s3); fstep(tl + 1, Xb, X2, s1, s0); fstep(tl + 2, X2, Xb, s2, s1); fstep(tl + 3, Xb, X2, s3, s2); }
+            for (; tl < cnt; ++tl) { fstep(tl, X2, Xb, s0, s3); X2 = Xb; s0 = s1; s1 = s2; s2 = s3; }      // (at most three steps: the sets move up by copies)
         }
         wave_lds_sync();
         if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
