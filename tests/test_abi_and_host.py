@@ -149,3 +149,34 @@ def test_sx_casadi_semantics():
     Jf = sx.Function("J", [x], [J])
     assert np.allclose(Jf([0.3, -0.2, 1.5]).full(), [[-0.2 * (1 - np.tanh(-0.06) ** 2), 0.3 * (1 - np.tanh(-0.06) ** 2), 3.0]])
     assert float(sx.inv(sx.SX(np.array([[2.0, 0.0], [0.0, 4.0]])))[1, 1]) == 0.25
+
+
+def test_ocsolver_rejects_finite_bounds_and_new_entry_points_validate_arguments(built):
+    """(i) the reference passes state / control bounds to IPOPT as lbw / ubw (PDP.py:141-168); the GPU solvers handle the equality-
+    constrained NLP only, so finite bounds raise instead of being silently ignored (the +-1e20 defaults mean "none", as for IPOPT);
+    (ii) pdp_oc_solve_ms_batched / its workspace entry point are host-side and validate their arguments without a GPU."""
+    from pdp_amd import PDP, runtime, zoo
+    from pdp_amd.sx import SX, vertcat
+    x, u, w = SX.sym("x", 2), SX.sym("u"), SX.sym("w")
+    oc = PDP.OCSys("bounded")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(x)
+    oc.setControlVariable(u, control_lb=[-1.0], control_ub=[1.0])
+    oc.setDyn(x + 0.1 * vertcat(x[1], u))
+    oc.setPathCost(w * (x[0] * x[0] + u * u))
+    oc.setFinalCost(x[0] * x[0])
+    with pytest.raises(NotImplementedError, match="control_lb"):
+        oc.ocSolver([1.0, 0.0], 5, [1.0])
+    oc.setControlVariable(u)                      # defaults: +-1e20
+    oc._check_unbounded()
+    lib, info = built[0].build_problem(zoo.make_problem("pendulum", "irl"))
+    m = runtime.ModelLib(lib)
+    B, T = 7, 30
+    n0, n1 = m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 0), m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 100)
+    per = (T + 1) * 2 + T * 1 + T * 2 + T * 2 + (T + 1) * 2 + T * 1 + T * (2 * 1 + 1 + 1) + T * (4 + 2 + 1)     # dx du dlam c gradx gradu gains P,W
+    assert n0 == 8 * B * (per + 2) and n1 - n0 == 8 * B * 2 * 100
+    opts = runtime.PdpOcMsOpts(1e-10, 100, 0, 0)
+    import ctypes
+    assert m.lib.pdp_oc_solve_ms_batched(0, T, None, None, 0, None, None, None, None, None, None, None, None, None, None, ctypes.byref(opts), None, 0, None) == -1
+    cp = runtime.ModelLib(built[0].build_problem(zoo.make_problem("pendulum", "oc"))[0])
+    assert cp.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 10) == 0
