@@ -35,6 +35,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "
 # out-of-bounds global reads on guard-banded operands, gone at -O1 and gone without the option (probes/lqr_oob_probe.py, DESIGN.md section 8;
 # profiles/r02_lqr_oob_root_cause.txt).  The kernel is HBM-bound: the option bought nothing there.
 CORE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("PDP_HIP_EXTRA_FLAGS", "").split()
+TUNED_LABELS = ("pendulum", "cartpole", "robotarm", "quadrotor", "rocket")        # zoo.py: the reference's five benchmark systems
 # OC models (the fused kernel): loop strength reduction rewrites the running LDS addresses of the step loops as (induction variable + 0)
 # and leaves a `v_add_u32 v, 0, v` in front of every ds_read (39 VALU instructions per time step); the loops already carry their own
 # running addresses.  Measured: fused kernel +5 % without LSR; the SysID / ControlPlanning kernels lose up to 12 % -> OC models only.
@@ -439,7 +440,10 @@ def compile_model(name, force=False):
     deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_fused2_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
-    return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force)
+    # -amdgpu-mfma-vgpr-form (hidden LLVM option, +4 % on the headline kernel, but see CORE_FLAGS above) only for the benchmark systems,
+    # whose kernels are parity-tested one by one on NaN-dirtied memory; a user's model is built with plain -O3
+    flags = HIP_FLAGS if name.split("_")[0] in TUNED_LABELS else CORE_FLAGS
+    return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force, flags=flags)
 
 
 def compile_core(force=False):
