@@ -426,36 +426,67 @@ class ModelLib:
         rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
                                               ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
         if rc == -2 and self.n <= 16 and self.m <= 4:
-            # m + p > 16: beyond the fused kernel's single parameter tile.  The reference's own route, kernel by kernel (PDP.py:272-314,
-            # 557-608 and the chain rule of cartpole_PDP.py:63-74): trajectory and costates, aux matrices to HBM, lqrSolver (column blocks
-            # for any p), contraction with (x - x_demo, u - u_demo)
-            if not (flags & 1):
-                x.copy_(self.oc_rollout(x0, u, theta, want_cost=False)[0])
-                lam.copy_(self.oc_costate(x, u, theta))
-            aux = self.oc_auxsys(x, u, lam, theta)
-            X, U, _, st = lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], aux["hxe"], E=aux["dynE"], Hxu=aux["Hxu"], Hxe=aux["Hxe"],
-                                    Hue=aux["Hue"], want_costate=False)
-            ex, eu = x - demo_x, u - demo_u
-            loss.copy_((ex ** 2).sum(dim=(1, 2)) + (eu ** 2).sum(dim=(1, 2)))
-            g = torch.empty((B, p), dtype=torch.float64, device="cuda")
-            core = load_core()
-            core.pdp_cp_grad_contract_batched.restype = C.c_int
-            core.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
-            ex_path, ex_fin, eu_c = ex[:, :T].contiguous(), ex[:, T].contiguous(), eu.contiguous()      # (named: they must outlive the launch)
-            check(core.pdp_cp_grad_contract_batched(B, T, n, m, p, ptr(ex_path), ptr(eu_c), ptr(ex_fin), ptr(X), ptr(U), ptr(g), current_stream_ptr()),
-                  "pdp_cp_grad_contract_batched")
-            grad.copy_(g)
+            # m + p > 16 (beyond the fused kernel's single parameter tile) or a horizon whose staging exceeds the LDS: the reference's own
+            # route, kernel by kernel
+            self._oc_pdp_grad_materialised(u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp, dudp)
             if packed:
                 pk[:, p].copy_(loss)
-            status.copy_(st)
-            if want_sens:
-                dxdp.copy_(X)
-                dudp.copy_(U)
             rc = 0
         check(rc, "pdp_oc_pdp_grad_batched")
         out = dict(loss=loss, grad=grad, x=x, lam=lam, status=status)
         if packed:
             out["packed"] = pk
+        if want_sens:
+            out.update(dxdp=dxdp, dudp=dudp)
+        return out
+
+    def _oc_pdp_grad_materialised(self, u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp=None, dudp=None):
+        """The PDP gradient unit by the reference's own route (PDP.py:272-314, 557-608 and the chain rule of cartpole_PDP.py:63-74), one
+        kernel per stage: trajectory and costates (unless given), aux matrices to HBM, lqrSolver (column blocks for any p), contraction
+        with (x - x_demo, u - u_demo).  Fills the given output tensors."""
+        torch = torch_cuda()
+        B, T = u.shape[0], u.shape[1]
+        n, m, p = self.n, self.m, self.p
+        if not (flags & 1):
+            x.copy_(self.oc_rollout(x0, u, theta, want_cost=False)[0])
+            lam.copy_(self.oc_costate(x, u, theta))
+        aux = self.oc_auxsys(x, u, lam, theta)
+        X, U, _, st = lqr_solve(aux["dynF"], aux["dynG"], aux["Hxx"], aux["Huu"], aux["hxx"], aux["hxe"], E=aux["dynE"], Hxu=aux["Hxu"], Hxe=aux["Hxe"],
+                                Hue=aux["Hue"], want_costate=False)
+        ex, eu = x - demo_x, u - demo_u
+        loss.copy_((ex ** 2).sum(dim=(1, 2)) + (eu ** 2).sum(dim=(1, 2)))
+        g = torch.empty((B, p), dtype=torch.float64, device="cuda")
+        core = load_core()
+        core.pdp_cp_grad_contract_batched.restype = C.c_int
+        core.pdp_cp_grad_contract_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7
+        ex_path, ex_fin, eu_c = ex[:, :T].contiguous(), ex[:, T].contiguous(), eu.contiguous()      # (named: they must outlive the launch)
+        check(core.pdp_cp_grad_contract_batched(B, T, n, m, p, ptr(ex_path), ptr(eu_c), ptr(ex_fin), ptr(X), ptr(U), ptr(g), current_stream_ptr()),
+              "pdp_cp_grad_contract_batched")
+        grad.copy_(g)
+        status.copy_(st)
+        if dxdp is not None:
+            dxdp.copy_(X)
+        if dudp is not None:
+            dudp.copy_(U)
+
+    def oc_pdp_grad_materialised(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False):
+        """same results as oc_pdp_grad through the materialised kernels (getAuxSys -> lqrSolver -> chain rule): the reference's data flow"""
+        torch = torch_cuda()
+        u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
+        B, T = u.shape[0], u.shape[1]
+        f64 = dict(dtype=torch.float64, device="cuda")
+        flags = 0
+        if x is not None:
+            x, lam, flags = dev(x).clone(), dev(lam).clone(), 1
+        else:
+            x0 = dev(x0).reshape(B, self.n)
+            x, lam = torch.empty((B, T + 1, self.n), **f64), torch.empty((B, T, self.n), **f64)
+        loss, grad = torch.empty((B,), **f64), torch.empty((B, self.p), **f64)
+        status = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        dxdp = torch.empty((B, T + 1, self.n, self.p), **f64) if want_sens else None
+        dudp = torch.empty((B, T, self.m, self.p), **f64) if want_sens else None
+        self._oc_pdp_grad_materialised(u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp, dudp)
+        out = dict(loss=loss, grad=grad, x=x, lam=lam, status=status)
         if want_sens:
             out.update(dxdp=dxdp, dudp=dudp)
         return out

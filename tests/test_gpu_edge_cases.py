@@ -253,3 +253,23 @@ def test_fused_unit_beyond_one_parameter_tile_takes_the_materialised_kernel_rout
     # and the gradient is the derivative of the loss through the trajectory only where theta enters the rollout: finite difference on a
     # dynamics parameter with the controls fixed differs (the PDP gradient differentiates the OPTIMAL control problem), so only shapes / finiteness here
     assert np.all(np.isfinite(npy(out["grad"])))
+
+
+def test_long_horizon_fused_unit_equals_the_materialised_route():
+    """T = 600 (the fused kernel's rollout staging: 82 KB of LDS per wave, 24 chunks) and T = 1500 (staging beyond the 160 KB of a CU: the
+    class surface takes the kernel-by-kernel route): both equal getAuxSys -> lqrSolver -> chain rule on the same trajectories."""
+    from pdp_amd import zoo
+    mdl = zoo.get("quadrotor", "irl")
+    rng = np.random.default_rng(9)
+    th = np.array([1, 1, 1, 1, .4, 1, 1, 5, 1.0])
+    for T in (600, 1500):
+        B = 2
+        x0 = np.zeros((B, 13)); x0[:, 2] = 1.0; x0[:, 6] = 1.0
+        u = 2.5 + 0.002 * rng.standard_normal((B, T, 4))
+        dx = np.zeros((B, T + 1, 13)); dx[:, :, 6] = 1.0
+        du = np.full((B, T, 4), 2.5)
+        a = mdl.oc_pdp_grad(u, th, dx, du, x0=x0)
+        b = mdl.oc_pdp_grad_materialised(u, th, dx, du, x0=x0)
+        assert int(a["status"].sum()) == 0 and int(b["status"].sum()) == 0
+        assert rel(npy(a["x"]), npy(b["x"])) < 1e-9 and rel(npy(a["lam"]), npy(b["lam"])) < 1e-9
+        assert rel(npy(a["loss"]), npy(b["loss"])) < 1e-12 and rel(npy(a["grad"]), npy(b["grad"])) < 1e-8
