@@ -425,9 +425,9 @@ class ModelLib:
         ws = buf("ws", (max(nbytes, 8) // 8,))
         rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
                                               ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
-        if rc == -2 and self.n <= 16 and self.m <= 4:
-            # m + p > 16 (beyond the fused kernel's single parameter tile) or a horizon whose staging exceeds the LDS: the reference's own
-            # route, kernel by kernel
+        if rc == -2 and self.n <= 32 and self.m <= 8:
+            # m + p > 16 (beyond the fused kernel's single parameter tile), n > 16 / m > 4 (beyond one tile per matrix: the generic LQR
+            # kernel takes over), or a horizon whose staging exceeds the LDS: the reference's own route, kernel by kernel
             self._oc_pdp_grad_materialised(u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp, dudp)
             if packed:
                 pk[:, p].copy_(loss)

@@ -275,3 +275,54 @@ def test_long_horizon_fused_unit_equals_the_materialised_route():
         assert int(a["status"].sum()) == 0 and int(b["status"].sum()) == 0
         assert rel(npy(a["x"]), npy(b["x"])) < 1e-9 and rel(npy(a["lam"]), npy(b["lam"])) < 1e-9
         assert rel(npy(a["loss"]), npy(b["loss"])) < 1e-12 and rel(npy(a["grad"]), npy(b["grad"])) < 1e-7
+
+
+def test_user_model_with_20_states_runs_the_whole_class_surface():
+    """n = 20, m = 5, p = 6 (a chain of ten masses with five actuators): beyond the tile kernels (n <= 16, m <= 4).  rollout, costates and
+    getAuxSys are size-generic, lqrSolver takes the generic LDS kernel, pdp_grad_batch the kernel-by-kernel route: against the numpy oracle."""
+    from oracle import pdp_oracle as po
+    from pdp_amd import PDP
+    from pdp_amd.sx import SX, vertcat, dot
+    rng = np.random.default_rng(21)
+    nm, m, dt, T, B = 10, 5, 0.05, 8, 3
+    q, v, U, w = SX.sym("q", nm), SX.sym("v", nm), SX.sym("u", m), SX.sym("w", 6)       # w: stiffness, damping, 4 cost weights
+    acc = []
+    for i in range(nm):
+        left = q[i - 1] if i > 0 else 0.0
+        right = q[i + 1] if i + 1 < nm else 0.0
+        a = w[0] * (left - 2 * q[i] + right) - w[1] * v[i] - 0.3 * q[i] * q[i] * q[i]
+        if i % 2 == 0:
+            a = a + U[i // 2]
+        acc.append(a)
+    X = vertcat(q, v)
+    f = X + dt * vertcat(v, vertcat(*acc))
+    oc = PDP.OCSys("mass chain")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(X)
+    oc.setControlVariable(U)
+    oc.setDyn(f)
+    oc.setPathCost(w[2] * dot(q, q) + w[3] * dot(v, v) + w[4] * dot(U, U))
+    oc.setFinalCost(w[5] * dot(q, q))
+    th = np.array([2.0, 0.3, 1.0, 0.5, 0.2, 3.0])
+    x0, u = 0.5 * rng.standard_normal((B, 2 * nm)), 0.3 * rng.standard_normal((B, T, m))
+    xs, _ = oc.rollout_batch(x0, u, th)
+    demo_x, demo_u = npy(xs) + 0.1 * rng.standard_normal(xs.shape), u + 0.1 * rng.standard_normal(u.shape)
+    out = oc.pdp_grad_batch(u, th, demo_x, demo_u, ini_state=x0, want_sens=True)
+    assert int(out["status"].sum()) == 0 and out["grad"].shape == (B, 6)
+    aux = oc.getAuxSys_batch(out["x"], u, out["lam"], th)
+    n = 2 * nm
+    for i in range(B):
+        a = {k: [np.asarray(mm) for mm in npy(aux[k])[i]] for k in ("dynF", "dynG", "dynE", "Hxx", "Hxu", "Hxe", "Hux", "Huu", "Hue")}
+        a["hxx"], a["hxe"] = [npy(aux["hxx"])[i]], [npy(aux["hxe"])[i]]
+        ref = po.lqr_from_aux(a, n, 6, T)
+        assert rel(npy(out["dxdp"])[i], np.stack(ref["state_traj_opt"])) < TOL and rel(npy(out["dudp"])[i], np.stack(ref["control_traj_opt"])) < TOL
+        l, g = po.irl_loss_grad(npy(out["x"])[i], u[i], demo_x[i], demo_u[i], ref["state_traj_opt"], ref["control_traj_opt"])
+        assert abs(npy(out["loss"])[i] - l) <= 1e-12 * l and rel(npy(out["grad"])[i], g) < TOL
+    # the aux matrices themselves: finite differences of the kernels' own rollout (F) on one sample
+    eps = 1e-6
+    xp, xm = x0[:1].copy(), x0[:1].copy()
+    xp[0, 3] += eps
+    xm[0, 3] -= eps
+    fd = (npy(oc.rollout_batch(xp, u[:1, :1], th)[0])[0, 1] - npy(oc.rollout_batch(xm, u[:1, :1], th)[0])[0, 1]) / (2 * eps)
+    F0 = npy(oc.getAuxSys_batch(npy(xs)[:1, :2], u[:1, :1], np.zeros((1, 1, n)), th)["dynF"])[0, 0]
+    assert np.abs(F0[:, 3] - fd).max() < 1e-8
