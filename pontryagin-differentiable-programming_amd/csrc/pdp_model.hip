@@ -130,7 +130,7 @@ struct OcSolveWs {
 template <class Mdl>
 int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u, double* x, double* lam, double* cost, double* grad_norm,
              int32_t* converged, double* gains, const pdp_oc_solve_opts* op, int* iterations, void* ws, int64_t wsb, void* stv) {
-    if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= GEN_NMAX && Mdl::NU <= GEN_MMAX) {      // beyond n = 16 / m = 4 the LQ step runs on the generic LDS kernel
         constexpr int n = Mdl::NX, m = Mdl::NU;
         if (B <= 0 || T <= 0 || !x0 || !th || !u || !x || !lam || !op || !ws) return PDP_E_ARG;
         const int K = op->ls_trials > 0 ? op->ls_trials : 10, every = op->check_every > 0 ? op->check_every : 4;
@@ -154,8 +154,13 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
         auto lq = [&]() {
             if constexpr (n <= 4)       // small systems: four trajectories per wavefront (pdp_riccati_small.h)
                 hipLaunchKernelGGL((lqr_solve_small_kernel<m>), dim3((B + 3) / 4), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
-            else
+            else if constexpr (n <= 16 && m <= 4)
                 hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
+            else {
+                const size_t lds = sizeof(double) * lqr_generic_lds_doubles(n, m, 1);
+                (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(lqr_solve_generic_kernel, dim3(B), dim3(64), lds, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
+            }
         };
         pdp_oc_auxsys only_hu{}, hess{};
         only_hu.dHu = w.dHu;

@@ -75,7 +75,8 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
     torch = runtime.torch_cuda()
-    if method == "single" or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start):
+    big = oc.model().n > 16 or oc.model().m > 4          # beyond the multiple-shooting kernel's tiles: single shooting on the generic LQ kernel
+    if method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start):
         return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
                                            neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)
     mdl = oc.model()

@@ -318,6 +318,12 @@ def test_user_model_with_20_states_runs_the_whole_class_surface():
         assert rel(npy(out["dxdp"])[i], np.stack(ref["state_traj_opt"])) < TOL and rel(npy(out["dudp"])[i], np.stack(ref["control_traj_opt"])) < TOL
         l, g = po.irl_loss_grad(npy(out["x"])[i], u[i], demo_x[i], demo_u[i], ref["state_traj_opt"], ref["control_traj_opt"])
         assert abs(npy(out["loss"])[i] - l) <= 1e-12 * l and rel(npy(out["grad"])[i], g) < TOL
+    # ocSolver for the same model (single shooting, the LQ step on the generic kernel): a KKT point - H_u = 0 along rollout and costates
+    sol = oc.ocSolver_batch(x0, T, th)
+    assert bool(sol["converged"].all())
+    hu = oc.model().oc_auxsys(sol["state"], sol["control"], sol["costate"], th, only=("dHu",))["dHu"]
+    assert float(hu.abs().max()) <= 1e-8 * (1 + float(sol["control"].abs().max()))
+    assert float((oc.rollout_batch(x0, sol["control"], th)[0] - sol["state"]).abs().max()) <= 1e-10
     # the aux matrices themselves: finite differences of the kernels' own rollout (F) on one sample
     eps = 1e-6
     xp, xm = x0[:1].copy(), x0[:1].copy()
