@@ -1,0 +1,465 @@
+// pdp_fused3_kernels.h - the fused OC unit (forward + costates + aux system in LDS + Riccati + PDP gradient) as a PRODUCER / CONSUMER pair
+// of wavefronts per trajectory: oc_pdp_fused3_kernel.  Same inputs, outputs, workspace and arithmetic as oc_pdp_fused_kernel
+// (pdp_model_kernels.h); results are bit-identical (the same generated code and the same MFMA sequences run, only on two waves).
+//
+// Why.  Inside ONE wavefront fp64 MFMA and VALU instructions do not overlap (profiles/r01_probe_mfma_overlap.txt) and a lone wave reaches
+// about a third of the SIMD's fp64 VALU rate; two wavefronts on one SIMD do overlap one's MFMAs with the other's VALU / LDS work
+// (profiles/r02_probe_two_waves_per_simd.txt).  At the headline batch (1024 trajectories = the 1024 SIMDs of an MI355X) there is no second
+// trajectory to put on a SIMD, so the trajectory's own work is split by KIND, not by halves of a step (that was oc_pdp_fused2_kernel:
+// two synchronisations per time step, slower):
+//     runner    (waves 0..3 of a workgroup):  rollout, then the Riccati backward loops and the forward sensitivity loops - the serial,
+//                                              MFMA-heavy chains - over pools of aux-system entries it finds ready in LDS;
+//     evaluator (waves 4..7):                  everything that is lane-per-time-step or off the Riccati chain - the generated Jacobian /
+//                                              Hessian code (eval_patha / pathb / fwd), the costate recursion, the terminal condition, the
+//                                              loss terms - one chunk of time steps AHEAD of the runner, into a double-buffered pool.
+// The two meet once per CHUNK (about 13 time steps) at a pair of LDS counters (produced / consumed), not once per step.
+//
+// Placement.  A workgroup is 512 threads = 4 trajectories: waves w and w + 4 land on the same SIMD (probes/wave_placement_probe.hip: 1024 of
+// 1024 pairs, every SIMD hosts exactly two waves when 256 such workgroups are resident), so every SIMD runs one runner and the evaluator
+// of the same trajectory, 256 registers each.  (With 128-thread workgroups the two waves of a workgroup go to DIFFERENT SIMDs.)
+// Each trajectory owns a 40 KB slice of the workgroup's 160 KB of LDS.
+#pragma once
+#include "pdp_model_kernels.h"
+
+namespace pdp {
+
+template <class Mdl>
+struct Fused3Layout {
+    using L = FusedLayout<Mdl>;
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+    static constexpr int NCB = 1 + Mdl::PATHA_NCONST + Mdl::PATHB_NCONST, NCF = 1 + Mdl::FWD_NCONST, NCFIN = 1 + Mdl::FIN_NCONST;     // [0.0 | constants]
+    // backward pool row: [patha | pathb]; lambda_{t+1} (NX doubles, input of the pathb evaluation) is parked in the first slots of the
+    // pathb region, which the same lane overwrites only after it has read them (the one-wave kernel gives it slots of its own)
+    static constexpr int NA = Mdl::PATHA_NVAR, NB = Mdl::PATHB_NVAR > NX ? Mdl::PATHB_NVAR : NX;
+    static constexpr int BSTRIDE = (NA + NB) | 1, FSTRIDE = L::FSTRIDE;
+    // offsets (doubles) inside a trajectory's slice
+    static constexpr int FIN = RICCATI_SCRATCH;                 // [0.0 | terminal constants | terminal entries]   (behind the Riccati scratch; runner only)
+    static constexpr int PAR = FIN + NCFIN + Mdl::FIN_NVAR;      // theta (NP) | theta-only precomputed values (NPC)
+    static constexpr int DLT = PAR + NP + Mdl::NPC;              // NX: lambda_T staging (evaluator, start) / x_T - xdemo_T (runner, end)
+    static constexpr int MISC = DLT + NX;                        // 8 doubles: ints 0..7 = counters | [4] evaluator's loss sum | [5] dead slot
+    static constexpr int CPF = MISC + 8;                         // forward-group constants
+    static constexpr int CPB = CPF + NCF;                        // backward-group constants, directly in front of the pool
+    static constexpr int POOL = CPB + NCB;                       // two buffers of BUF doubles
+    static constexpr int SLICE = 160 * 1024 / 8 / 4;
+    static constexpr int BUF = (SLICE - POOL) / 2;
+    static constexpr int ROWS = BUF / BSTRIDE < 64 ? BUF / BSTRIDE : 64;       // time steps per backward chunk
+    static constexpr int ROWSF = BUF / FSTRIDE < 64 ? BUF / FSTRIDE : 64;      // ... per forward chunk (shorter rows)
+};
+
+// the kernel applies when the rollout staging fits the pool area and a chunk holds a useful number of steps
+template <class Mdl>
+__host__ __device__ constexpr bool fused3_ok(int T) {
+    using F3 = Fused3Layout<Mdl>;
+    return Mdl::NX > 4 && F3::ROWS >= 4 && F3::ROWSF >= 4 && (T + 1) * Mdl::NX + T * Mdl::NU <= 2 * F3::BUF;
+}
+
+// counters in LDS: release / acquire at workgroup scope (LDS and - for the trajectory the runner leaves in global memory - the CU's L1)
+PDP_DEV void f3_signal(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+PDP_DEV void f3_wait_ge(int* f, int v) {
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
+}
+
+// running gather positioned at row tl of the pool buffer that starts bufoff doubles behind the first (constants do not move)
+PDP_DEV GatherRun gather_at3(const Gather& g, int tl, const double* blk, int bufoff) {
+    GatherRun r;
+    const unsigned base = lds_addr(blk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r.cur[k] = base + 8u * (unsigned)(g.off[k] + tl * g.tmul[k] + (g.tmul[k] ? bufoff : 0));
+        r.tmul[k] = 8 * g.tmul[k];
+    }
+    return r;
+}
+
+template <class Mdl>
+__global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
+                                                            const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
+                                                            const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
+                                                            double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
+                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
+    using F3 = Fused3Layout<Mdl>;
+    using L = FusedLayout<Mdl>;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
+    constexpr int GSZ = fused_gain_doubles<Mdl>(), GSZ0 = fused_gain0_doubles<Mdl>();
+    constexpr int BS = F3::BSTRIDE, FS = F3::FSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wid & 3;
+    const bool runner = wid < 4;
+    const int b = blockIdx.x * 4 + slot;
+    double* lds = lds_all + slot * F3::SLICE;
+    double* scratch = lds;
+    double* fin = lds + F3::FIN;
+    double* par = lds + F3::PAR;
+    double* dlT = lds + F3::DLT;
+    double* misc = lds + F3::MISC;
+    int* fl = (int*)misc;                                   // [0] stage (1: parameters in LDS, 2: trajectory in memory) [1] unused
+                                                            // [2] chunks produced [3] chunks consumed [4] evaluator finished
+    double* blkF = lds + F3::CPF;
+    double* blkB = lds + F3::CPB;
+    double* pool = lds + F3::POOL;
+    if (runner && lane < 8) fl[lane] = 0;
+    __syncthreads();                                        // the only workgroup barrier: counters zeroed before anyone polls them
+    if (b >= B) return;
+    const d4 z = zero4();
+#define PDP_F3_PAR()                                                \
+    double th[NP], pc[Mdl::NPC];                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) th[i_] = par[i_]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < Mdl::NPC; ++i_) pc[i_] = par[NP + i_]
+    double* xb = x + (int64_t)b * (T + 1) * NX;
+    double* lb = lam + (int64_t)b * T * NX;
+    const double* ub = u + (int64_t)b * T * NU;
+    const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
+    const double* dub = demo_u + (int64_t)b * T * NU;
+    double* gw = ws_gain + (int64_t)b * T * GSZ;
+    const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
+    const int nchunk = (T + F3::ROWS - 1) / F3::ROWS;
+    const int ch = (T + nchunk - 1) / nchunk;               // backward chunks of equal length
+    const int nchunkF = (T + F3::ROWSF - 1) / F3::ROWSF;
+    const int chF = (T + nchunkF - 1) / nchunkF;            // forward chunks likewise
+#ifdef PDP_PHASE_TIMING     // debug builds (probes/phase_timing3.py): cycle stamps of trajectory 0 behind loss[B]
+    long long ts[12]; int nts = 0; long long twait = 0, tw0 = 0;
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 12; ++i) ts[i] = 0;
+#define F3_STAMP() ts[nts++] = __builtin_readcyclecounter()
+#define F3_W0() tw0 = __builtin_readcyclecounter()
+#define F3_W1() twait += __builtin_readcyclecounter() - tw0
+#else
+#define F3_STAMP()
+#define F3_W0()
+#define F3_W1()
+#endif
+    F3_STAMP();
+
+    if (runner) {
+        // =========================================== runner ===========================================
+        __builtin_amdgcn_s_setprio(3);
+        {
+            double th0[NP], pc0[Mdl::NPC];
+            load_theta<Mdl>(theta, b, tb, th0);
+            Mdl::precompute(th0, pc0);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) par[i] = th0[i];
+#pragma unroll
+                for (int i = 0; i < Mdl::NPC; ++i) par[NP + i] = pc0[i];
+            }
+            f3_signal(fl + 0, 1);
+        }
+        // ---- rollout x+ = f(x, u, theta): scalar recursion executed uniformly by the wave, staged in the (still unused) pool
+        if (!given) {
+            double* xs = pool;                                   // (T+1) x NX
+            double* us = pool + (T + 1) * NX;                    // T x NU
+            for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
+            PDP_F3_PAR();
+            double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+            }
+            wave_lds_sync();
+            double un[NU];                                       // u_{t+1} is read from LDS while step t computes
+#pragma unroll
+            for (int i = 0; i < NU; ++i) un[i] = us[i];
+            for (int t = 0; t < T; ++t) {
+                const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { uc[i] = un[i]; un[i] = us[tn * NU + i]; }
+                Mdl::dyn(xc, uc, th, pc, xn);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+                }
+            }
+            wave_lds_sync();
+            for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API output
+        }
+        f3_signal(fl + 0, 2);                                    // release: the trajectory is in memory, the staging area is free
+        F3_STAMP();
+
+        // ---- terminal condition: P = hxx(x_T), W = hxe(x_T) - evaluated here, while the evaluator fills the first chunk
+        bool ok = true;
+        d4 P, W2;
+        {
+            if (lane == 0) fin[0] = 0.0;
+            for (int i_ = lane; i_ < Mdl::FIN_NCONST; i_ += 64) fin[1 + i_] = Mdl::fin_const(i_);
+            if (lane == 0) {
+                PDP_F3_PAR();
+                double xT[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
+                PackedSink s{fin + F3::NCFIN};
+                Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
+            }
+            wave_lds_sync();
+            Gather gP, gW;
+            make_gather(gP, lane, F3::NCFIN, 0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fin_code(0, r * NX + c) : -1; });
+            make_gather(gW, lane, F3::NCFIN, 0, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fin_code(1, r * NP + (c - M)) : -1; });
+            P = gather_tile(fin, gP, 0);
+            W2 = gather_tile(fin, gW, 0);
+        }
+        F3_STAMP();
+
+        // ---- backward sweep: Riccati steps over the chunks the evaluator has filled
+        {
+            constexpr int NA = F3::NA, NCA = Mdl::PATHA_NCONST;
+            auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
+            auto codeB = [](int mat, int i) { int c = Mdl::pathb_code(mat, i); return c >= 0 ? c + NA : (c == -1 ? -1 : c - NCA); };
+            Gather gF, gY, gHxx, gHX, gHU, gGr, gHux;
+            make_gather(gF, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+            make_gather(gY, lane, F3::NCB, BS, [&](int r, int c) {
+                return r >= NX ? -1 : (c < M ? codeA(1, r * NU + c) : (c < M + NP ? codeA(2, r * NP + (c - M)) : -1)); });
+            make_gather(gGr, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeA(1, r * NU + (c & 3)) : -1; });
+            make_gather(gHux, lane, F3::NCB, BS, [&](int r, int c) { return (r < M && c < NX) ? codeB(1, c * NU + r) : -1; });
+            make_gather(gHxx, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
+            make_gather(gHX, lane, F3::NCB, BS, [&](int r, int c) {
+                return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
+            make_gather(gHU, lane, F3::NCB, BS, [&](int r, int c) {
+                return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
+            // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
+            const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+            for (int g = 0; g < nchunk; ++g) {
+                const int c = nchunk - 1 - g, t0 = c * ch, cnt = min(ch, T - t0), bo = (g & 1) * F3::BUF;
+                F3_W0();
+                f3_wait_ge(fl + 2, g + 1);
+                F3_W1();
+                GatherRun rF = gather_at3(gF, cnt - 1, blkB, bo), rY = gather_at3(gY, cnt - 1, blkB, bo), rHxx = gather_at3(gHxx, cnt - 1, blkB, bo),
+                          rHX = gather_at3(gHX, cnt - 1, blkB, bo), rHU = gather_at3(gHU, cnt - 1, blkB, bo), rGr = gather_at3(gGr, cnt - 1, blkB, bo),
+                          rHux = gather_at3(gHux, cnt - 1, blkB, bo);
+                // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead (two register sets in rotation, no copies at the
+                // back edge); the Hessian tiles are accumulator inputs of later MFMAs and are requested at the top of their own step.  The last
+                // step of a chunk prefetches nothing (no LDS read outside the buffer).
+                d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
+                auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
+                    const int t = t0 + tl;
+                    d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
+                    if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }
+                    RiccatiGains gn;
+                    d4 P_old;
+                    ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
+                    store_all<1>(gw + t * GSZ, mK, gn.K);
+                    store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
+                };
+                int tl = cnt - 1;
+                for (; tl >= 1; tl -= 2) { bstep(tl, Fa, Ya, Fb, Yb); bstep(tl - 1, Fb, Yb, Fa, Ya); }
+                if (tl == 0) bstep(0, Fa, Ya, Fb, Yb);
+                f3_signal(fl + 3, g + 1);
+            }
+        }
+        bool finite = tile_finite(P) && tile_finite(W2);
+        F3_STAMP();
+
+        // ---- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, gradient
+        double acc = 0.0, lsum = 0.0;
+        d4 X2 = z;
+        {
+            constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
+            constexpr int NCP = F3::POOL - F3::CPF;                            // the pool seen from the forward constants
+            Gather gFT, gGT, gE, gDX, gDU;
+            make_gather(gFT, lane, NCP, FS, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
+            make_gather(gGT, lane, NCP, FS, [](int r, int c) { return (r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1; });
+            make_gather(gE, lane, NCP, FS, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fwd_code(2, r * NP + (c - M)) : -1; });
+            make_gather(gDX, lane, NCP, FS, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
+            make_gather(gDU, lane, NCP, FS, [](int r, int c) { return (r < M) ? DLU + r : -1; });
+            // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored); K is read back transposed and
+            // replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
+            const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+            d4 KTn = -load_all<4>(gw, mKT);
+            d4 kn = -load_all<1>(gw + NX * NU, mIK);
+            for (int c = 0; c < nchunkF; ++c) {
+                const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0), bo = (g & 1) * F3::BUF;
+                F3_W0();
+                f3_wait_ge(fl + 2, g + 1);
+                F3_W1();
+                GatherRun rFT = gather_at3(gFT, 0, blkF, bo), rGT = gather_at3(gGT, 0, blkF, bo), rE = gather_at3(gE, 0, blkF, bo),
+                          rDX = gather_at3(gDX, 0, blkF, bo), rDU = gather_at3(gDU, 0, blkF, bo);
+                auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
+                    const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
+                    KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
+                    knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
+                    d4 FT = gather_run(rFT, 1);
+                    d4 GT = gather_run<1>(rGT, 1);
+                    d4 E2 = gather_run(rE, 1);
+                    d4 DX = gather_run(rDX, 1);                 // (x_t - xd_t)[row] broadcast over columns
+                    d4 DU = gather_run<1>(rDU, 1);
+                    d4 U2;
+                    riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
+                    acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
+                    if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
+                    if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+                };
+                // two steps per trip, the sensitivity tile and the prefetched gains alternating between two register sets
+                d4 Xb, KTb, kb;
+                int tl = 0;
+                for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); fstep(tl + 1, Xb, X2, KTb, kb, KTn, kn); }
+                if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; }
+                f3_signal(fl + 3, g + 1);
+            }
+        }
+        F3_STAMP();
+        // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
+        wave_lds_sync();
+        if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
+        if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + T) * NX * NP, NX, NP, NP, 0, M, lane, X2);
+        finite = finite && tile_finite(X2);
+        acc = sum_over_rowgroups(acc);
+        lsum = wave_sum(lsum);
+        F3_W0();
+        f3_wait_ge(fl + 4, 1);
+        F3_W1();
+        lsum += misc[4];                                        // the evaluator's share: sum over t < T of |x - xd|^2 + |u - ud|^2
+        // PDP_OC_PACKED: grad is [B][NP + 1] with the loss in the last column - the row the data-parallel iteration all-gathers
+        const int gstride = (flags & PDP_OC_PACKED) ? NP + 1 : NP;
+        if (lane >= M && lane < M + NP) grad[(int64_t)b * gstride + (lane - M)] = acc;
+        if (lane == 0) { loss[b] = lsum; if (flags & PDP_OC_PACKED) grad[(int64_t)b * gstride + NP] = lsum; }
+        int st = 0;
+        if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
+        if (!ok) st |= PDP_STATUS_PIVOT;
+        if (lane == 0 && status) status[b] = st;
+#ifdef PDP_PHASE_TIMING
+        F3_STAMP();
+        if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B); for (int i = 0; i < 12; ++i) o[i] = ts[i]; o[12] = twait; }
+        if (lane == 0) { long long* o = (long long*)(loss + B) + 64 + 4 * b; o[0] = rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = ts[nts - 1] - ts[0]; o[3] = twait; }
+#endif
+    } else {
+        // ========================================== evaluator ==========================================
+        __builtin_amdgcn_s_setprio(0);
+        F3_W0();
+        f3_wait_ge(fl + 0, 2);                                   // parameters in LDS, trajectory in memory
+        F3_W1();
+        F3_STAMP();
+        // ---- terminal condition and the constants of both groups
+        if (lane == 0) { blkB[0] = 0.0; blkF[0] = 0.0; }
+        for (int i_ = lane; i_ < Mdl::PATHA_NCONST; i_ += 64) blkB[1 + i_] = Mdl::patha_const(i_);
+        for (int i_ = lane; i_ < Mdl::PATHB_NCONST; i_ += 64) blkB[1 + Mdl::PATHA_NCONST + i_] = Mdl::pathb_const(i_);
+        for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blkF[1 + i_] = Mdl::fwd_const(i_);
+        d4 Lam = z;                                              // costate tile: column 0 holds lambda_{t+1}; lambda_T = h_x(x_T)
+        if (!given) {
+            PDP_F3_PAR();
+            double xT[NX], lT[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
+            Mdl::dhx(xT, th, pc, lT);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dlT[i] = lT[i];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX && tile_col(lane) == 0) Lam[r] = dlT[row]; }
+        }
+        F3_STAMP();
+        // ---- backward chunks: (A) lane = time step evaluates F, G, E, c_x -> (C) costates through the chunk on MFMA,
+        //      lambda_t = c_x + F_t' lambda_{t+1} -> (B) lane = time step evaluates the lambda-weighted Hessians
+        {
+            constexpr int NA = F3::NA;
+            auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
+            Gather gF, gCX;
+            make_gather(gF, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+            make_gather(gCX, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
+            for (int g = 0; g < nchunk; ++g) {
+                const int c = nchunk - 1 - g, t0 = c * ch, cnt = min(ch, T - t0), bo = (g & 1) * F3::BUF;
+                double* pb = pool + bo;
+                F3_W0();
+                f3_wait_ge(fl + 3, g - 1);                       // the buffer's previous chunk has been consumed
+                F3_W1();
+                if (lane < cnt) {
+                    PDP_F3_PAR();
+                    const int t = t0 + lane;
+                    double xc[NX], uc[NU];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xc[i] = xb[t * NX + i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+                    PackedSink s{pb + lane * BS};
+                    Mdl::eval_patha(xc, uc, nullptr, th, pc, s);
+                }
+                wave_lds_sync();
+                if (!given) {
+                    // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
+                    GatherRun cF = gather_at3(gF, cnt - 1, blkB, bo), cC = gather_at3(gCX, cnt - 1, blkB, bo), wL;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
+                        const int row = tile_row(lane, r);
+                        const bool valid = tile_col(lane) == 0 && row < NX;
+                        wL.cur[r] = valid ? lds_addr(pb) + 8u * (unsigned)((cnt - 1) * BS + NA + row) : lds_addr(misc + 5);
+                        wL.tmul[r] = valid ? 8 * BS : 0;
+                    }
+                    d4 Fc = gather_run(cF, -1), CX = gather_run(cC, -1);
+                    auto cstep = [&](int tl, const d4 Lin, d4& Lout) {
+                        d4 Fc_n = Fc, CX_n = CX;
+                        if (tl > 0) { Fc_n = gather_run(cF, -1); CX_n = gather_run(cC, -1); }
+                        scatter_run(wL, Lin, -1);
+                        Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                        Fc = Fc_n; CX = CX_n;
+                    };
+                    d4 Lam2 = z;
+                    int tl = cnt - 1;
+                    for (; tl >= 1; tl -= 2) { cstep(tl, Lam, Lam2); cstep(tl - 1, Lam2, Lam); }
+                    if (tl == 0) { cstep(0, Lam, Lam2); Lam = Lam2; }
+                    wave_lds_sync();
+                }
+                if (lane < cnt) {
+                    PDP_F3_PAR();
+                    const int t = t0 + lane;
+                    double xc[NX], uc[NU], lc[NX];
+                    double* row = pb + lane * BS;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xc[i] = xb[t * NX + i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+                    if (given) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) lc[i] = lb[t * NX + i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { lc[i] = row[NA + i]; lb[t * NX + i] = lc[i]; }      // costate is an API output
+                    }
+                    PackedSink s{row + NA};
+                    Mdl::eval_pathb(xc, uc, lc, th, pc, s);
+                }
+                f3_signal(fl + 2, g + 1);
+            }
+        }
+        F3_STAMP();
+        // ---- forward chunks: lane = time step evaluates F', G', E and the loss terms x - x_demo, u - u_demo
+        double lsum = 0.0;
+        {
+            constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;
+            for (int c = 0; c < nchunkF; ++c) {
+                const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0), bo = (g & 1) * F3::BUF;
+                F3_W0();
+                f3_wait_ge(fl + 3, g - 1);
+                F3_W1();
+                if (lane < cnt) {
+                    PDP_F3_PAR();
+                    const int t = t0 + lane;
+                    double xc[NX], uc[NU];
+                    double* row = pool + bo + lane * FS;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; double d = xc[i] - dxb[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; double d = uc[i] - dub[t * NU + i]; row[DLU + i] = d; lsum += d * d; }
+                    PackedSink s{row};
+                    Mdl::eval_fwd(xc, uc, nullptr, th, pc, s);
+                }
+                f3_signal(fl + 2, g + 1);
+            }
+        }
+        lsum = wave_sum(lsum);
+        if (lane == 0) misc[4] = lsum;
+        f3_signal(fl + 4, 1);
+#ifdef PDP_PHASE_TIMING
+        F3_STAMP();
+        if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 16; for (int i = 0; i < 12; ++i) o[i] = ts[i]; o[12] = twait; }
+#endif
+    }
+}
+
+}  // namespace pdp

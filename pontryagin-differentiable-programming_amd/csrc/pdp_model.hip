@@ -12,12 +12,13 @@
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"
 #include "pdp_fused2_kernels.h"
+#include "pdp_fused3_kernels.h"
 #include <cstdlib>
 
 using namespace pdp;
 
 #ifndef PDP_FUSED_DEFAULT_VARIANT
-#define PDP_FUSED_DEFAULT_VARIANT 1
+#define PDP_FUSED_DEFAULT_VARIANT 3
 #endif
 
 namespace {
@@ -87,10 +88,19 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         if (wsb < oc_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
         const size_t lds = fused_lds_bytes<Mdl>(T);
         if (lds > 160 * 1024) return PDP_E_SIZE;
-        // PDP_FUSED_VARIANT=2 (environment): two wavefronts per trajectory (pdp_fused2_kernels.h); systems with n <= 4 always take the
-        // one-wave kernel (its small-system algebra has nothing to split)
+        // Kernel variants (environment PDP_FUSED_VARIANT overrides the default): 3 = runner / evaluator wave pair per trajectory, four
+        // trajectories per 512-thread workgroup (pdp_fused3_kernels.h) - the default wherever it applies (n > 4, rollout staging within the
+        // pool area); 1 = one wavefront per trajectory (systems with n <= 4, long horizons); 2 = the step-split experiment (pdp_fused2_kernels.h)
         static const int variant = [] { const char* e = std::getenv("PDP_FUSED_VARIANT"); return e ? std::atoi(e) : PDP_FUSED_DEFAULT_VARIANT; }();
         PDP_CLEAR();
+        if constexpr (Mdl::NX > 4) {
+            if (variant == 3 && fused3_ok<Mdl>(T)) {
+                (void)hipFuncSetAttribute((const void*)oc_pdp_fused3_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL((oc_pdp_fused3_kernel<Mdl>), dim3((B + 3) / 4), dim3(512), 160 * 1024, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss,
+                                   grad, dxdp, dudp, status, (double*)ws);
+                return launched();
+            }
+        }
         if (variant == 2 && Mdl::NX > 4) {
             (void)hipFuncSetAttribute((const void*)oc_pdp_fused2_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((oc_pdp_fused2_kernel<Mdl>), dim3(B), dim3(128), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
