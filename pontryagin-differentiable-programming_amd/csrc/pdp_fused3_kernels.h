@@ -28,18 +28,22 @@ struct Fused3Layout {
     using L = FusedLayout<Mdl>;
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
     static constexpr int NCB = 1 + Mdl::PATHA_NCONST + Mdl::PATHB_NCONST, NCF = 1 + Mdl::FWD_NCONST, NCFIN = 1 + Mdl::FIN_NCONST;     // [0.0 | constants]
-    // backward pool row: [patha | pathb]; lambda_{t+1} (NX doubles, input of the pathb evaluation) is parked in the first slots of the
-    // pathb region, which the same lane overwrites only after it has read them (the one-wave kernel gives it slots of its own)
+    // backward pool row: [patha | pathb | 0.0 | constants of both groups]; lambda_{t+1} (NX doubles, input of the pathb evaluation) is parked in
+    // the first slots of the pathb region, which the same lane overwrites only after it has read them.  EVERY row carries its own zero and
+    // its own copy of the (few) constant entries, so that every tile element - varying, constant or absent - sits at the same distance
+    // from one row to the next: the time step becomes an immediate offset of the ds_read and the per-lane address registers are updated
+    // once per U steps instead of once per step (the one-wave kernel keeps one constant pool and per-lane strides of 0 or one row).
     static constexpr int NA = Mdl::PATHA_NVAR, NB = Mdl::PATHB_NVAR > NX ? Mdl::PATHB_NVAR : NX;
-    static constexpr int BSTRIDE = (NA + NB) | 1, FSTRIDE = L::FSTRIDE;
+    static constexpr int CB0 = NA + NB;                                          // slot of the row's 0.0; the constants follow
+    static constexpr int BSTRIDE = (CB0 + NCB) | 1;
+    static constexpr int CF0 = Mdl::FWD_NVAR + NX + NU;                          // forward row: [fwd | x - x_demo | u - u_demo | 0.0 | constants]
+    static constexpr int FSTRIDE = (CF0 + NCF) | 1;
     // offsets (doubles) inside a trajectory's slice
     static constexpr int FIN = RICCATI_SCRATCH;                 // [0.0 | terminal constants | terminal entries]   (behind the Riccati scratch; runner only)
     static constexpr int PAR = FIN + NCFIN + Mdl::FIN_NVAR;      // theta (NP) | theta-only precomputed values (NPC)
     static constexpr int DLT = PAR + NP + Mdl::NPC;              // NX: lambda_T staging (evaluator, start) / x_T - xdemo_T (runner, end)
     static constexpr int MISC = DLT + NX;                        // 8 doubles: ints 0..7 = counters | [4] evaluator's loss sum | [5] dead slot
-    static constexpr int CPF = MISC + 8;                         // forward-group constants
-    static constexpr int CPB = CPF + NCF;                        // backward-group constants, directly in front of the pool
-    static constexpr int POOL = CPB + NCB;                       // two buffers of BUF doubles
+    static constexpr int POOL = MISC + 8;                        // two buffers of BUF doubles
     static constexpr int SLICE = 160 * 1024 / 8 / 4;
     static constexpr int BUF = (SLICE - POOL) / 2;
     static constexpr int ROWS = BUF / BSTRIDE < 64 ? BUF / BSTRIDE : 64;       // time steps per backward chunk
@@ -59,16 +63,35 @@ PDP_DEV void f3_wait_ge(int* f, int v) {
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(2);
 }
 
-// running gather positioned at row tl of the pool buffer that starts bufoff doubles behind the first (constants do not move)
-PDP_DEV GatherRun gather_at3(const Gather& g, int tl, const double* blk, int bufoff) {
-    GatherRun r;
-    const unsigned base = lds_addr(blk);
+// Gathers over uniform rows: off[r] = slot (in doubles, inside a row) of tile element (lane, r); absent elements read the row's 0.0
+struct Gather3 { int off[4]; };
+template <class CodeFn>
+PDP_DEV void make_gather3(Gather3& g, int lane, int c0, CodeFn code_of /* (row, col) -> code >= 0, -1 (zero) or <= -2 (constant) */) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        r.cur[k] = base + 8u * (unsigned)(g.off[k] + tl * g.tmul[k] + (g.tmul[k] ? bufoff : 0));
-        r.tmul[k] = 8 * g.tmul[k];
+    for (int r = 0; r < 4; ++r) {
+        const int code = code_of(tile_row(lane, r), tile_col(lane));
+        g.off[r] = code >= 0 ? code : (code == -1 ? c0 : c0 + 1 + (-2 - code));
     }
+}
+struct Run3 { unsigned cur[4]; };       // absolute LDS byte addresses of the four elements in the row the run is positioned at
+PDP_DEV Run3 run3_at(const Gather3& g, const double* row) {
+    Run3 r;
+    const unsigned base = lds_addr(row);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.cur[k] = base + 8u * (unsigned)g.off[k];
     return r;
+}
+template <int NR = 4>
+PDP_DEV d4 read3(const Run3& r, unsigned imm) {      // imm: byte distance of the wanted row from the run's row - a literal after unrolling
+    d4 v = zero4();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = *(PDP_LDS const double*)(uintptr_t)(r.cur[k] + imm);
+    return v;
+}
+template <int NR = 4>
+PDP_DEV void move3(Run3& r, int bytes) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r.cur[k] += (unsigned)bytes;
 }
 
 template <class Mdl>
@@ -82,8 +105,11 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>(), GSZ0 = fused_gain0_doubles<Mdl>();
     constexpr int BS = F3::BSTRIDE, FS = F3::FSTRIDE;
+    constexpr int U = 4;                                    // time steps per address update in the runner's loops
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, slot = wid & 3;
+    // the wave index is uniform over the wave - said explicitly, or every pointer derived from it (trajectory, workspace, LDS slice) would be
+    // carried per lane and every global access would pay 64-bit VALU address arithmetic
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, slot = wid & 3;
     const bool runner = wid < 4;
     const int b = blockIdx.x * 4 + slot;
     double* lds = lds_all + slot * F3::SLICE;
@@ -94,8 +120,6 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
     double* misc = lds + F3::MISC;
     int* fl = (int*)misc;                                   // [0] stage (1: parameters in LDS, 2: trajectory in memory) [1] unused
                                                             // [2] chunks produced [3] chunks consumed [4] evaluator finished
-    double* blkF = lds + F3::CPF;
-    double* blkB = lds + F3::CPB;
     double* pool = lds + F3::POOL;
     if (runner && lane < 8) fl[lane] = 0;
     __syncthreads();                                        // the only workgroup barrier: counters zeroed before anyone polls them
@@ -112,8 +136,12 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
     const double* dub = demo_u + (int64_t)b * T * NU;
     double* gw = ws_gain + (int64_t)b * T * GSZ;
     const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
+    // backward chunks, last time steps first, of equal length.  (A short first chunk - the runner idles until the first chunk is ready - was
+    // tried: the evaluator, at low priority, then cannot fill the SECOND chunk within the few steps the runner spends on the first, and the
+    // runner waits there instead: 0.1107 ms against 0.1093 ms.)
     const int nchunk = (T + F3::ROWS - 1) / F3::ROWS;
-    const int ch = (T + nchunk - 1) / nchunk;               // backward chunks of equal length
+    const int ch = (T + nchunk - 1) / nchunk;
+    auto bchunk = [&](int g, int& t0, int& cnt) { const int c = nchunk - 1 - g; t0 = c * ch; cnt = min(ch, T - t0); };      // chunk g covers [t0, t0 + cnt)
     const int nchunkF = (T + F3::ROWSF - 1) / F3::ROWSF;
     const int chF = (T + nchunkF - 1) / nchunkF;            // forward chunks likewise
 #ifdef PDP_PHASE_TIMING     // debug builds (probes/phase_timing3.py): cycle stamps of trajectory 0 behind loss[B]
@@ -208,44 +236,61 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
             constexpr int NA = F3::NA, NCA = Mdl::PATHA_NCONST;
             auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
             auto codeB = [](int mat, int i) { int c = Mdl::pathb_code(mat, i); return c >= 0 ? c + NA : (c == -1 ? -1 : c - NCA); };
-            Gather gF, gY, gHxx, gHX, gHU, gGr, gHux;
-            make_gather(gF, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
-            make_gather(gY, lane, F3::NCB, BS, [&](int r, int c) {
+            Gather3 gF, gY, gHxx, gHX, gHU, gGr, gHux;
+            make_gather3(gF, lane, F3::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+            make_gather3(gY, lane, F3::CB0, [&](int r, int c) {
                 return r >= NX ? -1 : (c < M ? codeA(1, r * NU + c) : (c < M + NP ? codeA(2, r * NP + (c - M)) : -1)); });
-            make_gather(gGr, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeA(1, r * NU + (c & 3)) : -1; });
-            make_gather(gHux, lane, F3::NCB, BS, [&](int r, int c) { return (r < M && c < NX) ? codeB(1, c * NU + r) : -1; });
-            make_gather(gHxx, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
-            make_gather(gHX, lane, F3::NCB, BS, [&](int r, int c) {
+            make_gather3(gGr, lane, F3::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeA(1, r * NU + (c & 3)) : -1; });
+            make_gather3(gHux, lane, F3::CB0, [&](int r, int c) { return (r < M && c < NX) ? codeB(1, c * NU + r) : -1; });
+            make_gather3(gHxx, lane, F3::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeB(0, r * NX + c) : -1; });
+            make_gather3(gHX, lane, F3::CB0, [&](int r, int c) {
                 return r >= NX ? -1 : (c < M ? codeB(1, r * NU + c) : (c < M + NP ? codeB(2, r * NP + (c - M)) : -1)); });
-            make_gather(gHU, lane, F3::NCB, BS, [&](int r, int c) {
+            make_gather3(gHU, lane, F3::CB0, [&](int r, int c) {
                 return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
             // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
             const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+            constexpr int RB = 8 * BS;                           // bytes per row
             for (int g = 0; g < nchunk; ++g) {
-                const int c = nchunk - 1 - g, t0 = c * ch, cnt = min(ch, T - t0), bo = (g & 1) * F3::BUF;
+                int t0, cnt;
+                bchunk(g, t0, cnt);
+                const double* pb = pool + (g & 1) * F3::BUF;
                 F3_W0();
                 f3_wait_ge(fl + 2, g + 1);
                 F3_W1();
-                GatherRun rF = gather_at3(gF, cnt - 1, blkB, bo), rY = gather_at3(gY, cnt - 1, blkB, bo), rHxx = gather_at3(gHxx, cnt - 1, blkB, bo),
-                          rHX = gather_at3(gHX, cnt - 1, blkB, bo), rHU = gather_at3(gHU, cnt - 1, blkB, bo), rGr = gather_at3(gGr, cnt - 1, blkB, bo),
-                          rHux = gather_at3(gHux, cnt - 1, blkB, bo);
-                // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead (two register sets in rotation, no copies at the
-                // back edge); the Hessian tiles are accumulator inputs of later MFMAs and are requested at the top of their own step.  The last
-                // step of a chunk prefetches nothing (no LDS read outside the buffer).
-                d4 Fa = gather_run(rF, -1), Ya = gather_run(rY, -1), Fb = z, Yb = z;
-                auto bstep = [&](int tl, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
+                int tl = cnt - 1;
+                // the runs sit one row BELOW the step's row: the step reads at +RB, its one-step-ahead requests at +0
+                const double* r0 = pb + (tl - 1) * BS;
+                Run3 rF = run3_at(gF, r0), rY = run3_at(gY, r0), rHxx = run3_at(gHxx, r0), rHX = run3_at(gHX, r0), rHU = run3_at(gHU, r0),
+                     rGr = run3_at(gGr, r0), rHux = run3_at(gHux, r0);
+                auto move_all = [&](int bytes) {
+                    move3(rF, bytes); move3(rY, bytes); move3(rHxx, bytes); move3(rHX, bytes); move3<1>(rHU, bytes); move3(rGr, bytes); move3<1>(rHux, bytes);
+                };
+                // F and [G|E] feed the first MFMAs of a step and are requested one step ahead (two register sets in rotation); the Hessian
+                // tiles are accumulator inputs of later MFMAs and are requested at the top of their own step.  Step 0 of a chunk requests
+                // nothing ahead (no LDS read outside the buffer).
+                d4 Fa = read3(rF, RB), Ya = read3(rY, RB), Fb = z, Yb = z;
+                auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {      // imm: distance of row tl from the runs
                     const int t = t0 + tl;
-                    d4 Hxx = gather_run(rHxx, -1), HX2 = gather_run(rHX, -1), HU2 = gather_run<1>(rHU, -1), Grep = gather_run(rGr, -1), Hux = gather_run<1>(rHux, -1);
-                    if (tl > 0) { Fn = gather_run(rF, -1); Yn = gather_run(rY, -1); }
+                    d4 Hxx = read3(rHxx, imm), HX2 = read3(rHX, imm), HU2 = read3<1>(rHU, imm), Grep = read3(rGr, imm), Hux = read3<1>(rHux, imm);
+                    if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
                     d4 P_old;
                     ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
                 };
-                int tl = cnt - 1;
-                for (; tl >= 1; tl -= 2) { bstep(tl, Fa, Ya, Fb, Yb); bstep(tl - 1, Fb, Yb, Fa, Ya); }
-                if (tl == 0) bstep(0, Fa, Ya, Fb, Yb);
+                // single steps until a whole number of groups of U remains (the register sets move up by copies there)
+                for (; (tl + 1) % U != 0; --tl) { bstep(tl, RB, Fa, Ya, Fb, Yb); Fa = Fb; Ya = Yb; move_all(-RB); }
+                // groups of U steps: the runs sit on row tl - U, step tl - j reads at (U - j) rows - literal offsets, one address update per group
+                move_all(-(U - 1) * RB);
+                for (; tl >= U - 1; tl -= U) {
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        if (j & 1) bstep(tl - j, (unsigned)((U - j) * RB), Fb, Yb, Fa, Ya);
+                        else bstep(tl - j, (unsigned)((U - j) * RB), Fa, Ya, Fb, Yb);
+                    }
+                    move_all(-U * RB);
+                }
                 f3_signal(fl + 3, g + 1);
             }
         }
@@ -257,45 +302,54 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
         d4 X2 = z;
         {
             constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
-            constexpr int NCP = F3::POOL - F3::CPF;                            // the pool seen from the forward constants
-            Gather gFT, gGT, gE, gDX, gDU;
-            make_gather(gFT, lane, NCP, FS, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
-            make_gather(gGT, lane, NCP, FS, [](int r, int c) { return (r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1; });
-            make_gather(gE, lane, NCP, FS, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fwd_code(2, r * NP + (c - M)) : -1; });
-            make_gather(gDX, lane, NCP, FS, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
-            make_gather(gDU, lane, NCP, FS, [](int r, int c) { return (r < M) ? DLU + r : -1; });
+            Gather3 gFT, gGT, gE, gDX, gDU;
+            make_gather3(gFT, lane, F3::CF0, [](int r, int c) { return (r < NX && c < NX) ? Mdl::fwd_code(0, c * NX + r) : -1; });
+            make_gather3(gGT, lane, F3::CF0, [](int r, int c) { return (r < M && c < NX) ? Mdl::fwd_code(1, c * NU + r) : -1; });
+            make_gather3(gE, lane, F3::CF0, [](int r, int c) { return (r < NX && c >= M && c < M + NP) ? Mdl::fwd_code(2, r * NP + (c - M)) : -1; });
+            make_gather3(gDX, lane, F3::CF0, [](int r, int c) { return (r < NX) ? DLX + r : -1; });
+            make_gather3(gDU, lane, F3::CF0, [](int r, int c) { return (r < M) ? DLU + r : -1; });
             // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored); K is read back transposed and
             // replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
             const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
             d4 KTn = -load_all<4>(gw, mKT);
             d4 kn = -load_all<1>(gw + NX * NU, mIK);
+            constexpr int RF = 8 * FS;
+            static_assert((U & 1) == 0, "the register sets of the unrolled loops alternate: U must be even");
             for (int c = 0; c < nchunkF; ++c) {
-                const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0), bo = (g & 1) * F3::BUF;
+                const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0);
+                const double* pb = pool + (g & 1) * F3::BUF;
                 F3_W0();
                 f3_wait_ge(fl + 2, g + 1);
                 F3_W1();
-                GatherRun rFT = gather_at3(gFT, 0, blkF, bo), rGT = gather_at3(gGT, 0, blkF, bo), rE = gather_at3(gE, 0, blkF, bo),
-                          rDX = gather_at3(gDX, 0, blkF, bo), rDU = gather_at3(gDU, 0, blkF, bo);
-                auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
+                Run3 rFT = run3_at(gFT, pb), rGT = run3_at(gGT, pb), rE = run3_at(gE, pb), rDX = run3_at(gDX, pb), rDU = run3_at(gDU, pb);
+                auto move_all = [&](int bytes) { move3(rFT, bytes); move3<1>(rGT, bytes); move3(rE, bytes); move3(rDX, bytes); move3<1>(rDU, bytes); };
+                auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
                     const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
                     KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
                     knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
-                    d4 FT = gather_run(rFT, 1);
-                    d4 GT = gather_run<1>(rGT, 1);
-                    d4 E2 = gather_run(rE, 1);
-                    d4 DX = gather_run(rDX, 1);                 // (x_t - xd_t)[row] broadcast over columns
-                    d4 DU = gather_run<1>(rDU, 1);
+                    d4 FT = read3(rFT, imm);
+                    d4 GT = read3<1>(rGT, imm);
+                    d4 E2 = read3(rE, imm);
+                    d4 DX = read3(rDX, imm);                    // (x_t - xd_t)[row] broadcast over columns
+                    d4 DU = read3<1>(rDU, imm);
                     d4 U2;
                     riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                     acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
                     if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                     if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
                 };
-                // two steps per trip, the sensitivity tile and the prefetched gains alternating between two register sets
+                // groups of U steps with literal row offsets, the sensitivity tile and the prefetched gains alternating between two register sets
                 d4 Xb, KTb, kb;
                 int tl = 0;
-                for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); fstep(tl + 1, Xb, X2, KTb, kb, KTn, kn); }
-                if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; }
+                for (; tl + U <= cnt; tl += U) {
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        if (j & 1) fstep(tl + j, (unsigned)(j * RF), Xb, X2, KTb, kb, KTn, kn);
+                        else fstep(tl + j, (unsigned)(j * RF), X2, Xb, KTn, kn, KTb, kb);
+                    }
+                    move_all(U * RF);
+                }
+                for (; tl < cnt; ++tl) { fstep(tl, 0u, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; move_all(RF); }
                 f3_signal(fl + 3, g + 1);
             }
         }
@@ -335,10 +389,6 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
         F3_W1();
         F3_STAMP();
         // ---- terminal condition and the constants of both groups
-        if (lane == 0) { blkB[0] = 0.0; blkF[0] = 0.0; }
-        for (int i_ = lane; i_ < Mdl::PATHA_NCONST; i_ += 64) blkB[1 + i_] = Mdl::patha_const(i_);
-        for (int i_ = lane; i_ < Mdl::PATHB_NCONST; i_ += 64) blkB[1 + Mdl::PATHA_NCONST + i_] = Mdl::pathb_const(i_);
-        for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blkF[1 + i_] = Mdl::fwd_const(i_);
         d4 Lam = z;                                              // costate tile: column 0 holds lambda_{t+1}; lambda_T = h_x(x_T)
         if (!given) {
             PDP_F3_PAR();
@@ -360,11 +410,14 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
         {
             constexpr int NA = F3::NA;
             auto codeA = [](int mat, int i) { return Mdl::patha_code(mat, i); };
-            Gather gF, gCX;
-            make_gather(gF, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
-            make_gather(gCX, lane, F3::NCB, BS, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
+            Gather3 gF, gCX;
+            make_gather3(gF, lane, F3::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeA(0, r * NX + c) : -1; });
+            make_gather3(gCX, lane, F3::CB0, [&](int r, int c) { return (r < NX && c == 0) ? codeA(3, r) : -1; });
+            constexpr int RB = 8 * BS;
             for (int g = 0; g < nchunk; ++g) {
-                const int c = nchunk - 1 - g, t0 = c * ch, cnt = min(ch, T - t0), bo = (g & 1) * F3::BUF;
+                int t0, cnt;
+                bchunk(g, t0, cnt);
+                const int bo = (g & 1) * F3::BUF;
                 double* pb = pool + bo;
                 F3_W0();
                 f3_wait_ge(fl + 3, g - 1);                       // the buffer's previous chunk has been consumed
@@ -377,13 +430,20 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                     for (int i = 0; i < NX; ++i) xc[i] = xb[t * NX + i];
 #pragma unroll
                     for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
-                    PackedSink s{pb + lane * BS};
+                    double* row = pb + lane * BS;
+                    PackedSink s{row};
                     Mdl::eval_patha(xc, uc, nullptr, th, pc, s);
+                    row[F3::CB0] = 0.0;                          // the row's own zero and constants (see Fused3Layout)
+#pragma unroll
+                    for (int i = 0; i < Mdl::PATHA_NCONST; ++i) row[F3::CB0 + 1 + i] = Mdl::patha_const(i);
+#pragma unroll
+                    for (int i = 0; i < Mdl::PATHB_NCONST; ++i) row[F3::CB0 + 1 + Mdl::PATHA_NCONST + i] = Mdl::pathb_const(i);
                 }
                 wave_lds_sync();
                 if (!given) {
                     // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
-                    GatherRun cF = gather_at3(gF, cnt - 1, blkB, bo), cC = gather_at3(gCX, cnt - 1, blkB, bo), wL;
+                    Run3 cF = run3_at(gF, pb + (cnt - 1) * BS), cC = run3_at(gCX, pb + (cnt - 1) * BS);
+                    GatherRun wL;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
                         const int row = tile_row(lane, r);
@@ -391,10 +451,10 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                         wL.cur[r] = valid ? lds_addr(pb) + 8u * (unsigned)((cnt - 1) * BS + NA + row) : lds_addr(misc + 5);
                         wL.tmul[r] = valid ? 8 * BS : 0;
                     }
-                    d4 Fc = gather_run(cF, -1), CX = gather_run(cC, -1);
+                    d4 Fc = read3(cF, 0u), CX = read3(cC, 0u);
                     auto cstep = [&](int tl, const d4 Lin, d4& Lout) {
                         d4 Fc_n = Fc, CX_n = CX;
-                        if (tl > 0) { Fc_n = gather_run(cF, -1); CX_n = gather_run(cC, -1); }
+                        if (tl > 0) { move3(cF, -RB); move3(cC, -RB); Fc_n = read3(cF, 0u); CX_n = read3(cC, 0u); }
                         scatter_run(wL, Lin, -1);
                         Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
                         Fc = Fc_n; CX = CX_n;
@@ -448,6 +508,9 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                     for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; double d = uc[i] - dub[t * NU + i]; row[DLU + i] = d; lsum += d * d; }
                     PackedSink s{row};
                     Mdl::eval_fwd(xc, uc, nullptr, th, pc, s);
+                    row[F3::CF0] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < Mdl::FWD_NCONST; ++i) row[F3::CF0 + 1 + i] = Mdl::fwd_const(i);
                 }
                 f3_signal(fl + 2, g + 1);
             }
