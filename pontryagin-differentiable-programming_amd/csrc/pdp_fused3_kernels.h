@@ -33,7 +33,7 @@ struct Fused3Layout {
     // its own copy of the (few) constant entries, so that every tile element - varying, constant or absent - sits at the same distance
     // from one row to the next: the time step becomes an immediate offset of the ds_read and the per-lane address registers are updated
     // once per U steps instead of once per step (the one-wave kernel keeps one constant pool and per-lane strides of 0 or one row).
-    static constexpr int NA = Mdl::PATHA_NVAR, NB = Mdl::PATHB_NVAR > NX ? Mdl::PATHB_NVAR : NX;
+    static constexpr int NA = Mdl::PATHA_NVAR, NB = Mdl::PATHB_NVAR > 16 ? Mdl::PATHB_NVAR : 16;      // (16: the costate tile's column 0 is stored whole)
     static constexpr int CB0 = NA + NB;                                          // slot of the row's 0.0; the constants follow
     static constexpr int BSTRIDE = (CB0 + NCB) | 1;
     static constexpr int CF0 = Mdl::FWD_NVAR + NX + NU;                          // forward row: [fwd | x - x_demo | u - u_demo | 0.0 | constants]
@@ -441,28 +441,34 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 }
                 wave_lds_sync();
                 if (!given) {
-                    // F_t and c_x,t do not depend on the recursion: they are gathered one step ahead of the MFMA chain that needs them
-                    Run3 cF = run3_at(gF, pb + (cnt - 1) * BS), cC = run3_at(gCX, pb + (cnt - 1) * BS);
-                    GatherRun wL;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {       // lambda_{t+1} goes to pool row tl; tile elements outside column 0 to a dead slot
-                        const int row = tile_row(lane, r);
-                        const bool valid = tile_col(lane) == 0 && row < NX;
-                        wL.cur[r] = valid ? lds_addr(pb) + 8u * (unsigned)((cnt - 1) * BS + NA + row) : lds_addr(misc + 5);
-                        wL.tmul[r] = valid ? 8 * BS : 0;
-                    }
-                    d4 Fc = read3(cF, 0u), CX = read3(cC, 0u);
-                    auto cstep = [&](int tl, const d4 Lin, d4& Lout) {
-                        d4 Fc_n = Fc, CX_n = CX;
-                        if (tl > 0) { move3(cF, -RB); move3(cC, -RB); Fc_n = read3(cF, 0u); CX_n = read3(cC, 0u); }
-                        scatter_run(wL, Lin, -1);
-                        Lout = mma_tn(Fc, Lin, CX);     // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
-                        Fc = Fc_n; CX = CX_n;
-                    };
-                    d4 Lam2 = z;
+                    // F_t and c_x,t do not depend on the recursion: they are requested one step ahead of the MFMA chain that needs them (two
+                    // register sets in rotation, like the costate tile itself - the chain of a step reads its predecessor's tile until its
+                    // last instruction).  Same addressing as the runner's loops: runs one row below the step's row, literal row offsets.
                     int tl = cnt - 1;
-                    for (; tl >= 1; tl -= 2) { cstep(tl, Lam, Lam2); cstep(tl - 1, Lam2, Lam); }
-                    if (tl == 0) { cstep(0, Lam, Lam2); Lam = Lam2; }
+                    const double* r0 = pb + (tl - 1) * BS;
+                    Run3 cF = run3_at(gF, r0), cC = run3_at(gCX, r0), wL;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wL.cur[r] = lds_addr(r0) + 8u * (unsigned)(NA + tile_row(lane, r));      // lambda_{t+1} -> row tl (column-0 lanes)
+                    auto move_all = [&](int bytes) { move3(cF, bytes); move3(cC, bytes); move3(wL, bytes); };
+                    d4 Fa = read3(cF, RB), CXa = read3(cC, RB), Fb = z, CXb = z, Lam2 = z;
+                    auto cstep = [&](int tl, unsigned imm, const d4 Fc, const d4 CXc, d4& Fn, d4& CXn, const d4 Lin, d4& Lout) {
+                        if (tl > 0) { Fn = read3(cF, imm - RB); CXn = read3(cC, imm - RB); }
+                        if (tile_col(lane) == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) *(PDP_LDS double*)(uintptr_t)(wL.cur[r] + imm) = Lin[r];
+                        }
+                        Lout = mma_tn(Fc, Lin, CXc);    // lambda_t = c_x(x_t,u_t) + F_t' lambda_{t+1}
+                    };
+                    for (; (tl + 1) % U != 0; --tl) { cstep(tl, RB, Fa, CXa, Fb, CXb, Lam, Lam2); Fa = Fb; CXa = CXb; Lam = Lam2; move_all(-RB); }
+                    move_all(-(U - 1) * RB);
+                    for (; tl >= U - 1; tl -= U) {
+#pragma unroll
+                        for (int j = 0; j < U; ++j) {
+                            if (j & 1) cstep(tl - j, (unsigned)((U - j) * RB), Fb, CXb, Fa, CXa, Lam2, Lam);
+                            else cstep(tl - j, (unsigned)((U - j) * RB), Fa, CXa, Fb, CXb, Lam, Lam2);
+                        }
+                        move_all(-U * RB);
+                    }
                     wave_lds_sync();
                 }
                 if (lane < cnt) {
