@@ -173,10 +173,11 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
             }
             f3_signal(fl + 0, 1);
         }
-        // ---- rollout x+ = f(x, u, theta): scalar recursion executed uniformly by the wave, staged in the (still unused) pool
+        // ---- rollout x+ = f(x, u, theta): scalar recursion executed uniformly by the wave.  u is staged in the (still unused) pool and read one
+        // step ahead; x_{t+1} goes straight to the API output from lane 0 - global stores are counted by vmcnt, which nothing in the loop
+        // waits for, while LDS stores would sit in front of the next step's u reads in the in-order LDS counter (probes/rollout_probe.hip)
         if (!given) {
-            double* xs = pool;                                   // (T+1) x NX
-            double* us = pool + (T + 1) * NX;                    // T x NU
+            double* us = pool;                                   // T x NU
             for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
             PDP_F3_PAR();
             double xc[NX], xn[NX], uc[NU];
@@ -184,10 +185,10 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
             for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+                for (int i = 0; i < NX; ++i) xb[i] = xc[i];
             }
             wave_lds_sync();
-            double un[NU];                                       // u_{t+1} is read from LDS while step t computes
+            double un[NU];
 #pragma unroll
             for (int i = 0; i < NU; ++i) un[i] = us[i];
             for (int t = 0; t < T; ++t) {
@@ -199,11 +200,9 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 for (int i = 0; i < NX; ++i) xc[i] = xn[i];
                 if (lane == 0) {
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+                    for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
                 }
             }
-            wave_lds_sync();
-            for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API output
         }
         f3_signal(fl + 0, 2);                                    // release: the trajectory is in memory, the staging area is free
         F3_STAMP();
