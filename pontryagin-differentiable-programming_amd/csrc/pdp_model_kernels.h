@@ -553,12 +553,11 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
 #endif
     PDP_STAMP();
 
-    // ---------------- phase R: trajectory x+ = f(x,u,theta) (scalar recursion, executed uniformly by all lanes), staged in the
-    // (still unused) LDS pool and written out coalesced.  The costates are NOT computed here: they are propagated on MFMA
+    // ---------------- phase R: trajectory x+ = f(x,u,theta) (scalar recursion, executed uniformly by all lanes; u staged in the
+    // still unused LDS pool).  The costates are NOT computed here: they are propagated on MFMA
     // inside the backward chunks (lambda_t = c_x + F_t' lambda_{t+1} with the F_t tiles the Riccati step gathers anyway).
     if (!(flags & PDP_OC_GIVEN_TRAJ)) {
-        double* xs = pool;                                   // (T+1) x NX
-        double* us = pool + (T + 1) * NX;                    // T x NU
+        double* us = pool;                                   // T x NU
         for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
         PDP_LOAD_PAR();
         double xc[NX], xn[NX], uc[NU];
@@ -566,7 +565,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+            for (int i = 0; i < NX; ++i) xb[i] = xc[i];
         }
         wave_lds_sync();
         PDP_ACC0();
@@ -580,14 +579,14 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            // x_{t+1} goes straight to the API output from lane 0: global stores are counted by vmcnt, which nothing in the loop waits
+            // for; LDS stores would sit in front of the next step's u reads in the in-order LDS counter (probes/rollout_probe.hip)
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+                for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
             }
         }
-        wave_lds_sync();
         PDP_ACC(6);
-        for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = xs[i];       // coalesced write-out of the API output
         __threadfence_block();                               // x is re-read below by other lanes of this wave
         wave_lds_sync();
     }
