@@ -23,6 +23,10 @@
 
 namespace pdp {
 
+#ifdef PDP_PHASE_TIMING
+__device__ long long g_rb_stamp[16];      // cycle stamps inside the last backward step of trajectory 0 (PDP_RB_T in pdp_riccati.h)
+#endif
+
 template <class Mdl>
 struct Fused3Layout {
     using L = FusedLayout<Mdl>;
@@ -270,6 +274,9 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 d4 Fa = read3(rF, RB), Ya = read3(rY, RB), Fb = z, Yb = z;
                 auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {      // imm: distance of row tl from the runs
                     const int t = t0 + tl;
+#ifdef PDP_PHASE_TIMING_FINE
+                    if (blockIdx.x == 0 && threadIdx.x == 0) g_rb_stamp[9] = __builtin_readcyclecounter();
+#endif
                     d4 Hxx = read3(rHxx, imm), HX2 = read3(rHX, imm), HU2 = read3<1>(rHU, imm), Grep = read3(rGr, imm), Hux = read3<1>(rHux, imm);
                     if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
@@ -277,6 +284,9 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                     ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
+#ifdef PDP_PHASE_TIMING_FINE
+                    if (blockIdx.x == 0 && threadIdx.x == 0) { g_rb_stamp[11] = g_rb_stamp[10]; g_rb_stamp[10] = __builtin_readcyclecounter(); }
+#endif
                 };
                 // single steps until a whole number of groups of U remains (the register sets move up by copies there)
                 for (; (tl + 1) % U != 0; --tl) { bstep(tl, RB, Fa, Ya, Fb, Yb); Fa = Fb; Ya = Yb; move_all(-RB); }
@@ -378,11 +388,15 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
 #ifdef PDP_PHASE_TIMING
         F3_STAMP();
         if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B); for (int i = 0; i < 12; ++i) o[i] = ts[i]; o[12] = twait; }
+        if (lane == 0 && b == 0) { long long* o = (long long*)(loss + B) + 32; for (int i = 0; i < 16; ++i) o[i] = g_rb_stamp[i]; }
         if (lane == 0) { long long* o = (long long*)(loss + B) + 64 + 4 * b; o[0] = rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = ts[nts - 1] - ts[0]; o[3] = twait; }
 #endif
     } else {
         // ========================================== evaluator ==========================================
-        __builtin_amdgcn_s_setprio(0);
+#ifndef PDP_F3_EVAL_PRIO
+#define PDP_F3_EVAL_PRIO 0
+#endif
+        __builtin_amdgcn_s_setprio(PDP_F3_EVAL_PRIO);
         F3_W0();
         f3_wait_ge(fl + 0, 2);                                   // parameters in LDS, trajectory in memory
         F3_W1();
@@ -421,6 +435,9 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 F3_W0();
                 f3_wait_ge(fl + 3, g - 1);                       // the buffer's previous chunk has been consumed
                 F3_W1();
+#ifdef PDP_F3_EXP_IDLE_EVALUATOR      // timing experiment only (wrong results): chunks >= 2 are not evaluated, the runner re-uses old pool contents
+                if (g >= 2) { f3_signal(fl + 2, g + 1); continue; }
+#endif
                 if (lane < cnt) {
                     PDP_F3_PAR();
                     const int t = t0 + lane;

@@ -8,6 +8,10 @@
 #endif
 #define PDP_HD __host__ __device__ inline
 #include PDP_MODEL_HEADER
+#ifdef PDP_PHASE_TIMING_FINE      // timing builds with -DPDP_PHASE_TIMING_FINE: cycle stamps inside the Riccati step of the fused3 runner (probes/phase_timing3.py)
+namespace pdp { extern __device__ long long g_rb_stamp[16]; }
+#define PDP_RB_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pdp::g_rb_stamp[i] = __builtin_readcyclecounter(); } while (0)
+#endif
 #include "pdp_model_kernels.h"
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"

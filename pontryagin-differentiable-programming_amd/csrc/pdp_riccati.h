@@ -73,16 +73,22 @@ PDP_DEV bool posdef_small(const double* a) {
 // does not depend on P) instead of being passed in - for callers that have no transposed copy of Hxu at hand.
 // WANT_PD: g.pd reports whether Quu is positive definite (multiple-shooting OC solver: the KKT matrix of the Newton step has the
 // right inertia iff every Quu of the sweep is positive definite).
+#ifndef PDP_RB_T
+#define PDP_RB_T(i)      // timing builds (probes/phase_timing3.py) define it to take a cycle stamp
+#endif
 template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false, bool WANT_PD = false>
 PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2, double Hux0,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
     if constexpr (HUX_FROM_HX2) tile_to_lds17(scratch, HX2, lane);
+    PDP_RB_T(0);
     d4 PF = mma_tn(P, Ft, z);        // P F        (P symmetric)
     d4 PY2 = mma_tn(P, Y2, W0);      // [P G | P E + W]
+    PDP_RB_T(1);
     d4 FY = mma_tn(Ft, PY2, HX2);    // [Hxu + F'PG | Hxe + F'(PE+W)] = [Qux' | Wn]
     d4 Q2 = z;
     Q2[0] = mma4_tn(Grep, PY2, HU2[0]);   // [Quu | Que] = [Huu | Hue] + G' [PG | PE+W]: 4 rows, 4 small MFMAs
+    PDP_RB_T(2);
     if constexpr (HUX_FROM_HX2) {
         wave_lds_sync();
         Hux0 = ((lane >> 4) < M) ? scratch[(lane & 15) * 17 + (lane >> 4)] : 0.0;      // Hux[i][c] = Hxu[c][i]
@@ -91,6 +97,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     Qux[0] = mma4_tn(Grep, PF, Hux0);     // Qux = Hux + G'PF   (m x n)
     d4 Pn = mma_tn(Ft, PF, Hxx);     // Hxx + F'PF
     P_old_out = P;
+    PDP_RB_T(3);
     // ---- m x m system Quu (element (i,j) lives in lane 16 i + j, register 0)
     const int row = lane >> 4, col = lane & 15;
     d4 Z = z;                                   // Z = Quu^-T in the top-left corner
@@ -102,6 +109,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         // Z[i][j] = inv[j][i] = C_ij / det.  ~27 fp64 operations per lane instead of ~140 for the uniform adjugate.
         scratch[544 + lane] = Q2[0];            // rows 0..3 of Q2, flat [row*16 + col]
         wave_lds_sync();
+        PDP_RB_T(4);
         const int i = row, j = col & 3;
         const int r0 = (i == 0) ? 1 : 0, r1 = (i <= 1) ? 2 : 1, r2 = (i <= 2) ? 3 : 2;
         const int c0 = (j == 0) ? 1 : 0, c1 = (j <= 1) ? 2 : 1, c2 = (j <= 2) ? 3 : 2;
@@ -155,6 +163,7 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
         Zrep = zz;
     }
     Z[0] = (col < 4) ? Zrep : 0.0;
+    PDP_RB_T(5);
     d4 K = z;
     K[0] = mma4_blk(Zrep, Qux[0], 0.0);   // Quu^-1 Qux            (m x n)
     g.IK = z;
@@ -166,13 +175,16 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     g.Qux = Qux;
     P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
     tile_to_lds17(scratch + 272, P, lane);
+    PDP_RB_T(6);
     d4 Wn = mms_tn_r0(Qux, g.IK, FY);     // [Qux' - Qux' I | Wn - Qux' k]
     // columns < M of Wn are Qux' - Qux' (Z Quu): zero only up to the rounding of Z Quu ~ I.  Left in, they perturb P G of the next
     // step and the error compounds over the horizon (quadrotor T = 50: parity lost) - they are masked out.
     W0 = keep_cols(Wn, M, M + p0, lane);
     g.IK = keep_cols(g.IK, M, M + p0, lane);
     wave_lds_sync();
+    PDP_RB_T(7);
     P = 0.5 * (P + tile_from_lds17_transposed(scratch + 272, lane));
+    PDP_RB_T(8);
     return ok;
 }
 

@@ -31,6 +31,8 @@ for B in (1024,):
           (B, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[5] - r[0], r[12]))
     print('       evaluator: start +%d | wait for trajectory until +%d | terminal done +%d | backward chunks done +%d | forward chunks done +%d | waiting %d' %
           (e[0] - t0, e[1] - t0, e[2] - t0, e[3] - t0, e[4] - t0, e[12]))
+    f = st[32:48]
+    if 'PDP_PHASE_TIMING_FINE' in os.environ.get('PDP_EXTRA', ''): print('       last backward step (t = 0): entry->T0 %d | PF,PY2 issued %d | FY,Q2 issued %d | Qux,Pn issued %d | Quu in LDS %d | Z ready %d | K,IK,P- issued %d | P in LDS %d | symmetrised %d | stores %d || previous step exit -> this exit %d' % (f[0]-f[9], f[1]-f[0], f[2]-f[1], f[3]-f[2], f[4]-f[3], f[5]-f[4], f[6]-f[5], f[7]-f[6], f[8]-f[7], f[10]-f[8], f[10]-f[11]))
     per = st[64:64 + 4 * B].reshape(B, 4)
     t00 = per[:, 0].min()
     print('       all trajectories (100 MHz clock -> us): first start 0, last start %.2f us | first end %.2f, last end %.2f us | cycles min %d median %d max %d | wait median %d max %d' %
