@@ -323,7 +323,7 @@ def main():
             "config": {"workload": "C3: quadrotor OC/IRL unit n=13 m=4 p=9 T=50, batch=%d trajectories per GPU, shared theta" % B,
                        "batch_per_gpu": B, "horizon": T,
                        "exchange": "all_gather([B,10] gradient|loss rows) over RCCL on a side stream, overlapped with the next step's kernel" if distributed else "none (1 GPU)"},
-            "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,

@@ -25,7 +25,7 @@ for name in ("fetch", "write"):
     out[key + "_KB_mean"] = sum(vals) / max(1, len(vals)); out[key + "_dispatches"] = len(vals)
 # gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of wide coalesced reads -> doubled; WRITE_SIZE as is
 out["oc_pdp_fused_kernel_hbm_bytes_per_launch"] = 1024.0 * (2.0 * out["FETCH_SIZE_KB_mean"] + out["WRITE_SIZE_KB_mean"])
-out["note"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs`, per dispatch of oc_pdp_fused_kernel (B=1024); FETCH_SIZE doubled (gfx950 correction of the guide), WRITE_SIZE uncorrected"
+out["note"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs`, per dispatch of the fused OC kernel (oc_pdp_fused3_kernel by default, B=1024); FETCH_SIZE doubled (gfx950 correction of the guide), WRITE_SIZE uncorrected"
 json.dump(out, open("gpurun_out/pmc_hbm_traffic_%s.json" % tag, "w"), indent=1)
 print(json.dumps(out, indent=1))
 import shutil
