@@ -447,7 +447,7 @@ def compile_model(name, force=False):
 
 
 def compile_core(force=False):
-    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_lqr_kernels.h", "pdp_lqr_stream_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
     return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force, flags=CORE_FLAGS)
 
 

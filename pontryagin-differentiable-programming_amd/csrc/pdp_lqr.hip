@@ -8,6 +8,8 @@
 #include <cstdio>
 #include "../../include/pdp_hip.h"
 #include "pdp_lqr_kernels.h"
+#include "pdp_lqr_stream_kernels.h"
+#include <cstdlib>
 
 using namespace pdp;
 
@@ -140,6 +142,10 @@ extern "C" {
 
 const char* pdp_hip_version(void) { return "pdp_hip 0.1 gfx950"; }
 
+#ifdef PDP_LQS_TIMING      // probe builds only (probes/lqr_stream_timing.py)
+int pdp_lqs_read_stamps(long long* out, void* stream) { hipLaunchKernelGGL(lqs_read_stamps, dim3(1), dim3(64), 0, (hipStream_t)stream, out); return launched(); }
+#endif
+
 int64_t pdp_lqr_workspace_bytes(int B, int T, int n, int m, int p, int want_costate) {
     int64_t per = (int64_t)n * m + (int64_t)m * p + (want_costate ? (int64_t)n * n + (int64_t)n * p : 0);
     return (int64_t)B * T * per * (int64_t)sizeof(double);
@@ -179,6 +185,23 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
             case 2: hipLaunchKernelGGL((lqr_solve_small_kernel<2>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
             case 3: hipLaunchKernelGGL((lqr_solve_small_kernel<3>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
             default: hipLaunchKernelGGL((lqr_solve_small_kernel<4>), grid, block, 0, s, pr, X, U, Lam, status, wg, wpw); break;
+        }
+        return launched();
+    }
+    // dense matrices from HBM, one parameter tile: the runner / streamer kernel (pdp_lqr_stream_kernels.h); PDP_LQR_VARIANT=1 keeps the one-wave kernel
+    static const int variant = [] { const char* e = std::getenv("PDP_LQR_VARIANT"); return e ? std::atoi(e) : 2; }();
+    if (variant == 2 && nt == 1 && lqs_ok(pr.n, pr.m, pr.p, Lam != nullptr)) {
+        const dim3 grid((pr.B + 3) / 4), block(512);
+        PDP_CLEAR();
+        switch (pr.m) {
+            case 1: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL((lqr_solve_stream_kernel<1>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
+            case 2: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL((lqr_solve_stream_kernel<2>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
+            case 3: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL((lqr_solve_stream_kernel<3>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
+            default: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    hipLaunchKernelGGL((lqr_solve_stream_kernel<4>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
         }
         return launched();
     }
