@@ -218,3 +218,15 @@ def test_lqr_guard_banded_operands_every_instantiation():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-u", os.path.join(root, "probes", "lqr_oob_probe.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "RESULT libpdp_hip.so: 0 of 16 instantiations mismatch" in r.stdout, r.stdout[-3000:]
+
+
+def test_one_wave_lqr_kernel_stays_parity_green():
+    """The runner / streamer kernel (lqr_solve_stream_kernel) is the default wherever it applies; the one-wave kernel behind it (more than one
+    parameter tile, the single-shooting solver's LQ step, PDP_LQR_VARIANT=1) must keep producing the same results: this file's reference /
+    oracle tests rerun in a process with the variant selected."""
+    import subprocess, sys
+    env = dict(os.environ, PDP_LQR_VARIANT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "matches_reference or matches_oracle_seeded or optional_inputs"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
