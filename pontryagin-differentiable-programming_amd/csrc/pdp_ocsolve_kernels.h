@@ -54,6 +54,26 @@ PDP_DEV void store_tile_column(double* __restrict__ dst, const d4 v, int R, int 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int row = tile_row(lane, r); if (row < R) dst[row] = v[r]; }
 }
+// the same through a BUFFER store: voff[r] = byte offset of this lane's row inside the column, or 0x80000000 where the lane holds no element of it - the
+// buffer's range check drops those lanes in hardware, so there is no predicated block (mask, branch, 64-bit address arithmetic) per register
+typedef unsigned pdp_u2 __attribute__((ext_vector_type(2)));
+struct ColStore { unsigned voff[4]; };
+PDP_DEV ColStore make_col_store(int R, int col, int lane) {
+    ColStore c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = tile_row(lane, r); c.voff[r] = (tile_col(lane) == col && row < R) ? 8u * (unsigned)row : 0x80000000u; }
+    return c;
+}
+template <int NR = 4, class RS>
+PDP_DEV void store_tile_column_buf(RS rs, unsigned soff, const ColStore& c, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double x = v[r];
+        pdp_u2 w;
+        w.x = (unsigned)__double2loint(x); w.y = (unsigned)__double2hiint(x);
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs, c.voff[r], soff, 0);
+    }
+}
 PDP_DEV double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -296,6 +316,10 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                                                                                : ((r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1); });
         make_gather(gE, lane, L::NC, L::FSTRIDE, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
         d4 X2 = z;
+        // dx, du, dlam leave through one buffer over the trajectory's [dx | du | dlam] block of the workspace
+        const ColStore csX = make_col_store(NX, M, lane), csU = make_col_store(NU, M, lane);
+        const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dxb, 0, (int)(((int64_t)(T + 1) * NX + (int64_t)T * NU + (int64_t)T * NX) * 8), 0x00020000);
+        const unsigned offU = (unsigned)((T + 1) * NX) * 8u, offL = offU + (unsigned)(T * NU) * 8u;
         // gains and P_{t+1}, W_{t+1} of step t are requested one step ahead (each lane re-reads what it stored in the backward sweep)
         d4 KTn = -load_all<NRT>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
@@ -339,9 +363,9 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                 riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                 Lm = mma_tn(Pc, Xn, Wc);                             // dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (P symmetric)
                 }
-                store_tile_column(dub + t * NU, U2, NU, M, lane);
-                store_tile_column(dxb + (t + 1) * NX, Xn, NX, M, lane);
-                store_tile_column(dlb + t * NX, Lm, NX, M, lane);
+                store_tile_column_buf<1>(rsD, offU + (unsigned)(t * NU) * 8u, csU, U2);
+                store_tile_column_buf<NRT>(rsD, (unsigned)((t + 1) * NX) * 8u, csX, Xn);
+                store_tile_column_buf<NRT>(rsD, offL + (unsigned)(t * NX) * 8u, csX, Lm);
             };
             d4 Xb, KTb, kb, Pb, Wb;
             int tl = 0;
