@@ -41,6 +41,33 @@ PDP_DEV d4 load_run(RunPtr& r, int dir) {          // read the current step's el
     return v;
 }
 
+// Branch-free stores of tiles into exact-size arrays through BUFFER instructions: every lane keeps, per tile register, the byte offset of its element
+// inside one time step's block - or 0x80000000 if the array has no such element, which the buffer's range check drops in hardware (num_records =
+// the trajectory's bytes of that array, far below 2 GB; 0 for an absent array: everything dropped); the time step is the instruction's scalar offset.
+// store_map's predicated stores cost a basic block each (mask reload, branch, 64-bit address arithmetic) - ~20 per backward step.
+typedef unsigned lqs_u2 __attribute__((ext_vector_type(2)));
+struct StoreMap { unsigned off[4]; };
+PDP_DEV StoreMap lqs_store_map(const TileMap& m) {
+    StoreMap r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.off[k] = m.off[k] >= 0 ? 8u * (unsigned)m.off[k] : 0x80000000u;
+    return r;
+}
+#define LQS_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+template <int NR = 4, class R>
+PDP_DEV void lqs_store(R rs, const StoreMap& m, unsigned soff, const d4 v) {
+#ifdef PDP_LQS_EXP_NOSTORE      // timing experiment only (wrong results)
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const double x = v[k];          // (bit-casting the vector element directly made every store write register 0's value)
+        lqs_u2 w;
+        w.x = (unsigned)__double2loint(x); w.y = (unsigned)__double2hiint(x);
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs, m.off[k], soff, 0);
+    }
+}
+
 // gains workspace per (b,t): KT [n*m] then k [m*p];  P/W workspace per (b,t): P [n*n] then W [n*p]
 template <int M, int NT>
 __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
@@ -59,6 +86,12 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
                   mMP = make_dense_map<false>(M, p0, p, 0, M, lane), mFT = make_dense_map<true>(n, n, n, 0, 0, lane),
                   mGT = make_dense_map<true>(n, M, M, 0, 0, lane), mNMrep = make_rep4_map(n, M, M, lane);   // G / K' replicated in the 4 column blocks
 
+    // first-parameter-tile outputs leave through range-checked buffer stores (one resource per array, this trajectory's part of it)
+    const StoreMap sNN = lqs_store_map(mNN), sNP = lqs_store_map(mNP), sNM = lqs_store_map(mNM), sMP = lqs_store_map(mMP);
+    const auto rPW = LQS_RSRC(ws_pw ? ws_pw + (int64_t)b * T * pwsz : ws_gain, ws_pw ? (int64_t)T * pwsz * 8 : 0);
+    const auto rG = LQS_RSRC(ws_gain + (int64_t)b * T * gsz, (int64_t)T * gsz * 8);
+    const auto rU = LQS_RSRC(Uo + (int64_t)b * T * M * p, (int64_t)T * M * p * 8), rX = LQS_RSRC(Xo + (int64_t)b * (T + 1) * n * p, (int64_t)(T + 1) * n * p * 8),
+               rL = LQS_RSRC(Lo ? Lo + (int64_t)b * T * n * p : Uo, Lo ? (int64_t)T * n * p * 8 : 0);
     // terminal condition: PP[T-1] = hxx, WW[T-1] = hxe (PDP.py:561-562)
     d4 P = load_map(mat_at(pr.hxx, b, 0), mNN);
     d4 W[NT];
@@ -95,8 +128,8 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
 #endif
         if (ws_pw) {   // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
             double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
-            store_map(pw, mNN, P);
-            store_map(pw + n * n, mNP, W[0]);
+            lqs_store(rPW, sNN, (unsigned)(t * pwsz) * 8u, P);
+            lqs_store(rPW, sNP, (unsigned)(t * pwsz + n * n) * 8u, W[0]);
 #pragma unroll
             for (int j = 1; j < NT; ++j) store_dense(pw + n * n + p0 + 16 * (j - 1), n, min(16, p - p0 - 16 * (j - 1)), p, 0, 0, lane, W[j]);
         }
@@ -108,8 +141,8 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
         ok = riccati_backward<M, true, true>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, 0.0, scratch, lane, p0, g, P_old) && ok;
 #endif
         double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
-        store_map(gw, mNM, g.KT);
-        store_map<1>(gw + n * M, mMP, g.IK);
+        lqs_store(rG, sNM, (unsigned)(t * gsz) * 8u, g.KT);
+        lqs_store<1>(rG, sMP, (unsigned)(t * gsz + n * M) * 8u, g.IK);
         if constexpr (NT > 1) {
             const double *E = mat_at(pr.E, b, t), *Hxe = mat_at(pr.Hxe, b, t), *Hue = mat_at(pr.Hue, b, t);
 #pragma unroll
@@ -173,12 +206,12 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
             d4 U, Xn;
             riccati_forward(KTn, kn, c.FT, c.GT, Et, X[j], U, Xn);
             X[j] = Xn;
-            if (j == 0) { store_map<1>(uo, mMP, U); store_map(xo, mNP, Xn); }
+            if (j == 0) { lqs_store<1>(rU, sMP, (unsigned)(t * M * p) * 8u, U); lqs_store(rX, sNP, (unsigned)((t + 1) * n * p) * 8u, Xn); }
             else { store_dense(uo + c0, M, w, p, 0, sh, lane, U); store_dense(xo + c0, n, w, p, 0, sh, lane, Xn); }
             if (lo) {
                 d4 Wt = (j == 0) ? c.Wt : load_dense<false>(pw + n * n + c0, n, w, p, 0, sh, lane);
                 d4 L = mma_tn(c.Pt, Xn, Wt);                    // P x+ + W  (P symmetric)
-                if (j == 0) store_map(lo, mNP, L); else store_dense(lo + c0, n, w, p, 0, sh, lane, L);
+                if (j == 0) lqs_store(rL, sNP, (unsigned)(t * n * p) * 8u, L); else store_dense(lo + c0, n, w, p, 0, sh, lane, L);
             }
             finite = finite && tile_finite(Xn);
         }

@@ -86,33 +86,7 @@ PDP_DEV d4 lqs_read(const LqsGather& g, unsigned slot_addr) {
     return v;
 }
 
-// Branch-free stores of tiles into exact-size arrays through BUFFER instructions: every lane keeps, per tile register, the byte offset of its element
-// inside one time step's block - or 0x80000000 if the array has no such element, which the buffer's range check drops in hardware (num_records =
-// the trajectory's bytes of that array, far below 2 GB; 0 for an absent array: everything dropped); the time step is the instruction's scalar offset.
-// store_map's predicated stores cost a basic block each (mask reload, branch, 64-bit address arithmetic) - ~20 per backward step, about as long as
-// the step's arithmetic; per-lane pointers with a dump word for the absent elements (tried) made the dump lines a hot spot in L2.
-typedef unsigned lqs_u2 __attribute__((ext_vector_type(2)));
-struct StoreMap { unsigned off[4]; };
-PDP_DEV StoreMap lqs_store_map(const TileMap& m) {
-    StoreMap r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r.off[k] = m.off[k] >= 0 ? 8u * (unsigned)m.off[k] : 0x80000000u;
-    return r;
-}
-#define LQS_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
-template <int NR = 4, class R>
-PDP_DEV void lqs_store(R rs, const StoreMap& m, unsigned soff, const d4 v) {
-#ifdef PDP_LQS_EXP_NOSTORE      // timing experiment only (wrong results)
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const double x = v[k];          // (bit-casting the vector element directly made every store write register 0's value)
-        lqs_u2 w;
-        w.x = (unsigned)__double2loint(x); w.y = (unsigned)__double2hiint(x);
-        __builtin_amdgcn_raw_buffer_store_b64(w, rs, m.off[k], soff, 0);
-    }
-}
+// (range-checked buffer stores lqs_store / StoreMap / LQS_RSRC: pdp_lqr_kernels.h)
 
 template <int M>
 __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
