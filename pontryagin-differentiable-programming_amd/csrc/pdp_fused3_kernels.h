@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
     double* gw = ws_gain + (int64_t)b * T * GSZ;
     const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
     // backward chunks, last time steps first, of equal length.  (A short first chunk - the runner idles until the first chunk is ready - was
-    // tried: the evaluator, at low priority, then cannot fill the SECOND chunk within the few steps the runner spends on the first, and the
-    // runner waits there instead: 0.1107 ms against 0.1093 ms.)
+    // tried twice: the evaluator, at low priority, then cannot fill the SECOND chunk within the few steps the runner spends on the first, and
+    // the runner waits there instead: first chunk of 5 steps 0.1107 against 0.1093 ms at the time, 8 | 16 | 16 | 10 steps 210 k against 207 k cycles.)
     const int nchunk = (T + F3::ROWS - 1) / F3::ROWS;
     const int ch = (T + nchunk - 1) / nchunk;
     auto bchunk = [&](int g, int& t0, int& cnt) { const int c = nchunk - 1 - g; t0 = c * ch; cnt = min(ch, T - t0); };      // chunk g covers [t0, t0 + cnt)
@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
 
         // ---- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, gradient
         double acc = 0.0, lsum = 0.0;
+        const double dT = lane < NX ? xb[T * NX + lane] - dxb[T * NX + lane] : 0.0;      // terminal residual, requested ahead of the loops that hide its latency
         d4 X2 = z;
         {
             constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
         F3_STAMP();
         // terminal term (x_T - xd_T)' X_T   (cartpole_PDP.py:74)
         wave_lds_sync();
-        if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+        if (lane < NX) { dlT[lane] = dT; lsum += dT * dT; }
         wave_lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
