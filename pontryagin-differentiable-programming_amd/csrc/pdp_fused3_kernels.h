@@ -180,7 +180,11 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
         // ---- rollout x+ = f(x, u, theta): scalar recursion executed uniformly by the wave.  u is staged in the (still unused) pool and read one
         // step ahead; x_{t+1} goes straight to the API output from lane 0 - global stores are counted by vmcnt, which nothing in the loop
         // waits for, while LDS stores would sit in front of the next step's u reads in the in-order LDS counter (probes/rollout_probe.hip)
-        if (!given) {
+        double xTr[NX];                                          // x_T stays in registers for the terminal condition (no round trip through memory)
+        if (given) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xTr[i] = xb[T * NX + i];
+        } else {
             double* us = pool;                                   // T x NU
             for (int i = lane; i < T * NU; i += 64) us[i] = ub[i];
             PDP_F3_PAR();
@@ -207,6 +211,8 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                     for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xTr[i] = xc[i];
         }
         f3_signal(fl + 0, 2);                                    // release: the trajectory is in memory, the staging area is free
         F3_STAMP();
@@ -219,11 +225,8 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
             for (int i_ = lane; i_ < Mdl::FIN_NCONST; i_ += 64) fin[1 + i_] = Mdl::fin_const(i_);
             if (lane == 0) {
                 PDP_F3_PAR();
-                double xT[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) xT[i] = xb[T * NX + i];
                 PackedSink s{fin + F3::NCFIN};
-                Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
+                Mdl::eval_fin(xTr, nullptr, nullptr, th, pc, s);
             }
             wave_lds_sync();
             Gather gP, gW;
