@@ -61,6 +61,9 @@ __host__ __device__ constexpr bool fused3_ok(int T) {
     return Mdl::NX > 4 && F3::ROWS >= 4 && F3::ROWSF >= 4 && (T + 1) * Mdl::NX + T * Mdl::NU <= 2 * F3::BUF;
 }
 
+typedef unsigned f3_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned f3_u4 __attribute__((ext_vector_type(4)));
+
 // counters in LDS: release / acquire at workgroup scope (LDS and - for the trajectory the runner leaves in global memory - the CU's L1)
 PDP_DEV void f3_signal(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 PDP_DEV void f3_wait_ge(int* f, int v) {
@@ -196,6 +199,8 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 for (int i = 0; i < NX; ++i) xb[i] = xc[i];
             }
             wave_lds_sync();
+            const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((T + 1) * NX * 8), 0x00020000);
+            const unsigned xvoff = lane == 0 ? 0u : 0x80000000u;
             double un[NU];
 #pragma unroll
             for (int i = 0; i < NU; ++i) un[i] = us[i];
@@ -206,9 +211,21 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                 Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xc[i] = xn[i];
-                if (lane == 0) {
+                // x_{t+1} to the API output from lane 0, without a branch: a buffer store whose offset is out of range in every other lane
+                {
+                    const unsigned so = (unsigned)((t + 1) * NX) * 8u;
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
+                    for (int i = 0; i + 1 < NX; i += 2) {
+                        f3_u4 w;
+                        w.x = (unsigned)__double2loint(xn[i]); w.y = (unsigned)__double2hiint(xn[i]);
+                        w.z = (unsigned)__double2loint(xn[i + 1]); w.w = (unsigned)__double2hiint(xn[i + 1]);
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rsX, xvoff + 8u * i, so, 0);
+                    }
+                    if constexpr (NX & 1) {
+                        f3_u2 w;
+                        w.x = (unsigned)__double2loint(xn[NX - 1]); w.y = (unsigned)__double2hiint(xn[NX - 1]);
+                        __builtin_amdgcn_raw_buffer_store_b64(w, rsX, xvoff + 8u * (NX - 1), so, 0);
+                    }
                 }
             }
 #pragma unroll

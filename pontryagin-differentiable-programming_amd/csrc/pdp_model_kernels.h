@@ -388,6 +388,8 @@ __global__ void __launch_bounds__(64) oc_ls_select_kernel(int B, int T, int K, c
 // ------------------------------------------------------------------------------------------------------
 // OC: fused forward + costates + aux system (LDS) + Riccati + PDP gradient, one wavefront per trajectory
 // ------------------------------------------------------------------------------------------------------
+typedef unsigned pdp_u2x __attribute__((ext_vector_type(2)));
+typedef unsigned pdp_u4 __attribute__((ext_vector_type(4)));
 struct Gather { int off[4]; int tmul[4]; };
 // running form: cur[r] is the ABSOLUTE LDS byte address of the element for the current step (the base of the dynamic LDS block is a
 // link-time constant the compiler cannot fold: added once here, not as a VALU add in front of every ds_read); the ds_read / ds_write
@@ -568,6 +570,8 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             for (int i = 0; i < NX; ++i) xb[i] = xc[i];
         }
         wave_lds_sync();
+        const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((T + 1) * NX * 8), 0x00020000);
+        const unsigned xvoff = lane == 0 ? 0u : 0x80000000u;
         PDP_ACC0();
         double un[NU];                                       // u_{t+1} is read from LDS while step t computes
 #pragma unroll
@@ -580,10 +584,23 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
             // x_{t+1} goes straight to the API output from lane 0: global stores are counted by vmcnt, which nothing in the loop waits
-            // for; LDS stores would sit in front of the next step's u reads in the in-order LDS counter (probes/rollout_probe.hip)
-            if (lane == 0) {
+            // for; LDS stores would sit in front of the next step's u reads in the in-order LDS counter (probes/rollout_probe.hip).  No
+            // branch either: a buffer store whose offset is out of range in every other lane (a conditional block makes the waits that
+            // follow it conservative).
+            {
+                const unsigned so = (unsigned)((t + 1) * NX) * 8u;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
+                for (int i = 0; i + 1 < NX; i += 2) {
+                    pdp_u4 w;
+                    w.x = (unsigned)__double2loint(xn[i]); w.y = (unsigned)__double2hiint(xn[i]);
+                    w.z = (unsigned)__double2loint(xn[i + 1]); w.w = (unsigned)__double2hiint(xn[i + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsX, xvoff + 8u * i, so, 0);
+                }
+                if constexpr (NX & 1) {
+                    pdp_u2x w;
+                    w.x = (unsigned)__double2loint(xn[NX - 1]); w.y = (unsigned)__double2hiint(xn[NX - 1]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsX, xvoff + 8u * (NX - 1), so, 0);
+                }
             }
         }
         PDP_ACC(6);
