@@ -269,7 +269,7 @@ template <class Mdl, int NT>
 int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,
                    double* u, void* st) {
     const size_t lds = sizeof(double) * (1 + Mdl::PATH_NCONST + Mdl::CHUNK * (Mdl::PATH_NVAR | 1) + (size_t)(T + 1) * Mdl::NX + (size_t)T * Mdl::NU +
-                                         (size_t)T * pol->n_pivots + Mdl::NX + 8);
+                                         (size_t)T * pol->n_pivots + Mdl::NX + 8 + 64 + (Mdl::NX > Mdl::NU ? Mdl::NX : Mdl::NU));
     if (lds > 150 * 1024) return PDP_E_SIZE;
     (void)hipFuncSetAttribute((const void*)cp_step_poly_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PDP_CLEAR();

@@ -1067,6 +1067,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     double* us = xs + (T + 1) * NX;          // T x NU
     double* basis = us + T * NU;             // T x n_pivots
     double* hx = basis + T * pol.n_pivots;   // NX
+    double* dump = hx + NX + 8;              // 64 + max(NX, NU) words nobody reads (see the rollout)
     const int b = blockIdx.x, lane = threadIdx.x, np = pol.n_pivots;
     const int tile0 = blockIdx.y * NT;         // a batch smaller than the machine spreads its parameter tiles over grid.y (rollout repeated)
     const double* th = theta + (int64_t)b * tb;
@@ -1100,11 +1101,15 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
             J += Mdl::path_cost(xc, uc, nullptr, pc);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
-            if (lane == 0) {
+            // x_{t+1}, u_t into the LDS staging from lane 0 WITHOUT a conditional block (it would make the wait in front of the next step's basis
+            // reads a full lgkmcnt(0)): every lane stores, the others into a private dump word behind the staging
+            {
+                double* dx_ = lane == 0 ? xs + (t + 1) * NX : dump + lane;
+                double* du_ = lane == 0 ? us + t * NU : dump + lane;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+                for (int i = 0; i < NX; ++i) dx_[i] = xn[i];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) us[t * NU + j] = uc[j];
+                for (int j = 0; j < NU; ++j) du_[j] = uc[j];
             }
         }
         J += Mdl::final_cost(xc, nullptr, pc);
