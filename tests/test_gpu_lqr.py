@@ -50,7 +50,7 @@ def test_lqr_matches_reference_on_demo_aux_systems(golden_dir, name):
 
 
 @pytest.mark.parametrize("n,m,p,T,B", [(13, 4, 9, 50, 64), (13, 3, 10, 100, 16), (4, 1, 7, 50, 256), (16, 4, 12, 8, 3), (7, 2, 40, 11, 5),
-                                        (13, 4, 60, 6, 2), (2, 1, 1, 1, 1), (5, 3, 13, 2, 4)])
+                                        (13, 4, 60, 6, 2), (2, 1, 1, 1, 1), (5, 3, 13, 2, 4), (13, 4, 9, 1, 5), (9, 2, 5, 3, 7), (6, 1, 15, 5, 2)])
 def test_lqr_matches_oracle_seeded(n, m, p, T, B):
     from oracle import pdp_oracle as po
     from pdp_amd import runtime as rt
