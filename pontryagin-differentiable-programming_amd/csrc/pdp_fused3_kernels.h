@@ -108,7 +108,6 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
                                                             double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
                                                             double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
     using F3 = Fused3Layout<Mdl>;
-    using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>(), GSZ0 = fused_gain0_doubles<Mdl>();
     constexpr int BS = F3::BSTRIDE, FS = F3::FSTRIDE;
