@@ -58,43 +58,89 @@ def synth_inputs(batch, seed):
     return x0, u, demo_x, demo_u
 
 
-def cpu_baseline(budget_s=12.0, threads=None):
-    """The oracle's C restatement (oracle/libpdp_oracle.so, OpenMP) when built, else the numpy oracle, timed on a bounded
-    sample of the same workload on this host's cores.  Reported beside the GPU number; never the thing measured above."""
-    cores = threads or os.cpu_count() or 1
-    x0, u, dx, du = synth_inputs(int(min(8192, max(256, 16 * cores))), 12345)      # >= 16 trajectories per core for the OpenMP port
+def effective_cores():
+    """Cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
+    host with a 16-CPU quota has 16, whatever os.cpu_count() says)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:                                                        # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                    # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(np.ceil(quota))))
+    return n
+
+
+def cpu_baseline(budget_s=16.0):
+    """The oracle's C restatement (oracle/pdp_oracle.c, OpenMP over the batch), rebuilt for this host with -O3 -march=native, timed on a
+    bounded sample of the same workload: first on one thread, then on every core this process may use (effective_cores) and - when that
+    scales poorly - on half of them (SMT siblings); the best is reported, with the 1 -> N scaling efficiency in `sample`.  Buffers are
+    allocated and touched before the timed loops.  Reported beside the GPU number; never the thing measured above."""
+    cores = effective_cores()
     th = np.array(THETA)
     try:
         from oracle import c_oracle
-        lib = c_oracle.load()
+        native = c_oracle.build_native()
+        lib = c_oracle.load(path=native) if native else c_oracle.load()
     except Exception:
-        lib = None
-    if lib is not None:
-        n = min(len(x0), 4 * cores)
-        t0 = time.perf_counter()
-        c_oracle.quadrotor_oc_unit(lib, x0[:n], u[:n], th, dx[:n], du[:n], threads=cores)
+        lib, native = None, None
+    if lib is None:
+        from oracle import models, pdp_oracle as po
+        x0, u, dx, du = synth_inputs(256, 12345)
+        st = models.IRL_SETUP["quadrotor"]
+        oc = po.make_oc(models.REGISTRY["quadrotor"](**st["kwargs"]), st["dt"])
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and done < len(x0):
+            po.pdp_oc_unit(oc, x0[done], u[done], th, dx[done], du[done])
+            done += 1
         dt = time.perf_counter() - t0
-        n = int(min(len(x0), max(n, n * budget_s / max(dt, 1e-6) / 8)))
-        reps, t_tot, done = 0, 0.0, 0
-        while t_tot < budget_s / 2:
+        return {"value": done / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
+                "sample": "%d quadrotor trajectories (T=50), numpy restatement of PDP.py (oracle/pdp_oracle.py), 1 thread" % done}
+
+    def rate(threads, seconds):
+        n = int(min(32768, max(256, 64 * threads)))            # >= 64 trajectories per thread and call: thread wake-up is noise
+        x0, u, dx, du = synth_inputs(n, 12345)
+        out = {"x": np.zeros((n, HORIZON + 1, N_STATE)), "lam": np.zeros((n, HORIZON, N_STATE)), "loss": np.zeros(n), "grad": np.zeros((n, N_PAR))}
+        c_oracle.quadrotor_oc_unit(lib, x0, u, th, dx, du, threads=threads, out=out)      # warm-up: threads started, pages touched
+        done, t_tot = 0, 0.0
+        while t_tot < seconds:
             t0 = time.perf_counter()
-            c_oracle.quadrotor_oc_unit(lib, x0[:n], u[:n], th, dx[:n], du[:n], threads=cores)
+            c_oracle.quadrotor_oc_unit(lib, x0, u, th, dx, du, threads=threads, out=out)
             t_tot += time.perf_counter() - t0
             done += n
-            reps += 1
-        return {"value": done / t_tot, "unit": "trajectories/s", "cores": cores, "kind": "port",
-                "sample": "%d x %d quadrotor trajectories (T=50), C restatement of PDP.py (oracle/pdp_oracle.c), %s" %
-                          (reps, n, "OpenMP over the batch" if cores > 1 else "1 thread")}
-    from oracle import models, pdp_oracle as po
-    st = models.IRL_SETUP["quadrotor"]
-    oc = po.make_oc(models.REGISTRY["quadrotor"](**st["kwargs"]), st["dt"])
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and done < len(x0):
-        po.pdp_oc_unit(oc, x0[done], u[done], th, dx[done], du[done])
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "trajectories/s", "cores": 1, "kind": "port",
-            "sample": "%d quadrotor trajectories (T=50), numpy restatement of PDP.py (oracle/pdp_oracle.py), 1 thread" % done}
+        return done / t_tot, done
+
+    r1, n1 = rate(1, budget_s * 0.25)
+    best, tried = (r1, 1, n1), [(1, r1)]
+    for t in ([cores] if cores > 1 else []):
+        r, n = rate(t, budget_s * 0.4)
+        tried.append((t, r))
+        if r > best[0]:
+            best = (r, t, n)
+        if r < 0.6 * t * r1 and t >= 4:                         # poor scaling: SMT siblings / shared quota - try the physical cores alone
+            r2, n2 = rate(t // 2, budget_s * 0.3)
+            tried.append((t // 2, r2))
+            if r2 > best[0]:
+                best = (r2, t // 2, n2)
+    eff = best[0] / (best[1] * r1)
+    return {"value": best[0], "unit": "trajectories/s", "cores": best[1], "kind": "port",
+            "one_thread": r1, "scaling_efficiency_1_to_N": eff, "cores_available": cores, "os_cpu_count": os.cpu_count(),
+            "tried_threads_rate": [[t, r] for t, r in tried],
+            "sample": "%d quadrotor trajectories (T=50, C3 inputs) on %d threads, C restatement of PDP.py (oracle/pdp_oracle.c, %s), OpenMP over the batch; "
+                      "1 thread: %.0f traj/s, %d threads: %.0f traj/s = %.0f %% of linear scaling" %
+                      (best[2], best[1], "rebuilt on this host with gcc -O3 -march=native" if native else "portable -O2 build", r1, best[1], best[0], 100 * eff)}
 
 
 def _event_ms(torch, fn, reps=10, warm=2):
@@ -339,7 +385,8 @@ def main():
             res["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-            res["cpu_baseline_1thread"] = cpu_baseline(budget_s=6.0, threads=1)
+            res["cpu_baseline_1thread"] = {"value": res["cpu_baseline"]["one_thread"], "unit": "trajectories/s", "cores": 1, "kind": "port",
+                                           "sample": "the same C restatement on one thread (like-for-like with the single-threaded reference)"}
         if world == 1 and not args.no_other_configs and B == BATCH:
             try:
                 res["other_configs"] = other_configs(torch)

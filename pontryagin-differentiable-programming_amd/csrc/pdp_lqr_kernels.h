@@ -256,6 +256,7 @@ template <int M>
 __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
                                                               double* __restrict__ Lo, int32_t* __restrict__ status,
                                                               double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
+    static_assert(M >= 1 && M <= 4, "four rows per trajectory: m <= 4 (larger control dimensions take lqr_solve_generic_kernel)");
     const int lane = threadIdx.x, row = lane >> 4, col = lane & 15, ci = col & 3;
     const int n = pr.n, p = pr.p, T = pr.T, B = pr.B;
     const int tlane = small_transpose_lane(lane);

@@ -15,6 +15,7 @@ namespace pdp { extern __device__ long long g_rb_stamp[16]; }
 #include "pdp_model_kernels.h"
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"
+#include "pdp_ocsolve2_kernels.h"
 #include "pdp_fused2_kernels.h"
 #include "pdp_fused3_kernels.h"
 #include <cstdlib>
@@ -37,6 +38,12 @@ inline int launched() {
 }
 #define PDP_CLEAR() (void)hipGetLastError()
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+[[maybe_unused]] inline int device_cu_count() {
+    static int n = 0;
+    if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
 
 template <class Mdl> constexpr bool fused_oc_ok() { return Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4 && Mdl::NU + Mdl::NP <= 16; }
 
@@ -166,7 +173,7 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
         pr.Hxu = {w.Hxu, (int64_t)T * n * m, n * m}; pr.Huu = {w.Huu, (int64_t)T * m * m, m * m}; pr.Hue = {w.dHu, (int64_t)T * m, m};
         pr.hxx = {w.hxx, n * n, 0}; pr.hxe = {w.hxe0, n, 0};
         auto lq = [&]() {
-            if constexpr (n <= 4)       // small systems: four trajectories per wavefront (pdp_riccati_small.h)
+            if constexpr (n <= 4 && m <= 4)       // small systems: four trajectories per wavefront (pdp_riccati_small.h; its tile rows hold m <= 4 controls)
                 hipLaunchKernelGGL((lqr_solve_small_kernel<m>), dim3((B + 3) / 4), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
             else if constexpr (n <= 16 && m <= 4)
                 hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
@@ -216,9 +223,26 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
 
+// Multiple-shooting solver variants (environment PDP_MS_VARIANT overrides): 2 = runner / evaluator wave pair per trajectory
+// (pdp_ocsolve2_kernels.h), the default wherever its LDS layout fits; 1 = one wavefront per trajectory (pdp_ocsolve_kernels.h).
+inline int ms_variant() { static const int v = [] { const char* e = std::getenv("PDP_MS_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
 template <class Mdl>
 int64_t oc_solve_ms_ws_bytes(int B, int T, int max_iter) {
-    if constexpr (Mdl::KIND == PDP_KIND_OC) return (int64_t)B * MsLayout<Mdl>::ws_doubles(T, max_iter < 0 ? 0 : max_iter) * (int64_t)sizeof(double); else return 0;
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        const int64_t a = (int64_t)B * MsLayout<Mdl>::ws_doubles(T, max_iter < 0 ? 0 : max_iter) * (int64_t)sizeof(double);
+        const int64_t c = ms2_ws_bytes<Mdl>(B, T, max_iter);
+        return a > c ? a : c;                       // either variant may serve the call
+    } else return 0;
+}
+template <class Mdl, int TPW>
+int oc_solve_ms2_launch(int B, int T, const pdp_oc_ms_opts* op, const double* x0, const double* th, int tb, double* x, double* u, double* lam, double* cost,
+                        double* resid, int32_t* converged, int32_t* iterations, int32_t* status, double* gains, double* iter_log, void* ws, void* st) {
+    constexpr int lds = TPW * Ms2Layout<Mdl>::SLICE * (int)sizeof(double);
+    (void)hipFuncSetAttribute((const void*)oc_solve_ms2_kernel<Mdl, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    PDP_CLEAR();
+    hipLaunchKernelGGL((oc_solve_ms2_kernel<Mdl, TPW>), dim3((B + TPW - 1) / TPW), dim3(128 * TPW), lds, S(st), B, T, *op, x0, th, tb, x, u, lam, cost, resid,
+                       converged, iterations, status, gains, op->log_rows > 0 ? iter_log : (double*)nullptr, (double*)ws);
+    return launched();
 }
 template <class Mdl>
 int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double* x, double* u, double* lam, double* cost, double* resid,
@@ -227,6 +251,16 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
     if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
         if (B <= 0 || T <= 0 || !x0 || !th || !x || !u || !lam || !op || !ws) return PDP_E_ARG;
         if (op->max_iter < 0 || wsb < oc_solve_ms_ws_bytes<Mdl>(B, T, op->max_iter)) return PDP_E_ARG;
+        if constexpr (ms2_ok<Mdl>()) {
+            if (ms_variant() == 2) {
+                // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
+                // batches spread over the CUs with the two waves of a trajectory on different SIMDs
+                const int cus = device_cu_count();
+                if (B <= cus) return oc_solve_ms2_launch<Mdl, 1>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
+                if (B <= 2 * cus) return oc_solve_ms2_launch<Mdl, 2>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
+                return oc_solve_ms2_launch<Mdl, 4>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
+            }
+        }
         const size_t lds = ms_lds_bytes<Mdl>();
         if (lds > 160 * 1024) return PDP_E_SIZE;
         (void)hipFuncSetAttribute((const void*)oc_solve_ms_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,11 +293,6 @@ int cp_auxsys(int B, int T, const pdp_policy* pol, int p, const double* x, const
         hipLaunchKernelGGL((cp_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, *pol, p, x, u, th, tb, F, G, Ux, Ue, cx, cu, hx);
         return launched();
     } else { return PDP_E_MODE; }
-}
-[[maybe_unused]] inline int device_cu_count() {
-    static int n = 0;
-    if (n == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
-    return n;
 }
 template <class Mdl, int NT>
 int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,

@@ -118,6 +118,14 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     double th[NP > 0 ? NP : 1], pc[Mdl::NPC];                             \
     _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) th[i_] = par[i_];  \
     _Pragma("unroll") for (int i_ = 0; i_ < Mdl::NPC; ++i_) pc[i_] = par[NP + i_]
+#ifdef PDP_MS_TIMING      // timing builds (probes/ms_phase_timing.py): cycles per phase and iteration in the iteration log instead of IPOPT's columns
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = 0, tmi = 0;
+#define MS_T0() tm0 = __builtin_readcyclecounter()
+#define MS_T1(k) do { const long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tm0; tm0 = now_; } while (0)
+#else
+#define MS_T0()
+#define MS_T1(k)
+#endif
     double* xb = x + (int64_t)b * (T + 1) * NX;
     double* ub = u + (int64_t)b * T * NU;
     double* lb = lam + (int64_t)b * T * NX;
@@ -179,6 +187,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         double a_f = 0.0, a_th = 0.0, a_pr = 0.0, a_du = 0.0, a_z = 0.0, a_l = 0.0, a_lc = 0.0;
         bool fin = true, pdall = true, ok = true;
         // terminal stage: P = hs hxx + dw I, W = h_x(x_T) - lambda_T
+        MS_T0();
         wave_lds_sync();
         if (lane == 0) blk[0] = 0.0;
         for (int i = lane; i < Mdl::FIN_NCONST; i += 64) blk[1 + i] = Mdl::fin_const(i);
@@ -220,6 +229,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         for (int c = nchunk - 1; c >= 0 && pdall; --c) {
             const int t0 = c * ch, cnt = min(ch, T - t0);
             wave_lds_sync();
+            MS_T1(1);
             if (lane < cnt) {                       // lane = stage: KKT matrices, defect, Lagrangian gradients at (x_t, u_t, lambda_{t+1})
                 PDP_MS_PAR();
                 const int t = t0 + lane;
@@ -254,6 +264,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                 a_f += Mdl::path_cost(xc, uc, th, pc);
             }
             wave_lds_sync();
+            MS_T1(2);
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
                       rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
             d4 Fa = gather_run<NRT>(rF, -1), Ya = gather_run<NRT>(rY, -1), Fb = z, Yb = z;
@@ -296,17 +307,20 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             int tl = cnt - 1;
             for (; tl >= 1 && pdall; tl -= 2) { bstep(tl, Fa, Ya, Fb, Yb); if (pdall) bstep(tl - 1, Fb, Yb, Fa, Ya); else break; }
             if (tl == 0 && pdall) bstep(0, Fa, Ya, Fb, Yb);
+            MS_T1(3);
         }
         pdall = pdall && ok;
         f_cur = wave_sum(a_f); th_cur = wave_sum(a_th); lamc = wave_sum(a_lc);
         inf_pr = wave_max(a_pr); inf_du = wave_max(a_du); zmax = wave_max(a_z); lmax = wave_max(a_l);
         finite = __all(fin) && (pdall ? (tile_finite(P) && tile_finite(W2)) : true);
         finite = __all(finite);
+        MS_T1(1);
         return pdall;
     };
 
     // Forward pass of the LQ problem: dx, du, dlam into the workspace; returns grad(phi)' d = grad(L)' d + lambda' c  (A d = -c)
     auto forward = [&](double hs) -> double {
+        MS_T0();
         wave_lds_sync();
         for (int i = lane; i < Mdl::SOLF_NCONST; i += 64) blk[1 + i] = Mdl::solf_const(i);
         Gather gFT, gGT, gE;
@@ -329,6 +343,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         for (int c = 0; c < nchunk; ++c) {
             const int t0 = c * ch, cnt = min(ch, T - t0);
             wave_lds_sync();
+            MS_T1(4);
             if (lane < cnt) {
                 PDP_MS_PAR();
                 const int t = t0 + lane;
@@ -342,6 +357,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                 Mdl::eval_solf(xc, uc, nullptr, th, pc, s);
             }
             wave_lds_sync();
+            MS_T1(5);
             GatherRun rFT = gather_at(gFT, 0, blk), rGT = gather_at(gGT, 0, blk), rE = gather_at(gE, 0, blk);
             auto fstep = [&](int tl, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, const d4 Pc, const d4 Wc, d4& KTnx, d4& knx, d4& Pnx, d4& Wnx) {
                 const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
@@ -371,13 +387,16 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             int tl = 0;
             for (; tl + 1 < cnt; tl += 2) { fstep(tl, X2, Xb, KTn, kn, Pq, Wq, KTb, kb, Pb, Wb); fstep(tl + 1, Xb, X2, KTb, kb, Pb, Wb, KTn, kn, Pq, Wq); }
             if (tl < cnt) { fstep(tl, X2, Xb, KTn, kn, Pq, Wq, KTb, kb, Pb, Wb); X2 = Xb; KTn = KTb; kn = kb; Pq = Pb; Wq = Wb; }
+            MS_T1(6);
         }
         __threadfence_block();
         wave_lds_sync();
         double gd = 0.0;
         for (int q = lane; q < T * NX; q += 64) gd += rxs[NX + q] * dxb[NX + q];
         for (int q = lane; q < T * NU; q += 64) gd += rus[q] * dub[q];
-        return wave_sum(gd) + lamc;
+        gd = wave_sum(gd) + lamc;
+        MS_T1(4);
+        return gd;
     };
 
     // objective and constraint violation of the trial point (x + a dx, u + a du): lane = stage
@@ -441,11 +460,16 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
     // ---- main loop.  Every trip runs ONE backward sweep (the lambdas above have a single call site each: one copy of the sweep code).
     // phase 0 (cold start only): IPOPT's least-squares multiplier estimate (constr_mult_init_max = 1000),
     //     [I A'; A 0] [w; lambda] = -[grad f; 0]  - the same sweep with W = I and no defects; phase 1: the iteration.
+#ifdef PDP_MS_TIMING
+    tmi = __builtin_readcyclecounter();
+#endif
     int st = 0, it = 0, nfilt = 0, conv = 0, phase = warm ? 1 : 0;
     double hs = warm ? 1.0 : 0.0, dw = warm ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
     for (;;) {
         if (phase == 1 && dw == 0.0) {              // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
+            MS_T0();
             residuals();
+            MS_T1(0);
             if (!finite) { st |= PDP_STATUS_NONFINITE; break; }
             if (it == 0) { theta_max = 1e4 * fmax(1.0, th_cur); theta_min = 1e-4 * fmax(1.0, th_cur); }
             if (inf_pr <= op.tol * (1.0 + zmax) && inf_du <= op.tol * (1.0 + lmax)) { conv = 1; if (!gains_out) break; }
@@ -489,6 +513,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         amin *= 0.05;
         double alpha = 1.0, ft = 0.0, tht = 0.0;
         bool accepted = false, ftype = false;
+        MS_T0();
         while (alpha >= amin) {
             trial(alpha, ft, tht);
             bool okf = fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308 && tht <= theta_max;
@@ -506,10 +531,23 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
             if (accepted) break;
             alpha *= 0.5;
         }
+        MS_T1(7);
+#ifdef PDP_MS_TIMING
+        if (iter_log && it < op.log_rows && lane == 0) {
+            double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
+            const long long now_ = __builtin_readcyclecounter();
+            // residuals | backward: terminal + reductions | backward evaluation | Riccati steps | forward evaluation + gd | (unused) | forward steps | line search; total of the iteration
+            row[0] = (double)tm[0]; row[1] = (double)tm[1]; row[2] = (double)tm[2]; row[3] = (double)tm[3]; row[4] = (double)(tm[4] + tm[5]); row[5] = (double)tm[6]; row[6] = (double)tm[7];
+            row[7] = (double)(now_ - tmi);
+            tmi = now_;
+            for (int k_ = 0; k_ < 8; ++k_) tm[k_] = 0;
+        }
+#else
         if (iter_log && it < op.log_rows && lane == 0) {
             double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
             row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? alpha : 0.0; row[6] = gd; row[7] = theta;
         }
+#endif
         if (!accepted) { st |= PDP_MS_RESTORATION; break; }
         if (!ftype) {                               // (at most one entry per iteration: the workspace holds max_iter + 1)
             if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
@@ -540,6 +578,8 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
         }
     }
 #undef PDP_MS_PAR
+#undef MS_T0
+#undef MS_T1
 }
 
 template <class Mdl>

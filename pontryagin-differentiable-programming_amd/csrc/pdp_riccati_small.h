@@ -35,6 +35,7 @@ struct SmallGains {
 template <int M>
 PDP_DEV bool riccati_small_backward(double& Prep, double& W2, double Frep, double Y2, double Grep, double Hxxrep, double HX2, double HU2, double Huxrep,
                                     int lane, int tlane, int p0, SmallGains& g) {
+    static_assert(M >= 1 && M <= 4, "the small-system algebra keeps the m x m control block in rows 0..3 of a tile: m <= 4");
     const int row = lane >> 4, col = lane & 15;
     const double PF = mma4_blk(Prep, Frep, 0.0);          // (P F) rep                       (P symmetric)
     const double PY2 = mma4_blk(Prep, Y2, W2);            // [P G | P E + W]

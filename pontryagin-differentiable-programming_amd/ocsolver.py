@@ -99,8 +99,15 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
         u0 = warm_start["control"][bi] if warm_start is not None else None
         sub = solve_batch_single_shooting(oc, x0[bi], horizon, thb, u_init=u0, tol=tol, max_iter=max_iter, print_level=print_level,
                                           neighbor_retries=neighbor_retries, want_gains=want_gains)
+        # a row is replaced only where the fallback did better: it converged, or - both unconverged - it ended at a finite point with a
+        # smaller stationarity residual than the multiple-shooting iterate (a non-finite or worse fallback result never overwrites it)
+        fin_sub = torch.isfinite(sub["cost"]) & torch.isfinite(sub["grad_norm"]) & torch.isfinite(sub["state"]).all(dim=(1, 2))
+        fin_ms = torch.isfinite(sol["cost"][bi]) & torch.isfinite(sol["grad_norm"][bi])
+        take = sub["converged"] | (fin_sub & (~fin_ms | (sub["grad_norm"] < sol["grad_norm"][bi])))
+        idx = bi[take]
         for k in ("state", "control", "costate", "cost", "grad_norm", "converged") + (("gains",) if want_gains else ()):
-            sol[k][bi] = sub[k]
+            sol[k][idx] = sub[k][take]
+        sol["status"][idx] = 0                                 # the multiple-shooting status bits no longer describe these rows
         sol["iterations"] += int(sub["iterations"])
     return sol
 

@@ -332,3 +332,49 @@ def test_user_model_with_20_states_runs_the_whole_class_surface():
     fd = (npy(oc.rollout_batch(xp, u[:1, :1], th)[0])[0, 1] - npy(oc.rollout_batch(xm, u[:1, :1], th)[0])[0, 1]) / (2 * eps)
     F0 = npy(oc.getAuxSys_batch(npy(xs)[:1, :2], u[:1, :1], np.zeros((1, 1, n)), th)["dynF"])[0, 0]
     assert np.abs(F0[:, 3] - fd).max() < 1e-8
+
+
+def test_oc_solver_small_state_many_controls_takes_the_generic_lq_kernel():
+    """n = 3 <= 4 but m = 5 > 4: the packed small-system LQ kernel keeps the m x m control block in four tile rows, so this shape must reach the
+    generic LDS kernel (round-2 advisor finding: the dispatch looked at n alone and silently produced wrong Newton steps).  The problem is
+    linear-quadratic, so the optimum is the solution of one KKT system: compared against numpy."""
+    from pdp_amd import PDP
+    from pdp_amd.sx import SX, dot, mtimes
+    rng = np.random.default_rng(33)
+    n, m, T, B = 3, 5, 12, 4
+    A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    Bm = 0.5 * rng.standard_normal((n, m))
+    X, U, w = SX.sym("x", n), SX.sym("u", m), SX.sym("w", 2)
+    oc = PDP.OCSys("wide")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(X)
+    oc.setControlVariable(U)
+    oc.setDyn(mtimes(SX(A), X) + mtimes(SX(Bm), U))
+    oc.setPathCost(w[0] * dot(X, X) + w[1] * dot(U, U))
+    oc.setFinalCost(3.0 * w[0] * dot(X, X))
+    th = np.array([1.3, 0.4])
+    x0 = rng.standard_normal((B, n))
+    sol = oc.ocSolver_batch(x0, T, th, method="single")
+    assert bool(sol["converged"].all())
+    # numpy: minimise sum q |x_t|^2 + r |u_t|^2 + 3 q |x_T|^2 subject to the dynamics, by condensing onto the controls
+    q, r = th
+    for i in range(B):
+        Phi = np.zeros(((T + 1) * n, T * m))
+        free = np.zeros(((T + 1) * n,))
+        xk = x0[i].copy()
+        free[:n] = xk
+        for t in range(T):
+            xk = A @ xk
+            free[(t + 1) * n:(t + 2) * n] = xk
+        for s in range(T):
+            blk = Bm.copy()
+            for t in range(s + 1, T + 1):
+                Phi[t * n:(t + 1) * n, s * m:(s + 1) * m] = blk
+                blk = A @ blk
+        Wx = np.full((T + 1) * n, q)
+        Wx[T * n:] = 3.0 * q
+        Hm = Phi.T @ (Wx[:, None] * Phi) + r * np.eye(T * m)
+        u_star = np.linalg.solve(Hm, -Phi.T @ (Wx * free)).reshape(T, m)
+        x_star = (free + Phi @ u_star.reshape(-1)).reshape(T + 1, n)
+        assert np.abs(npy(sol["control"])[i] - u_star).max() <= 1e-9 * (1 + np.abs(u_star).max())
+        assert np.abs(npy(sol["state"])[i] - x_star).max() <= 1e-9 * (1 + np.abs(x_star).max())
