@@ -271,6 +271,134 @@ def other_configs(torch):
     return res
 
 
+def scaling_configs(torch, dist, world, rank, steps):
+    """BASELINE.json configs[3] / configs[4] as they are DEFINED: a fixed total batch (C4: 4096 rocket trajectories, C5: 8192 quadrotor
+    trajectories) cut into contiguous shards over the N ranks of this run (strong scaling; N = 1 runs the whole batch on one GPU), every rank
+    running the same fused kernels on its shard, one RCCL all-gather of the per-sample [B/N, p+1] (gradient | loss) rows per step on a side
+    stream, overlapped with the next step's kernel (pdp_amd.parallel.OverlappedGather).  Per entry: per-rank kernel_ms (HIP events), the blocking
+    exchange alone (exchange_us), the overlapped step time (max over ranks) and the aggregate trajectories/s = total batch / step time."""
+    from pdp_amd import JinEnv, parallel, runtime as rt, zoo
+    res = {}
+    distributed = world > 1
+    steps = max(3, min(steps, 20))
+
+    def run(name, B_total, p, make_unit, flop, note):
+        lo, hi = parallel.shard_bounds(B_total, world, rank)
+        b = hi - lo
+        rng = np.random.default_rng(1234)                     # every rank draws the full batch and keeps its shard: shards do not depend on N
+        unit = make_unit(rng, B_total, lo, hi)
+        og = parallel.OverlappedGather(b, p + 1) if (distributed and B_total % world == 0) else None
+
+        def step():
+            if og is not None:
+                buf = og.next_buffer()
+            out = unit(buf if og is not None else None)
+            if og is not None:
+                if out is not None:                            # units without a packed-output mode: two small packing copies
+                    buf[:, :p].copy_(out[1])
+                    buf[:, p].copy_(out[0])
+                og.submit()
+
+        for _ in range(2):
+            step()
+        if og is not None:
+            og.drain()
+        torch.cuda.synchronize()
+        kern_ms = _event_ms(torch, lambda: unit(og.buffers[0] if og is not None else None), reps=5, warm=1)
+        exch_us = None
+        if og is not None:
+            exch_us = 1e3 * _event_ms(torch, lambda: parallel.gather_packed(og.buffers[0], out=og.gathered[0]), reps=5, warm=1)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if og is not None:
+            og.drain()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        stats = torch.tensor([kern_ms, exch_us if exch_us is not None else 0.0, dt / steps * 1e3, float(b)], dtype=torch.float64, device="cuda")
+        if distributed:
+            allr = torch.empty((world, 4), dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allr, stats)
+        else:
+            allr = stats[None]
+        allr = allr.cpu().numpy()
+        step_ms = float(allr[:, 2].max())
+        tf = flop * B_total / (step_ms * 1e-3) / 1e12
+        res[name] = {"total_batch": B_total, "shard_per_rank": [int(v) for v in allr[:, 3]], "scaling": "strong", "steps": steps,
+                     "kernel_ms_per_rank": [float(v) for v in allr[:, 0]], "exchange_us_per_rank": [float(v) for v in allr[:, 1]] if distributed else None,
+                     "exchange_bytes_per_rank": int(b * (p + 1) * 8) if distributed else 0,
+                     "ms_per_step": step_ms, "traj_per_s": B_total / (step_ms * 1e-3),
+                     "algorithmic_flop_per_traj": flop, "achieved_tflops_all_gpus": tf, "frac_of_fp64_mfma_peak": tf / (FP64_MFMA_PEAK_TFLOPS * world), "note": note}
+
+    # ---- C4: rocket powered landing, T = 100, 4096 trajectories in total: fused OC unit (p = 10) and ControlPlanning.step (Lagrange policy, p = 18)
+    T4 = 100
+
+    def c4_inputs(rng, B):
+        x0 = np.zeros((B, 13))
+        x0[:, :3] = np.array([10, -8, 5.0]) + rng.standard_normal((B, 3))
+        x0[:, 3] = -0.1
+        x0[:, 6:10] = JinEnv.toQuaternion(1.5, [0, 0, 1])
+        u = np.tile(np.array([10.0, 0, 0]), (B, T4, 1)) + 0.1 * rng.standard_normal((B, T4, 3))
+        return x0, u
+
+    def c4_oc(rng, B, lo, hi):
+        mdl = zoo.get("rocket", "irl")
+        x0, u = c4_inputs(rng, B)
+        x0d, ud = rt.dev(x0[lo:hi]), rt.dev(u[lo:hi])
+        th = rt.dev(np.array([0.5, 1, 1, 1, 1, 1, 1, 50, 1, 1.0]))
+        dx, du = rt.dev(np.zeros((hi - lo, T4 + 1, 13))), rt.dev(np.zeros((hi - lo, T4, 3)))
+        bufs = {}
+
+        def unit(packed):
+            if packed is not None:
+                bufs["packed"] = packed
+            mdl.oc_pdp_grad(ud, th, dx, du, x0=x0d, buffers=bufs, packed=True)
+            return None
+        return unit
+
+    def c4_cp(rng, B, lo, hi):
+        mdl = zoo.get("rocket", "oc")
+        x0, _ = c4_inputs(rng, B)
+        x0d = rt.dev(x0[lo:hi])
+        thp, pol = rt.dev(0.5 * rng.standard_normal(18)), rt.make_policy("poly", pivots=np.linspace(0, T4, 6))
+        return lambda packed: mdl.cp_step(pol, 18, x0d, thp, T4)
+
+    run("C4_rocket_oc_unit_T100_p10_B4096", 4096, 10, c4_oc, 6.9e6, "BASELINE configs[3], U-OC: rollout + costates + aux system + Riccati + gradient")
+    run("C4_rocket_cp_step_T100_p18_B4096", 4096, 18, c4_cp, 0.95e6, "BASELINE configs[3], U-CP: ControlPlanning.step, Lagrange policy")
+
+    # ---- C5: quadrotor, T = 100, 8192 trajectories in total: SysID.step (p = 5) and neural-policy ControlPlanning.step (hidden [13, 13], p = 420)
+    T5 = 100
+
+    def c5_sysid(rng, B, lo, hi):
+        mdl = zoo.get("quadrotor", "sysid")
+        b = hi - lo
+        u5 = rt.dev((rng.uniform(-1, 1, (B, T5, 4)) + 2.5)[lo:hi])
+        x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (b, 1))
+        xobs = mdl.sysid_integrate(x0, u5, np.array([1, 1, 1, 1, .4]))
+        th5 = rt.dev(np.array([1.1, .95, 1.08, 1.03, .38]))
+        return lambda packed: mdl.sysid_step(u5, xobs, th5)
+
+    def c5_mlp(rng, B, lo, hi):
+        mdl = zoo.get("quadrotor", "oc")
+        x0 = np.zeros((B, 13))
+        x0[:, :3] = rng.uniform(-2, 2, (B, 3))
+        x0[:, 6] = 1
+        x0d = rt.dev(x0[lo:hi])
+        thp, pol = rt.dev(0.1 * rng.standard_normal(420)), rt.make_policy("mlp", layers=[13, 13, 4])
+        return lambda packed: mdl.cp_step(pol, 420, x0d, thp, T5)
+
+    run("C5_quadrotor_sysid_step_T100_p5_B8192", 8192, 5, c5_sysid, 0.18e6, "BASELINE configs[4], U-ID: SysID.step")
+    run("C5_quadrotor_mlp_step_T100_p420_B8192", 8192, 420, c5_mlp, 24.4e6,
+        "BASELINE configs[4], U-CP with the tanh-MLP policy [13, 13] (adjoint kernel: the 24.4 MFLOP figure counts the reference's forward sensitivities, "
+        "which the kernel does not execute); the exchange is %d x 421 doubles per rank" % (8192 // world))
+    return res if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +407,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default = config C3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-scaling-configs", action="store_true", help="skip the sharded C4 / C5 measurements (BASELINE configs[3], configs[4])")
     args = ap.parse_args()
 
     import torch
@@ -353,6 +482,13 @@ def main():
         per_rank = {"kernel_ms": allr[:, 0].tolist(), "exchange_us": allr[:, 1].tolist(), "ms_per_step": allr[:, 2].tolist()}
         dt = float(tmax.item())
 
+    scal = None
+    if not args.no_scaling_configs and B == BATCH:
+        try:
+            scal = scaling_configs(torch, dist, world, rank, args.steps)
+        except Exception as ex:              # the headline line must survive a failure of the side measurements (all ranks fail alike: no collective is left half-way)
+            scal = {"error": repr(ex)}
+
     if rank == 0:
         value = world * B * args.steps / dt
         traffic = None
@@ -383,6 +519,8 @@ def main():
         }
         if per_rank is not None:
             res["per_rank"] = per_rank
+        if scal is not None:
+            res["scaling_configs"] = scal
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["cpu_baseline_1thread"] = {"value": res["cpu_baseline"]["one_thread"], "unit": "trajectories/s", "cores": 1, "kind": "port",

@@ -35,7 +35,11 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "
 # out-of-bounds global reads on guard-banded operands, gone at -O1 and gone without the option (probes/lqr_oob_probe.py, DESIGN.md section 8;
 # profiles/r02_lqr_oob_root_cause.txt).  The kernel is HBM-bound: the option bought nothing there.
 CORE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("PDP_HIP_EXTRA_FLAGS", "").split()
-TUNED_LABELS = ("pendulum", "cartpole", "robotarm", "quadrotor", "rocket")        # zoo.py: the reference's five benchmark systems
+# Exact generated names (label + kind + content hash of the generated code) of the models that may be built with HIP_FLAGS: zoo.py registers
+# the reference's benchmark systems here.  Keyed on the HASH, not on the label: a user's own "quadrotor" with other dynamics, sizes or
+# horizon has another hash and is built with plain -O3 (round-2 advisor finding).  PDP_MFMA_VGPR_FORM=0 builds everything without the option,
+# =1 everything with it (tests/test_gpu_flag_fence.py compares the two builds of the headline models bit for bit).
+TUNED_NAMES = set()
 # OC models (the fused kernel): loop strength reduction rewrites the running LDS addresses of the step loops as (induction variable + 0)
 # and leaves a `v_add_u32 v, 0, v` in front of every ds_read (39 VALU instructions per time step); the loops already carry their own
 # running addresses.  Measured: fused kernel +5 % without LSR; the SysID / ControlPlanning kernels lose up to 12 % -> OC models only.
@@ -435,15 +439,25 @@ def _build(out, deps, cmd_tail, force, flags=None):
     return out
 
 
-def compile_model(name, force=False):
-    """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree)."""
-    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_ocsolve2_kernels.h", "pdp_fused2_kernels.h", "pdp_fused3_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
+def tuned(name):
+    env = os.environ.get("PDP_MFMA_VGPR_FORM")
+    if env is not None:
+        return env not in ("0", "")
+    return name in TUNED_NAMES
+
+
+def compile_model(name, force=False, plain_twin=False):
+    """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree).  plain_twin: the same model built with
+    CORE_FLAGS whatever tuned() says, as lib/libpdp_model_<name>__plain.so - the reference build tests/test_gpu_flag_fence.py compares with."""
+    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_ocsolve2_kernels.h", "pdp_fused3_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
-    # -amdgpu-mfma-vgpr-form (hidden LLVM option, +4 % on the headline kernel, but see CORE_FLAGS above) only for the benchmark systems,
-    # whose kernels are parity-tested one by one on NaN-dirtied memory; a user's model is built with plain -O3
-    flags = HIP_FLAGS if name.split("_")[0] in TUNED_LABELS else CORE_FLAGS
-    return _build(lib_path(name), deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force, flags=flags)
+    # -amdgpu-mfma-vgpr-form (hidden LLVM option, +4 % on the headline kernel, but see CORE_FLAGS above) only for the exact benchmark models
+    # (TUNED_NAMES), whose kernels are parity-tested one by one on NaN-dirtied memory and compared with their plain -O3 twins; a user's model
+    # is built with plain -O3
+    flags = HIP_FLAGS if (tuned(name) and not plain_twin) else CORE_FLAGS
+    out = lib_path(name + "__plain") if plain_twin else lib_path(name)
+    return _build(out, deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force, flags=flags)
 
 
 def compile_core(force=False):

@@ -16,7 +16,6 @@ namespace pdp { extern __device__ long long g_rb_stamp[16]; }
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"
 #include "pdp_ocsolve2_kernels.h"
-#include "pdp_fused2_kernels.h"
 #include "pdp_fused3_kernels.h"
 #include <cstdlib>
 
@@ -101,7 +100,7 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         if (lds > 160 * 1024) return PDP_E_SIZE;
         // Kernel variants (environment PDP_FUSED_VARIANT overrides the default): 3 = runner / evaluator wave pair per trajectory, four
         // trajectories per 512-thread workgroup (pdp_fused3_kernels.h) - the default wherever it applies (n > 4, rollout staging within the
-        // pool area); 1 = one wavefront per trajectory (systems with n <= 4, long horizons); 2 = the step-split experiment (pdp_fused2_kernels.h)
+        // pool area); 1 = one wavefront per trajectory (systems with n <= 4, long horizons)
         static const int variant = [] { const char* e = std::getenv("PDP_FUSED_VARIANT"); return e ? std::atoi(e) : PDP_FUSED_DEFAULT_VARIANT; }();
         PDP_CLEAR();
         if constexpr (Mdl::NX > 4) {
@@ -111,12 +110,6 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
                                    grad, dxdp, dudp, status, (double*)ws);
                 return launched();
             }
-        }
-        if (variant == 2 && Mdl::NX > 4) {
-            (void)hipFuncSetAttribute((const void*)oc_pdp_fused2_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((oc_pdp_fused2_kernel<Mdl>), dim3(B), dim3(128), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
-                               dudp, status, (double*)ws);
-            return launched();
         }
         (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,

@@ -62,10 +62,16 @@ struct Ms2Layout {
     static constexpr int PSZ = SMALL ? NX * NX : NX * (NX + 1) / 2;      // P_{t+1}: full (small systems keep it in rep form), else the upper triangle
     static constexpr int PWSZ = PSZ + NX;                                 //          | W_{t+1} [NX]
     __host__ __device__ static constexpr int pk(int i, int j) { return SMALL ? i * NX + j : (i <= j ? i * NX - i * (i - 1) / 2 + (j - i) : j * NX - j * (j - 1) / 2 + (i - j)); }
-    __host__ __device__ static constexpr int64_t res_doubles(int T) { return (int64_t)T * NX + (int64_t)(T + 1) * NX + (int64_t)T * NU; }      // c | grad_x L | grad_u L
-    // workspace per trajectory (doubles): dx | du | dlam | residual set 0 | residual set 1 | gains | P, W | filter (theta, phi)
+    // Everything the evaluator touches with one lane per stage is kept STAGE-MINOR: element (stage t, component i) at [i * TS + t], TS = T + 1 - a wave
+    // instruction of such a pass reads 64 consecutive doubles (4 cache lines).  In the API's stage-major layout [t][i] every lane sits in its own cache
+    // line: at B = 1024 (four trajectories per CU) the trial pass alone kept a CU's address unit busy for ~40 k cycles (profiles/r03_ms2_phase_timing_v1.txt).
+    // One group = [x-like (NX rows) | u-like (NU rows) | lambda-like (NX rows)] = (2 NX + NU) * TS doubles:
+    //     point set 0 | point set 1 (the iterate is in one, the trial point goes to the other) | step (dx | du | dlam) |
+    //     residual set 0 | residual set 1 (grad_x L | grad_u L | defect c)
+    // followed by the gains, (P, W) and the filter.  The API arrays are read once (warm start) and written once (the result).
+    __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
-        return (int64_t)(T + 1) * NX + (int64_t)T * NU + (int64_t)T * NX + 2 * res_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
+        return 5 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
     }
 };
 
@@ -79,11 +85,18 @@ __host__ __device__ constexpr bool ms2_ok() {
 #define PDP_MS_NOGAINS 32       /* status bit: gains were requested but no complete positive definite sweep exists at the returned point (zeros written) */
 
 // mailbox slots (ints) and result slots (doubles behind them)
-enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8 };
-enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_UPDATE = 3 };
+enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9 };
+// SWEEP: chunks of the iterate in set CUR.  TRIAL: residuals of CUR + alpha step -> set DST.  TRIAL_SWEEP: the same trial, then - speculating that the
+// runner accepts the point - straight on with the sweep of set DST (the runner aborts it otherwise)
+enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_TRIAL_SWEEP = 3 };
 enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, MS2_L = 6, MS2_LC = 7, MS2_FIN = 8 };
 
-PDP_DEV int ms2_load(int* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Mailbox values come out of LDS in vector registers although every lane reads the same word: said explicitly (v_readfirstlane), or every pointer and
+// branch derived from them would be treated as divergent - 64-bit per-lane addresses for each of the trial pass's ~100 loads, masked branches in the
+// runner's control flow
+PDP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+PDP_DEV double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+PDP_DEV int ms2_load(int* f) { return uni(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 // wait until *f >= v; false when the partner never gets there (watchdog) or the trajectory has been declared dead
 PDP_DEV bool ms2_wait_ge(int* f, int v, int* ctl) {
     int n = 0;
@@ -118,6 +131,11 @@ PDP_DEV d4 buf_load(RS rs, unsigned soff, const BufMap& m) {
     }
     return v;
 }
+
+// stage-minor access: UNIFORM row pointer (array base + component * stride: scalar registers) + this lane's byte offset (8 * stage, one VGPR shared by
+// every access of the pass) - the saddr + voffset form of global_load / global_store; `row[i * TS + t]` would carry a 64-bit address per component
+PDP_DEV double sm_ld(const double* row, unsigned off8) { return *(const double*)((const char*)row + off8); }
+PDP_DEV void sm_st(double* row, unsigned off8, double v) { *(double*)((char*)row + off8) = v; }
 
 template <class Mdl, int TPW>
 __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, pdp_oc_ms_opts op, const double* __restrict__ x0, const double* __restrict__ theta,
@@ -154,16 +172,17 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     double th[NP > 0 ? NP : 1], pc[Mdl::NPC];                             \
     _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) th[i_] = par[i_];  \
     _Pragma("unroll") for (int i_ = 0; i_ < Mdl::NPC; ++i_) pc[i_] = par[NP + i_]
-    double* xb = x + (int64_t)b * (T + 1) * NX;
+    double* xb = x + (int64_t)b * (T + 1) * NX;            // API arrays (stage-major): read at the start (warm), written at the end
     double* ub = u + (int64_t)b * T * NU;
     double* lb = lam + (int64_t)b * T * NX;
     double* w0 = ws + (int64_t)b * L::ws_doubles(T, op.max_iter);
-    double* dxb = w0;                                        // (T+1) x NX
-    double* dub = dxb + (int64_t)(T + 1) * NX;               // T x NU
-    double* dlb = dub + (int64_t)T * NU;                     // T x NX
-    double* rs0 = dlb + (int64_t)T * NX;                     // residual sets 0 / 1: c [T][NX] | grad_x L [T+1][NX] | grad_u L [T][NU]
-    const int64_t RES = L::res_doubles(T);
-    double* gw = rs0 + 2 * RES;                              // gains, T x GSZ
+    const int TS = T + 1;                                    // stride of the stage-minor arrays
+    const int64_t GRP = L::group_doubles(T);
+    const int OU = NX * TS, OL = (NX + NU) * TS;             // u-like / lambda-like rows inside a group
+    auto Pt = [&](int k) { return w0 + k * GRP; };           // point sets 0 / 1: x (t, i) at [i TS + t], u at [OU + i TS + t], lambda at [OL + i TS + t]
+    double* stp = w0 + 2 * GRP;                              // step: dx | du | dlam, same addressing
+    auto Rs = [&](int k) { return w0 + (3 + k) * GRP; };     // residual sets 0 / 1: grad_x L (T + 1 stages) | grad_u L | defect c
+    double* gw = w0 + 5 * GRP;                               // gains, T x GSZ
     double* pw = gw + (int64_t)T * GSZ;                      // P_{t+1}, W_{t+1}, T x PWSZ
     double* fth = pw + (int64_t)T * PWSZ;                    // filter: theta entries (at most one per iteration) ...
     double* fph = fth + (op.max_iter + 1);                   //         ... and phi entries
@@ -190,21 +209,36 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         }
         // ---- starting point: the caller's (x, u, lambda) [PDP_MS_WARM], or IPOPT's: w0 = 0 (PDP.py:155,166), x_0 = ini_state
         const bool warm = (op.flags & PDP_MS_WARM) != 0;
-        if (!warm) {
-            for (int i = lane; i < (T + 1) * NX; i += 64) xb[i] = i < NX ? x0[(int64_t)b * NX + i] : 0.0;
-            for (int i = lane; i < T * NU; i += 64) ub[i] = 0.0;
-            for (int i = lane; i < T * NX; i += 64) lb[i] = 0.0;
-        } else if (lane < NX) xb[lane] = x0[(int64_t)b * NX + lane];
-        for (int i = lane; i < NX; i += 64) dxb[i] = 0.0;   // x_0 is fixed
+        {
+            double* s0 = Pt(0);
+            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0); }
+            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = warm ? ub[q] : 0.0; }
+            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = warm ? lb[q] : 0.0; }
+            for (int i = lane; i < NX; i += 64) stp[i * TS] = 0.0;       // dx_0 = 0: x_0 is fixed
+        }
         bool dead = false;
         int seq = 0;
+#ifdef PDP_MS_TIMING      // timing builds (probes/ms_phase_timing.py): cycles per phase and iteration in the iteration log instead of IPOPT's columns
+        long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = 0, tmi = __builtin_readcyclecounter();
+#define MS2_T0() tm0 = __builtin_readcyclecounter()
+#define MS2_T1(k) do { const long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tm0; tm0 = now_; } while (0)
+#else
+#define MS2_T0()
+#define MS2_T1(k)
+#endif
         // commands: parameters first, then the sequence number with release semantics (LDS writes and global stores above are visible to the evaluator)
         auto issue = [&](int type, double alpha, int cur, int dst) {
             if (lane == 0) { ctl[MS2_TYPE] = type; ctl[MS2_CUR] = cur; ctl[MS2_DST] = dst; res[MS2_ALPHA] = alpha; ctl[MS2_PROD] = 0; ctl[MS2_CONS] = 0; }
             ++seq;
             f3_signal(ctl + MS2_SEQ, seq);
         };
-        auto wait_done = [&]() { if (!dead && !ms2_wait_ge(ctl + MS2_DONE, seq, ctl)) dead = true; };
+        auto wait_slot = [&](int slot_) {        // (the evaluator has the SIMD's issue slots while the runner has nothing to do)
+            __builtin_amdgcn_s_setprio(0);
+            if (!dead && !ms2_wait_ge(ctl + slot_, seq, ctl)) dead = true;
+            __builtin_amdgcn_s_setprio(3);
+        };
+        auto wait_done = [&]() { wait_slot(MS2_DONE); };
+        auto abort_sweep = [&]() { f3_signal(ctl + MS2_ABORT, seq); wait_done(); };
 
         // ---- loop-invariant gather / store maps
         auto codeS = [](int mat, int i) { return Mdl::sol_code(mat, i); };       // 0 F, 1 G, 2 Hxx, 3 Hxu, 4 Huu
@@ -243,8 +277,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         bool finite = true;
         auto read_res = [&]() {
             wave_lds_sync();
-            f_cur = res[MS2_F]; th_cur = res[MS2_TH]; inf_pr = res[MS2_PR]; inf_du = res[MS2_DU]; zmax = res[MS2_Z]; lmax = res[MS2_L]; lamc = res[MS2_LC];
-            finite = res[MS2_FIN] != 0.0;
+            f_cur = uni(res[MS2_F]); th_cur = uni(res[MS2_TH]); inf_pr = uni(res[MS2_PR]); inf_du = uni(res[MS2_DU]); zmax = uni(res[MS2_Z]); lmax = uni(res[MS2_L]);
+            lamc = uni(res[MS2_LC]);
+            finite = uni(res[MS2_FIN]) != 0.0;
         };
         bool PWfinite = true;
 
@@ -260,7 +295,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 int t0, cnt;
                 bchunk(g, t0, cnt);
                 const double* pb = pool + (g & 1) * L::BUF;
+                MS2_T0();
                 if (!ms2_wait_ge(ctl + MS2_PROD, g + 1, ctl)) { dead = true; break; }
+                MS2_T1(g == 0 ? 0 : 2);
                 if (g == 0) {       // terminal stage (the evaluator filled it before the first chunk): P = hs hxx + dw I, W = h_x(x_T) - lambda_T
                     Gather gP;
                     make_gather(gP, lane, L::NCFIN, 0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::fin_code(0, r * NX + (c & 3)) : -1)
@@ -328,6 +365,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     move_all(-U * RB);
                 }
                 if (pdall) f3_signal(ctl + MS2_CONS, g + 1);
+                MS2_T1(1);
             }
             pdall = pdall && ok && !dead;
             PWfinite = pdall ? __all(tile_finite(P) && tile_finite(W2)) : true;      // (an aborted sweep leaves P, W undefined)
@@ -345,12 +383,19 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             make_gather3(gE, lane, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
             make_gather3(gRX, lane, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FRX + r : -1; });
             make_gather3(gRU, lane, L::CF0, [](int r, int c) { return (r < M && c == M) ? L::FRU + r : -1; });
-            const ColStore csX = make_col_store(NX, M, lane), csU = make_col_store(NU, M, lane);
-            const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dxb, 0, (int)(((int64_t)(T + 1) * NX + (int64_t)T * NU) * 8), 0x00020000);
-            const unsigned offU = (unsigned)((T + 1) * NX) * 8u;
+            BufMap mDX, mDU;                                 // dx_{t+1} / du_t: column M of the tile, row i to [i TS + stage]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tile_row(lane, r);
+                mDX.voff[r] = (col == M && row < NX) ? 8u * (unsigned)(row * TS) : MS2_OOB;
+                mDU.voff[r] = (col == M && row < NU) ? 8u * (unsigned)(OU + row * TS) : MS2_OOB;
+            }
+            const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)stp, 0, (int)((int64_t)(NX + NU) * TS * 8), 0x00020000);
             // feedback gains of stage t are requested two steps ahead (three register sets in rotation)
             struct Gn { d4 KT, k; };
-            auto ldg = [&](int t) { const int tt = t < T ? t : T - 1; Gn s; const unsigned so = (unsigned)(tt * GSZ) * 8u; s.KT = -buf_load<NRT>(rsG, so, mKT); s.k = -buf_load<1>(rsG, so, mIK); return s; };
+            // (loaded as stored, +K and +k: a negation right behind the load would make the step wait for the loads it has just issued; the sign is
+            // absorbed in the products below: V = K x + k = -du, dx+ = F dx + c - G V)
+            auto ldg = [&](int t) { const int tt = t < T ? t : T - 1; Gn s; const unsigned so = (unsigned)(tt * GSZ) * 8u; s.KT = buf_load<NRT>(rsG, so, mKT); s.k = buf_load<1>(rsG, so, mIK); return s; };
             Gn A = ldg(0), Bn = ldg(1), Cn;
             Cn.KT = z; Cn.k = z;
             d4 X2 = z, Xb = z;
@@ -360,7 +405,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             for (int c = 0; c < nchunkF && !dead; ++c) {
                 const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0);
                 const double* pb = pool + (g & 1) * L::BUF;
+                MS2_T0();
                 if (!ms2_wait_ge(ctl + MS2_PROD, g + 1, ctl)) { dead = true; break; }
+                MS2_T1(2);
                 Run3 rFT = run3_at(gFT, pb), rGT = run3_at(gGT, pb), rE = run3_at(gE, pb), rRX = run3_at(gRX, pb), rRU = run3_at(gRU, pb);
                 auto move_all = [&](int bytes) { move3<NRT>(rFT, bytes); move3<1>(rGT, bytes); move3<NRT>(rE, bytes); move3<NRT>(rRX, bytes); move3<1>(rRU, bytes); };
                 auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, const Gn& cur, Gn& fill) {
@@ -372,19 +419,24 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     d4 RXn = read3<NRT>(rRX, imm);
                     d4 RUc = read3<1>(rRU, imm);
                     if (scaledE) E2 = E2 * hs;
-                    d4 U2;
+                    d4 U2 = z;
                     if constexpr (SMALL) {
-                        U2 = z; Xn = z;
-                        double u0, x1;
-                        riccati_small_forward(cur.KT[0], cur.k[0], FT[0], GT[0], E2[0], Xc[0], u0, x1);
-                        U2[0] = u0; Xn[0] = x1;
-                        acc += RXn[0] * x1 + RUc[0] * u0;
+                        Xn = z;
+                        const double v0 = mma4_blk(cur.KT[0], Xc[0], cur.k[0]);         // K dx + k = -du
+                        double x1 = mma4_blk(FT[0], Xc[0], E2[0]);                      // F dx + c
+                        x1 = mma4_blk(-GT[0], v0, x1);                                  // - G (K dx + k)
+                        U2[0] = -v0; Xn[0] = x1;
+                        acc += RXn[0] * x1 + RUc[0] * U2[0];
                     } else {
-                        riccati_forward(cur.KT, cur.k, FT, GT, E2, Xc, U2, Xn);
+                        d4 V = z;
+                        V[0] = mma4_tn(cur.KT, Xc, cur.k[0]);
+                        Xn = mma_tn(FT, Xc, E2);
+                        Xn = mms_tn_r0(GT, V, Xn);
+                        U2[0] = -V[0];
                         acc += RXn[0] * Xn[0] + RXn[1] * Xn[1] + RXn[2] * Xn[2] + RXn[3] * Xn[3] + RUc[0] * U2[0];
                     }
-                    store_tile_column_buf<1>(rsD, offU + (unsigned)(t * NU) * 8u, csU, U2);
-                    store_tile_column_buf<NRT>(rsD, (unsigned)((t + 1) * NX) * 8u, csX, Xn);
+                    buf_store<1>(rsD, (unsigned)t * 8u, mDU, U2);
+                    buf_store<NRT>(rsD, (unsigned)(t + 1) * 8u, mDX, Xn);
                 };
                 int tl = 0;
                 for (; tl + 3 <= cnt; tl += 3) {
@@ -396,6 +448,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 }
                 for (; tl < cnt; ++tl) { fstep(tl, 0u, X2, Xb, A, Cn); X2 = Xb; A = Bn; Bn = Cn; move_all(RF); }
                 f3_signal(ctl + MS2_CONS, g + 1);       // release: dx, du of the chunk are in memory
+                MS2_T1(3);
             }
             return wave_sum(acc) + lamc;
         };
@@ -405,7 +458,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         //     [I A'; A 0] [w; lambda] = -[grad f; 0]  - the same sweep with W = I and no defects; phase 1: the iteration.
         int st = 0, it = 0, nfilt = 0, conv = 0, phase = warm ? 1 : 0, cur = 0;
         double hs = warm ? 1.0 : 0.0, dw = warm ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
-        bool gains_ok = false;
+        bool gains_ok = false, pending = false;         // pending: the evaluator is already on the sweep of the current iterate (TRIAL_SWEEP)
         // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays)
         issue(MS2_CMD_TRIAL, 0.0, cur, cur);
         wait_done();
@@ -413,24 +466,28 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         for (;;) {
             if (dead) break;
             if (phase == 1 && dw == 0.0) {              // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
-                if (!finite) { st |= PDP_STATUS_NONFINITE; break; }
-                if (it == 0) { theta_max = 1e4 * fmax(1.0, th_cur); theta_min = 1e-4 * fmax(1.0, th_cur); }
-                if (inf_pr <= op.tol * (1.0 + zmax) && inf_du <= op.tol * (1.0 + lmax)) { conv = 1; if (!gains_out) break; }
-                else if (it >= op.max_iter) { st |= PDP_MS_MAXITER; break; }
+                bool stop_ = false;
+                if (!finite) { st |= PDP_STATUS_NONFINITE; stop_ = true; }
+                else {
+                    if (it == 0) { theta_max = 1e4 * fmax(1.0, th_cur); theta_min = 1e-4 * fmax(1.0, th_cur); }
+                    if (inf_pr <= op.tol * (1.0 + zmax) && inf_du <= op.tol * (1.0 + lmax)) { conv = 1; if (!gains_out) stop_ = true; }
+                    else if (it >= op.max_iter) { st |= PDP_MS_MAXITER; stop_ = true; }
+                }
+                if (stop_) { if (pending) abort_sweep(); break; }
             }
-            issue(MS2_CMD_SWEEP, 0.0, cur, cur);
+            if (!pending) issue(MS2_CMD_SWEEP, 0.0, cur, cur);
+            pending = false;
             const bool pd = backward(hs, dw);
             if (dead) break;
             if (conv || !pd || (phase == 1 && !PWfinite)) {         // the sweep ends here: tell the evaluator to drop the remaining chunks
-                f3_signal(ctl + MS2_ABORT, seq);
-                wait_done();
+                abort_sweep();
                 if (dead) break;
             }
             gains_ok = pd && PWfinite;
             if (conv) break;                            // (the sweep at the solution left the LQR gains in the workspace)
             if (phase == 0) {
                 if (!(pd && PWfinite)) {
-                    if (pd) { f3_signal(ctl + MS2_ABORT, seq); wait_done(); if (dead) break; }
+                    if (pd) { abort_sweep(); if (dead) break; }
                     phase = 1; hs = 1.0; dw = 0.0; continue;
                 }
             } else {
@@ -444,15 +501,19 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if (dw > 0.0) dw_last = dw;
             }
             const double gd = forward(hs);
+            MS2_T0();
             wait_done();                                // the evaluator has finished dlam
+            MS2_T1(4);
             if (dead) break;
             if (phase == 0) {
                 double lm = 0.0;
                 bool fin = true;
-                for (int q = lane; q < T * NX; q += 64) { const double v = dlb[q]; lm = fmax(lm, fabs(v)); fin = fin && fabs(v) <= 1.7e308; }
+                const double* dl_ = stp + OL;
+                for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) { const double v = dl_[q]; lm = fmax(lm, fabs(v)); fin = fin && fabs(v) <= 1.7e308; }
                 lm = wave_max(lm);
                 if (__all(fin) && lm <= 1000.0) {
-                    for (int q = lane; q < T * NX; q += 64) lb[q] = dlb[q];
+                    double* lc_ = Pt(cur) + OL;
+                    for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) lc_[q] = dl_[q];
                     issue(MS2_CMD_TRIAL, 0.0, cur, cur);        // the residuals change with the multipliers
                     wait_done();
                     read_res();
@@ -471,11 +532,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             double alpha = 1.0, ft = 0.0, tht = 0.0;
             bool accepted = false, ftype = false;
             while (alpha >= amin && alpha > 1e-300) {      // (the second bound only guards against amin = 0)
-                issue(MS2_CMD_TRIAL, alpha, cur, cur ^ 1);
-                wait_done();
+                issue(MS2_CMD_TRIAL_SWEEP, alpha, cur, cur ^ 1);
+                wait_slot(MS2_TDONE);
                 if (dead) break;
                 wave_lds_sync();
-                ft = res[MS2_F]; tht = res[MS2_TH];
+                ft = uni(res[MS2_F]); tht = uni(res[MS2_TH]);
                 bool okf = fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308 && tht <= theta_max;
                 if (okf) {
                     bool dominated = false;
@@ -489,29 +550,52 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     } else if (tht <= (1.0 - 1e-5) * theta || ft <= f - 1e-8 * theta) accepted = true;
                 }
                 if (accepted) break;
+                abort_sweep();                          // (the evaluator went on with the sweep of the rejected point)
+                if (dead) break;
                 alpha *= 0.5;
             }
             if (dead) break;
+            pending = accepted;
+            MS2_T1(5);
+#ifndef PDP_MS_TIMING
             if (iter_log && it < op.log_rows && lane == 0) {
                 double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
                 row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? alpha : 0.0; row[6] = gd; row[7] = theta;
             }
-            if (!accepted) { st |= PDP_MS_RESTORATION; break; }
+#endif
+            if (!accepted) { st |= PDP_MS_RESTORATION; break; }      // (every rejected trial's sweep has been aborted above)
             if (!ftype) {                               // (at most one entry per iteration: the workspace holds max_iter + 1)
                 if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
                 ++nfilt;
                 __threadfence_block();
             }
-            read_res();                                 // the accepted trial's residuals are the new iterate's
-            cur ^= 1;
-            issue(MS2_CMD_UPDATE, alpha, cur, cur);     // (x, u, lambda) += alpha (dx, du, dlam)
-            wait_done();
+            read_res();                                 // the accepted trial's residuals are the new iterate's ...
+            cur ^= 1;                                   // ... and the trial pass left the point itself in the other set
+            MS2_T1(6);
+#ifdef PDP_MS_TIMING
+            if (iter_log && it < op.log_rows && lane == 0) {
+                // first-chunk wait | Riccati steps | later chunk waits | forward steps | dlam tail | line search | update; total of the iteration
+                double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
+                const long long now_ = __builtin_readcyclecounter();
+                for (int k_ = 0; k_ < 7; ++k_) { row[k_] = (double)tm[k_]; tm[k_] = 0; }
+                row[7] = (double)(now_ - tmi);
+                tmi = now_;
+                if (it + op.log_rows / 2 < op.log_rows) { double* r2 = row + (int64_t)(op.log_rows / 2) * 8; for (int k_ = 0; k_ < 8; ++k_) r2[k_] = res[12 + k_]; }
+            }
+#endif
             gains_ok = false;
             dw = 0.0;
             ++it;
         }
         issue(MS2_CMD_EXIT, 0.0, cur, cur);
         if (dead) st |= PDP_MS_INTERNAL;
+        {                                               // the iterate, stage-minor in the workspace, into the API arrays
+            __threadfence_block();
+            const double* sc = Pt(cur);
+            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; xb[q] = sc[i * TS + t]; }
+            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; ub[q] = sc[OU + i * TS + t]; }
+            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; lb[q] = sc[OL + i * TS + t]; }
+        }
         if (lane == 0) {
             if (cost) cost[b] = f_cur;
             if (resid) { resid[2 * b] = inf_pr; resid[2 * b + 1] = inf_du; }
@@ -535,65 +619,97 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         __builtin_amdgcn_s_setprio(0);
         bool dead = false;
         int last = 0;
+#ifdef PDP_MS_TIMING      // cumulative cycles of the evaluator: trial passes | updates | backward chunk evaluations | forward chunk evaluations | dlam | terminal | waits inside a sweep | number of trial passes
+        long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et0 = 0;
+#define MS2_E0() et0 = __builtin_readcyclecounter()
+#define MS2_E1(k) do { const long long now_ = __builtin_readcyclecounter(); et[k] += now_ - et0; et0 = now_; } while (0)
+#else
+#define MS2_E0()
+#define MS2_E1(k)
+#endif
         double a_f, a_th, a_pr, a_du, a_z, a_l, a_lc;
         bool fin_all;
         // Residuals of the point (x, u, lambda) + a (dx, du, dlam), lane = stage: defects, Lagrangian gradients (into residual set `dst`), objective,
         // constraint violation, the convergence measures.  a = 0: the current point (dx, du, dlam are not read into the result).
-        auto trial = [&](double a, double* rd) {
+        auto trial = [&](double a, int cur, int dst) {
             PDP_MS2_PAR();
-            const bool stepped = a != 0.0;
-            double* rc = rd;                                 // c [T][NX]
-            double* rx = rd + (int64_t)T * NX;               // grad_x L [T+1][NX]  (row 0: x_0 is fixed)
-            double* ru = rx + (int64_t)(T + 1) * NX;         // grad_u L [T][NU]
+            const bool stepped = a != 0.0, put = dst != cur;
+            const double* __restrict__ ps = Pt(cur);
+            // lane = NODE t = 0 .. T (T + 1 of them): node t < T evaluates stage t at its own (x_t, u_t, lambda_{t+1}); what couples neighbouring stages - the
+            // defect c_{t-1} = f(x_{t-1}, u_{t-1}) - x_t and the stationarity row grad_x L_t = H_x(t) - lambda_t - is formed by node t from ITS x_t and
+            // the previous node's f and lambda, handed up one lane (node 0 of a later pass: from lane 63 of the pass before, through scalar
+            // registers); node T does the terminal terms.  No lane reads another stage's rows: 2 (2 NX + NU) coalesced loads per pass, and every
+            // store is a range-checked buffer store (inactive lanes: out-of-range offset), so the pass has no conditional block around memory operations.
+            const auto rsPd = __builtin_amdgcn_make_buffer_rsrc((void*)Pt(dst), 0, (int)(GRP * 8), 0x00020000);
+            const auto rsRd = __builtin_amdgcn_make_buffer_rsrc((void*)Rs(dst), 0, (int)(GRP * 8), 0x00020000);      // grad_x L (T + 1 nodes; node 0: x_0 is fixed) | grad_u L | c
+            auto bst = [](auto rs, unsigned soff, unsigned voff, double v_) {
+                pdp_u2 w;
+                w.x = (unsigned)__double2loint(v_); w.y = (unsigned)__double2hiint(v_);
+                __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
+            };
             a_f = 0.0; a_th = 0.0; a_pr = 0.0; a_du = 0.0; a_z = 0.0; a_l = 0.0; a_lc = 0.0;
             bool fin = true;
-            for (int t = lane; t < T; t += 64) {
-                double xc[NX], uc[NU], lc[NX], xn[NX], v[NX];
+            double vprev[NX], lprev[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { vprev[i] = 0.0; lprev[i] = 0.0; }
+            for (int base = 0; base <= T; base += 64) {
+                const int t = base + lane;
+                const bool node = t <= T, stage = t < T, last = t == T;
+                const unsigned o8 = 8u * (unsigned)(node ? t : T);      // (lanes behind the horizon read node T's slots and store nothing)
+                const unsigned on = node ? o8 : MS2_OOB, os = stage ? o8 : MS2_OOB, oc = (node && t > 0) ? o8 - 8u : MS2_OOB;
+                double xc[NX], uc[NU], lc[NX], v[NX];
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    const double xa = xb[t * NX + i], xd = dxb[t * NX + i], xna = xb[(t + 1) * NX + i], xnd = dxb[(t + 1) * NX + i];
-                    const double la = lb[t * NX + i], ld = dlb[t * NX + i];
+                    const double xa = sm_ld(ps + i * TS, o8), xd = sm_ld(stp + i * TS, o8), la = sm_ld(ps + OL + i * TS, o8), ld = sm_ld(stp + OL + i * TS, o8);
                     xc[i] = stepped ? fma(a, xd, xa) : xa;
-                    xn[i] = stepped ? fma(a, xnd, xna) : xna;
-                    lc[i] = stepped ? fma(a, ld, la) : la;
-                    a_z = fmax(a_z, fabs(xc[i])); a_l = fmax(a_l, fabs(lc[i]));
+                    lc[i] = stepped ? fma(a, ld, la) : la;                 // (slot T of the lambda / u rows exists and is unused: node T reads it and drops it)
                 }
 #pragma unroll
-                for (int i = 0; i < NU; ++i) { const double ua = ub[t * NU + i], ud = dub[t * NU + i]; uc[i] = stepped ? fma(a, ud, ua) : ua; a_z = fmax(a_z, fabs(uc[i])); }
-                Mdl::dyn(xc, uc, th, pc, v);
+                for (int i = 0; i < NU; ++i) { const double ua = sm_ld(ps + OU + i * TS, o8), ud = sm_ld(stp + OU + i * TS, o8); uc[i] = stepped ? fma(a, ud, ua) : ua; }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    const double ci = v[i] - xn[i];
-                    rc[t * NX + i] = ci;
-                    a_th += fabs(ci); a_pr = fmax(a_pr, fabs(ci)); a_lc += lc[i] * ci;
-                    fin = fin && fabs(ci) <= 1.7e308;
+                    a_z = fmax(a_z, node ? fabs(xc[i]) : 0.0); a_l = fmax(a_l, stage ? fabs(lc[i]) : 0.0);
+                    if (put) { bst(rsPd, (unsigned)(i * TS) * 8u, on, xc[i]); bst(rsPd, (unsigned)(OL + i * TS) * 8u, os, lc[i]); }
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { a_z = fmax(a_z, stage ? fabs(uc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OU + i * TS) * 8u, os, uc[i]); }
+                Mdl::dyn(xc, uc, th, pc, v);
+                double nl[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    // the previous node's f(x, u) and lambda
+                    double nv = __shfl_up(v[i], 1, 64);
+                    nl[i] = __shfl_up(lc[i], 1, 64);
+                    if (lane == 0) { nv = vprev[i]; nl[i] = lprev[i]; }
+                    vprev[i] = readlane_f64(v[i], 63); lprev[i] = readlane_f64(lc[i], 63);
+                    const double ci = nv - xc[i];                        // defect of stage t - 1
+                    bst(rsRd, (unsigned)(OL + i * TS) * 8u, oc, ci);
+                    const bool has = node && t > 0;
+                    a_th += has ? fabs(ci) : 0.0; a_pr = fmax(a_pr, has ? fabs(ci) : 0.0); a_lc += has ? nl[i] * ci : 0.0;
+                    fin = fin && (!has || fabs(ci) <= 1.7e308);
                 }
                 Mdl::costate_step(xc, uc, lc, th, pc, v);
+                double hT[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) hT[i] = 0.0;
+                double fT = 0.0;
+                if (last) {                                              // terminal node: h_x(x_T), h(x_T)   (arithmetic only inside the branch)
+                    Mdl::dhx(xc, th, pc, hT);
+                    fT = Mdl::final_cost(xc, th, pc);
+                }
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    double g = 0.0;                          // x_0 is fixed: no stationarity row
-                    if (t > 0) { const double pa = lb[(t - 1) * NX + i], pd = dlb[(t - 1) * NX + i]; g = v[i] - (stepped ? fma(a, pd, pa) : pa); }
-                    rx[t * NX + i] = g;
-                    a_du = fmax(a_du, fabs(g));
-                    fin = fin && fabs(g) <= 1.7e308;
+                    const double g = last ? hT[i] - nl[i] : ((stage && t > 0) ? v[i] - nl[i] : 0.0);      // grad_x L of node t (x_0 is fixed: no row)
+                    bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
+                    a_du = fmax(a_du, node ? fabs(g) : 0.0);
+                    fin = fin && (!node || fabs(g) <= 1.7e308);
                 }
                 double hu[NU];
                 Mdl::dHu(xc, uc, lc, th, pc, hu);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) { ru[t * NU + i] = hu[i]; a_du = fmax(a_du, fabs(hu[i])); fin = fin && fabs(hu[i]) <= 1.7e308; }
-                a_f += Mdl::path_cost(xc, uc, th, pc);
-                if (t == T - 1) {
-                    double hx[NX];
-                    Mdl::dhx(xn, th, pc, hx);
-                    a_f += Mdl::final_cost(xn, th, pc);
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        const double g = hx[i] - lc[i];
-                        rx[T * NX + i] = g;
-                        a_du = fmax(a_du, fabs(g)); a_z = fmax(a_z, fabs(xn[i]));
-                        fin = fin && fabs(g) <= 1.7e308;
-                    }
-                }
+                for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OU + i * TS) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
+                const double pcst = Mdl::path_cost(xc, uc, th, pc);
+                a_f += stage ? pcst : (last ? fT : 0.0);
             }
             a_f = wave_sum(a_f); a_th = wave_sum(a_th); a_lc = wave_sum(a_lc);
             a_pr = wave_max(a_pr); a_du = wave_max(a_du); a_z = wave_max(a_z); a_l = wave_max(a_l);
@@ -607,37 +723,68 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         auto dlam_chunk = [&](int t0, int cnt) {
             if (lane < cnt) {
                 const int t = t0 + lane;
+                const unsigned o8 = 8u * (unsigned)t;
                 const double* pp = pw + (int64_t)t * PWSZ;
                 double d[NX], acc[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { d[i] = dxb[(t + 1) * NX + i]; acc[i] = pp[PSZ + i]; }
+                for (int i = 0; i < NX; ++i) { d[i] = sm_ld(stp + i * TS, o8 + 8u); acc[i] = pp[PSZ + i]; }
+                if constexpr (SMALL) {
+                    double pv[NX * NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j)
+                    for (int k = 0; k < NX * NX; ++k) pv[k] = pp[k];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) acc[i] = fma(pp[L::pk(i, j)], d[j], acc[i]);
+                    for (int j = 0; j < NX; ++j)
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dlb[t * NX + i] = acc[i];
+                        for (int i = 0; i < NX; ++i) acc[i] = fma(pv[i * NX + j], d[j], acc[i]);
+                } else {
+                    // the upper triangle row by row, in batches of rows whose loads are all requested before the first FMA that needs one (interleaved,
+                    // the pass makes a trip to memory per handful of FMAs); element (j, k), k >= j, serves acc[j] and, off the diagonal, acc[k]
+                    constexpr int RB_ = 4;
+#pragma unroll
+                    for (int j0 = 0; j0 < NX; j0 += RB_) {
+                        double pv[RB_][NX];
+#pragma unroll
+                        for (int jj = 0; jj < RB_; ++jj)
+#pragma unroll
+                            for (int k = 0; k < NX; ++k) pv[jj][k] = (j0 + jj < NX && k >= j0 + jj) ? pp[L::pk(j0 + jj < NX ? j0 + jj : 0, k)] : 0.0;
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int jj = 0; jj < RB_; ++jj)
+#pragma unroll
+                            for (int k = 0; k < NX; ++k)
+                                if (j0 + jj < NX && k >= j0 + jj) {
+                                    const int j = j0 + jj;
+                                    acc[j] = fma(pv[jj][k], d[k], acc[j]);
+                                    if (k != j) acc[k] = fma(pv[jj][k], d[j], acc[k]);
+                                }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) sm_st(stp + OL + i * TS, o8, acc[i]);
             }
         };
         for (;;) {
             if (!ms2_wait_ge(ctl + MS2_SEQ, last + 1, ctl)) break;
             last = ms2_load(ctl + MS2_SEQ);
             wave_lds_sync();
-            const int type = ctl[MS2_TYPE], cur = ctl[MS2_CUR], dst = ctl[MS2_DST];
-            const double alpha = res[MS2_ALPHA];
+            const int type = uni(ctl[MS2_TYPE]), cur = uni(ctl[MS2_CUR]), dst = uni(ctl[MS2_DST]);
+            const double alpha = uni(res[MS2_ALPHA]);
             if (type == MS2_CMD_EXIT) break;
-            if (type == MS2_CMD_TRIAL) {
-                trial(alpha, rs0 + (int64_t)dst * RES);
+            MS2_E0();
+            if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP) {
+                trial(alpha, cur, dst);
                 __threadfence_block();
-            } else if (type == MS2_CMD_UPDATE) {
-                for (int q = lane; q < T * NX; q += 64) { xb[NX + q] = fma(alpha, dxb[NX + q], xb[NX + q]); lb[q] = fma(alpha, dlb[q], lb[q]); }
-                for (int q = lane; q < T * NU; q += 64) ub[q] = fma(alpha, dub[q], ub[q]);
-                __threadfence_block();
-            } else {        // MS2_CMD_SWEEP
-                const double* rd = rs0 + (int64_t)cur * RES;
-                const double* rc = rd;
-                const double* rx = rd + (int64_t)T * NX;
-                const double* ru = rx + (int64_t)(T + 1) * NX;
+                MS2_E1(0);
+#ifdef PDP_MS_TIMING
+                et[7] += 1;
+                if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) res[12 + k_] = (double)et[k_];
+#endif
+                f3_signal(ctl + MS2_TDONE, last);
+            }
+            if (type == MS2_CMD_SWEEP || type == MS2_CMD_TRIAL_SWEEP) {
+                const int sw = type == MS2_CMD_SWEEP ? cur : dst;          // the set the sweep linearises at
+                const double* __restrict__ ps = Pt(sw);
+                const double* __restrict__ rd = Rs(sw);
                 bool aborted = false;
                 auto stop = [&]() { aborted = aborted || ms2_load(ctl + MS2_ABORT) == last; return aborted || dead; };
                 // terminal stage: hxx(x_T) entries and the terminal gradient
@@ -647,10 +794,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     PDP_MS2_PAR();
                     double xT[NX];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { xT[i] = xb[T * NX + i]; dlT[i] = rx[T * NX + i]; }
+                    for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
                     PackedSink s{fin + L::NCFIN};
                     Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
                 }
+                MS2_E1(5);
                 // backward chunks: lane = stage evaluates F, G, Hxx, Hxu, Huu at (x_t, u_t, lambda_{t+1}); defect and Lagrangian gradients come from the residual set
                 for (int g = 0; g < nchunk && !stop(); ++g) {
                     int t0, cnt;
@@ -661,15 +809,24 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!freed) break;
                     }
+                    MS2_E1(6);
                     if (lane < cnt) {
                         PDP_MS2_PAR();
                         const int t = t0 + lane;
+                        const unsigned o8 = 8u * (unsigned)t;
                         double xc[NX], uc[NU], lc[NX];
                         double* row = pool + (g & 1) * L::BUF + lane * BS;
+                        // (every load of the stage first, then the LDS stores: interleaved, each store waits for its loads - a trip to memory per component)
+                        double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; lc[i] = lb[t * NX + i]; row[L::C0 + i] = rc[t * NX + i]; row[L::RX + i] = rx[t * NX + i]; }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); lc[i] = sm_ld(ps + OL + i * TS, o8); cc[i] = sm_ld(rd + OL + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8); }
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; row[L::RU + i] = ru[t * NU + i]; }
+                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { row[L::C0 + i] = cc[i]; row[L::RX + i] = gx[i]; }
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) row[L::RU + i] = gu[i];
                         PackedSink s{row};
                         Mdl::eval_sol(xc, uc, lc, th, pc, s);
                         row[L::CB0] = 0.0;
@@ -677,6 +834,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         for (int i = 0; i < Mdl::SOL_NCONST; ++i) row[L::CB0 + 1 + i] = Mdl::sol_const(i);
                     }
                     f3_signal(ctl + MS2_PROD, g + 1);
+                    MS2_E1(2);
                 }
                 // forward chunks: F', G', the defect and the gradients the directional derivative needs; behind each consumed chunk the multiplier step
                 for (int c = 0; c < nchunkF && !stop(); ++c) {
@@ -687,15 +845,23 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!freed) break;
                     }
+                    MS2_E1(6);
                     if (lane < cnt) {
                         PDP_MS2_PAR();
                         const int t = t0 + lane;
+                        const unsigned o8 = 8u * (unsigned)t;
                         double xc[NX], uc[NU];
                         double* row = pool + (g & 1) * L::BUF + lane * FS;
+                        double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = xb[t * NX + i]; row[L::FC0 + i] = rc[t * NX + i]; row[L::FRX + i] = rx[(t + 1) * NX + i]; }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); cc[i] = sm_ld(rd + OL + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8 + 8u); }
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) { uc[i] = ub[t * NU + i]; row[L::FRU + i] = ru[t * NU + i]; }
+                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) { row[L::FC0 + i] = cc[i]; row[L::FRX + i] = gx[i]; }
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) row[L::FRU + i] = gu[i];
                         PackedSink s{row};
                         Mdl::eval_solf(xc, uc, nullptr, th, pc, s);
                         row[L::CF0] = 0.0;
@@ -703,27 +869,39 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         for (int i = 0; i < Mdl::SOLF_NCONST; ++i) row[L::CF0 + 1 + i] = Mdl::solf_const(i);
                     }
                     f3_signal(ctl + MS2_PROD, g + 1);
+                    MS2_E1(3);
                     if (c >= 1) {       // the runner has left chunk c - 1 (it could not start chunk c before the signal above): its dx are in memory
                         bool got = false;
                         int n = 0;
                         while (!(got = ms2_load(ctl + MS2_CONS) >= g) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!got) break;
+                        MS2_E1(6);
                         dlam_chunk((c - 1) * chF, min(chF, T - (c - 1) * chF));
+                        MS2_E1(4);
                     }
                 }
                 if (!stop()) {
                     bool got = false;
                     int n = 0;
                     while (!(got = ms2_load(ctl + MS2_CONS) >= nchunk + nchunkF) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
+                    MS2_E1(6);
                     if (got) dlam_chunk((nchunkF - 1) * chF, min(chF, T - (nchunkF - 1) * chF));
                 }
                 __threadfence_block();
+                MS2_E1(4);
             }
             if (dead) break;
+#ifdef PDP_MS_TIMING
+            if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) res[12 + k_] = (double)et[k_];
+#endif
             f3_signal(ctl + MS2_DONE, last);
         }
     }
 #undef PDP_MS2_PAR
+#undef MS2_T0
+#undef MS2_T1
+#undef MS2_E0
+#undef MS2_E1
 }
 
 template <class Mdl>

@@ -45,19 +45,37 @@ def make_problem(system, mode):
     return codegen.Problem(codegen.KIND_CP, env.X, env.U, dyn, None, env.path_cost, env.final_cost, label=system)
 
 
+FENCED = ("quadrotor_oc_", "rocket_oc_")
+_registered = False
+
+
+def register_tuned():
+    """Enter the exact generated names of the zoo models into codegen.TUNED_NAMES (see there)."""
+    global _registered
+    if not _registered:
+        for key in SPECS:
+            codegen.TUNED_NAMES.add(codegen.generate(make_problem(*key))[1]["name"])
+        _registered = True
+
+
 def build_all(force=False, prune=True):
     """generate + compile every zoo model in-tree; `prune` removes generated headers / libraries of zoo systems left over from
     older versions of the generator (their content hash no longer matches), so the tree only carries the current set."""
     import glob
     import os
+    register_tuned()
     problems = [make_problem(s, m) for (s, m) in SPECS]
     res = codegen.build_many(problems, force=force)
+    # plain -O3 twins of the headline models (C3 quadrotor, C4 rocket OC units): what tests/test_gpu_flag_fence.py compares the tuned builds with
+    twins = [codegen.compile_model(info["name"], force=force, plain_twin=True) for _, info in res
+             if info["name"].startswith(FENCED) and codegen.tuned(info["name"])]
     if prune:
         keep = set(info["name"] for _, info in res)
         systems = set(s for s, _ in SPECS)
         for path in glob.glob(os.path.join(codegen.GEN_DIR, "*.h")) + glob.glob(os.path.join(codegen.LIB_DIR, "libpdp_model_*.so")):
             name = os.path.basename(path)
             name = name[len("libpdp_model_"):-3] if name.endswith(".so") else name[:-2]
+            name = name[:-len("__plain")] if name.endswith("__plain") else name
             if name not in keep and name.split("_")[0] in systems and name.rsplit("_", 2)[-2] in ("oc", "cp", "sysid"):
                 os.remove(path)
                 if os.path.exists(path + ".stamp"):
@@ -73,6 +91,7 @@ def get(system, mode):
     from . import runtime
     key = (system, mode)
     if key not in _cache:
+        register_tuned()
         lib, info = codegen.build_problem(make_problem(system, mode))
         _cache[key] = runtime.load_model(lib)
     return _cache[key]

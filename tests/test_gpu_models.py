@@ -255,15 +255,3 @@ def test_sysid_matches_reference_run_and_oracle(golden_dir, name):
     F, E = mdl.sysid_auxsys(x, io["inputs"], g["theta"])
     aux = sid.getAuxSys(npy(x)[0], io["inputs"][0], g["theta"])
     assert rel(npy(F)[0], np.stack(aux["dynF"])) < 1e-11 and rel(npy(E)[0], np.stack(aux["dynE"])) < 1e-11
-
-
-def test_two_wave_variant_of_the_fused_kernel_stays_parity_green():
-    """oc_pdp_fused2_kernel (two wavefronts per trajectory, PDP_FUSED_VARIANT=2; an experiment that is slower than the shipped kernel,
-    DESIGN.md section 4.2) must keep producing the shipped kernel's results: the quadrotor / rocket fused-unit tests of this file rerun
-    in a process with the variant selected."""
-    import subprocess, sys
-    env = dict(os.environ, PDP_FUSED_VARIANT="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "(fused_pdp_unit_matches_oracle or fused_pdp_given_optimal) and (quadrotor or rocket)"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:]
