@@ -1,0 +1,258 @@
+// pdp_cp_mlp_kernels.h - fused ControlPlanning.step for the tanh-MLP policy (reference PDP/PDP.py:727-759 setNeuralPolicy, 763-786 integrateSys,
+// 850-878 step) with the network held in REGISTERS: cp_step_mlp16_kernel.  Same adjoint formulation, same arithmetic in the same order as
+// cp_step_adjoint_kernel (pdp_model_kernels.h) - loss and trajectory bit-identical, gradient equal to 1e-16 (tests/test_gpu_cp_mlp.py) - for networks of at most 4 weight layers of
+// width <= 16 (the reference's examples: hidden [n] or [n, n], PDP.py:730 / cartpole_PDP_neural.py:49; C5: [13, 13] -> 4, p = 420).
+//
+// Why.  At C5b (quadrotor, T = 100, p = 420, B = 1024) the general kernel spent ~18 k cycles per time step and trajectory: every layer product was a
+// loop of run-time length whose trip fetched one weight and one activation from LDS (~100 cycles per trip, 13 trips, 6 products per step), the
+// backward sweep re-ran the whole network on ONE lane per time step (26 fp64 tanh in sequence) only to recover u_t, and the parameters took 3.4 KB of
+// LDS per trajectory.  Here:
+//   * lane 16 k + r holds ROW r of A_k (forward product) and COLUMN r of A_k (transposed product of the adjoint sweep), zero-padded to 16: 33 doubles
+//     per lane for up to four layers, loaded once from theta (column-major vec, PDP.py:739);
+//   * a layer product is 16 FMAs on those registers with the input element broadcast from the lane that owns it (v_readlane -> scalar operand): the
+//     trip count is a compile-time 16, there is no LDS access in it; the wave computes layer k for all four lane groups at once, only group k's
+//     result is kept (the layers are sequential anyway);
+//   * activations stay in the lane that computed them: stored to / re-read from the workspace by that same lane (one 8-byte access per lane and
+//     step, requested one step ahead in the adjoint sweep); u_t is kept in LDS by the rollout, so the backward chunk evaluation is just the generated
+//     Jacobian code;
+//   * tanh is evaluated once per layer and step (one call for all lanes), never in the adjoint sweep (1 - z^2 from the stored z).
+// Measured (profiles/r03_cp_mlp_kernel.txt): C5b, B = 1024: 0.844 -> 0.281 ms (17.7 k -> 5.9 k cycles per time step), 3.6 - 4.0 M trajectories/s from B = 1024 up.
+// One wavefront per trajectory as before (the batch of C5 is 1024 per GPU = one trajectory per SIMD).  A batched-over-trajectories MFMA form (16
+// trajectories' activations as the columns of one 16x16x16 product) would cut the instruction count per trajectory further, but only pays for batches
+// well beyond 16 x 1024 trajectories per GPU, which no BASELINE configuration has; see DESIGN.md section 4.3.
+#pragma once
+#include "pdp_model_kernels.h"
+
+namespace pdp {
+
+constexpr int MLP16_W = 16, MLP16_MAXL = 4;
+
+struct Mlp16Layout { int xs, us, zs, ds, misc, blk, total, actw; };
+template <class Mdl>
+__host__ __device__ inline Mlp16Layout cp_mlp16_layout(int T, int rows) {
+    Mlp16Layout L;
+    int o = 0;
+    L.xs = o; o += (T + 1) * Mdl::NX;
+    L.us = o; o += T * Mdl::NU;
+    L.zs = o; o += MLP16_MAXL * MLP16_W + 2;              // layer inputs of the current step | 1.0 (bias factor) | 0.0
+    L.ds = o; o += MLP16_MAXL * MLP16_W;                  // layer deltas of the current step
+    L.misc = o; o += Mdl::NX + Mdl::NU + 2;               // (d pi/dx)' v | spare
+    L.blk = o; o += 1 + Mdl::PATH_NCONST + rows * (Mdl::PATH_NVAR | 1);
+    L.total = o + 8;
+    L.actw = 64;                                           // workspace doubles per time step: one per lane
+    return L;
+}
+template <class Mdl>
+__host__ inline bool cp_mlp16_ok(const pdp_policy& pol) {
+    if (pol.kind != PDP_POLICY_MLP || pol.n_layers < 1 || pol.n_layers > MLP16_MAXL || Mdl::NX > MLP16_W || Mdl::NU > MLP16_W) return false;
+    for (int k = 0; k < pol.n_layers; ++k) if (pol.sizes[k] < 1 || pol.sizes[k] > MLP16_W) return false;
+    return true;
+}
+// pool rows per evaluation pass: as many as fit beside the trajectory in 40 KB (four wavefronts, one per SIMD, share a CU's 160 KB)
+template <class Mdl>
+__host__ inline int cp_mlp16_rows(int T) {
+    const int stride = Mdl::PATH_NVAR | 1;
+    const int fixed = cp_mlp16_layout<Mdl>(T, 0).total;
+    int fit = (40 * 1024 / 8 - fixed) / stride;
+    if (fit < 8) fit = (160 * 1024 / 8 - fixed) / stride;     // long horizons: one workgroup per CU
+    return fit < 1 ? 0 : (fit > 64 ? 64 : fit);
+}
+
+template <class Mdl>
+__global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta,
+                                                            int tb, double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ xo,
+                                                            double* __restrict__ uo, double* __restrict__ ws_acts, int CH) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, W = MLP16_W;
+    constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Mlp16Layout L = cp_mlp16_layout<Mdl>(T, CH);
+    double *xs = lds + L.xs, *us = lds + L.us, *zs = lds + L.zs, *ds = lds + L.ds, *dpx = lds + L.misc, *blk = lds + L.blk, *pool = blk + NC;
+    const int b = blockIdx.x, lane = threadIdx.x, grp = lane >> 4, idx = lane & 15;
+    double* actg = ws_acts + (int64_t)b * T * 64;            // [T][64]: element (t, lane) written and re-read by the same lane
+    const int nl = pol.n_layers;
+    const double* thb = theta + (int64_t)b * tb;
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
+    // layer tables (uniform): parameter offset, rows, cols
+    int loff[MLP16_MAXL], lrows[MLP16_MAXL], lcols[MLP16_MAXL];
+    {
+        int cols = NX, off = 0;
+#pragma unroll
+        for (int k = 0; k < MLP16_MAXL; ++k) {
+            loff[k] = off; lcols[k] = cols; lrows[k] = (k < nl) ? pol.sizes[k] : 0;
+            if (k < nl) { off += lrows[k] * cols + lrows[k]; cols = lrows[k]; }
+        }
+    }
+    // this lane's layer (its group), and its row / column of that layer's weights: A_k is stored column-major, vec_F(A_k)[r + c rows]   (PDP.py:739)
+    int my_off = 0, my_rows = 0, my_cols = 0;
+#pragma unroll
+    for (int k = 0; k < MLP16_MAXL; ++k) if (grp == k) { my_off = loff[k]; my_rows = lrows[k]; my_cols = lcols[k]; }
+    double Wrow[W], Wcol[W], bias;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        Wrow[c] = (idx < my_rows && c < my_cols) ? thb[my_off + idx + c * my_rows] : 0.0;          // A[idx][c]
+        Wcol[c] = (idx < my_cols && c < my_rows) ? thb[my_off + c + idx * my_rows] : 0.0;          // A[c][idx]
+    }
+    bias = idx < my_rows ? thb[my_off + my_rows * my_cols + idx] : 0.0;
+    if (lane == 0) { blk[0] = 0.0; zs[MLP16_MAXL * W] = 1.0; zs[MLP16_MAXL * W + 1] = 0.0; }
+    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
+    // per-lane parameter slots q = 0..7 (parameter index lane + 64 q): LDS offsets of the two factors of d cost / d theta_j (delta_k[r] * z_k[c], or 1.0)
+    int pr[8], pz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        pr[q] = L.zs + MLP16_MAXL * W + 1; pz[q] = L.zs + MLP16_MAXL * W + 1;       // 0.0 * 0.0
+        if (j < p) {
+#pragma unroll
+            for (int k = 0; k < MLP16_MAXL; ++k) {
+                if (k < nl && j >= loff[k] && j < loff[k] + lrows[k] * lcols[k] + lrows[k]) {
+                    const int e = j - loff[k], nw = lrows[k] * lcols[k];
+                    if (e < nw) { pr[q] = L.ds + k * W + e % lrows[k]; pz[q] = L.zs + k * W + e / lrows[k]; }
+                    else { pr[q] = L.ds + k * W + (e - nw); pz[q] = L.zs + MLP16_MAXL * W; }
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // ---------------- forward rollout: x_{t+1} = f(x_t, pi(x_t)), executed uniformly by the wave
+    double J = 0.0;
+    {
+        double xc[NX], xn[NX], uc[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = xc[i];
+        }
+        for (int t = 0; t < T; ++t) {
+            double zprev = 0.0, zkeep = 0.0;
+#pragma unroll
+            for (int k = 0; k < MLP16_MAXL; ++k) {
+                if (k < nl) {
+                    double a = bias;
+#pragma unroll
+                    for (int c = 0; c < W; ++c) {
+                        const double zc = (k == 0) ? (c < NX ? xc[c < NX ? c : 0] : 0.0) : readlane_f64(zprev, 16 * (k > 0 ? k - 1 : 0) + c);
+                        a = fma(Wrow[c], zc, a);               // a += A[r][c] z[c], c ascending (as policy_eval)
+                    }
+                    if (k + 1 < nl) {
+                        const double zk = tanh(a);
+                        zprev = zk;
+                        zkeep = grp == k ? zk : zkeep;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) uc[j] = readlane_f64(a, 16 * k + j);
+                    }
+                }
+            }
+            actg[t * 64 + lane] = zkeep;                        // this lane's hidden activation of step t (groups >= nl - 1: unused)
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) us[t * NU + j] = uc[j];
+            }
+            if (uo) {
+                double uv = 0.0;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) uv = lane == j ? uc[j] : uv;
+                if (lane < NU) uo[((int64_t)b * T + t) * NU + lane] = uv;
+            }
+            Mdl::dyn(xc, uc, nullptr, pc, xn);
+            J += Mdl::path_cost(xc, uc, nullptr, pc);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
+            }
+        }
+        J += Mdl::final_cost(xc, nullptr, pc);
+        wave_lds_sync();
+    }
+    if (xo) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
+
+    // ---------------- adjoint sweep: mu_T = h_x ; v_t = c_u + G_t' mu_{t+1} ; grad += (d pi/d theta)' v_t ; mu_t = c_x + F_t' mu_{t+1} + (d pi/d x)' v_t
+    double mu[NX];
+    {
+        double xT[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xT[i] = xs[T * NX + i];
+        Mdl::dhx(xT, nullptr, pc, mu);
+    }
+    double gacc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gacc[q] = 0.0;
+    // per-lane pool offsets: column idx of F (group 0, idx < NX), column idx of G (the output layer's group, idx < NU), c_x[idx], c_u[idx]
+    const bool lane_x = grp == 0 && idx < NX, lane_u = grp == nl - 1 && idx < NU;
+    int fo[NX], fm[NX], go[NX], gm[NX], cxo = 0, cxm = 0, cuo = 0, cum = 0;
+    auto enc = [&](int code, int& o, int& m) { if (code >= 0) { o = NC + code; m = STRIDE; } else { o = (code == -1) ? 0 : 1 + (-2 - code); m = 0; } };
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        enc(lane_x ? Mdl::path_code(0, k * NX + idx) : -1, fo[k], fm[k]);
+        enc(lane_u ? Mdl::path_code(1, k * NU + idx) : -1, go[k], gm[k]);
+    }
+    enc(lane_x ? Mdl::path_code(2, idx) : -1, cxo, cxm);
+    enc(lane_u ? Mdl::path_code(3, idx) : -1, cuo, cum);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rollout's activation stores have landed (re-read by the same lanes below)
+    double znext = actg[(T - 1) * 64 + lane];
+    const int nchunk = (T + CH - 1) / CH;
+    const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int t0 = c * ch, cnt = min(ch, T - t0);
+        wave_lds_sync();
+        if (lane < cnt) {                           // lane = time step: F, G, c_x, c_u at (x_t, u_t) of the stored trajectory
+            const int t = t0 + lane;
+            double xc[NX], uc[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xs[t * NX + i];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uc[j] = us[t * NU + j];
+            PackedSink sk{pool + lane * STRIDE};
+            Mdl::eval_path(xc, uc, nullptr, nullptr, pc, sk);
+        }
+        wave_lds_sync();
+        for (int tl = cnt - 1; tl >= 0; --tl) {
+            const int t = t0 + tl;
+            const double zk_own = znext;                          // this lane's activation of step t
+            if (t > 0) znext = actg[(t - 1) * 64 + lane];          // ... and of the step the sweep visits next, requested now
+            // layer inputs of the step into LDS (factors of the parameter gradient): z_0 = x_t, z_{k+1} = the activations of group k
+            if (lane < NX) zs[lane] = xs[t * NX + lane];
+            if (grp + 1 < nl) zs[(grp + 1) * W + idx] = zk_own;
+            // v = c_u + G' mu   (lanes of the output layer's group)
+            double delta = blk[cuo + tl * cum];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) delta = fma(blk[go[k] + tl * gm[k]], mu[k], delta);
+            double dkeep = 0.0, back0 = 0.0;
+#pragma unroll
+            for (int k = MLP16_MAXL - 1; k >= 0; --k) {
+                if (k < nl) {
+                    dkeep = grp == k ? delta : dkeep;             // delta_k lives in group k
+                    double back = 0.0;                            // (A_k' delta_k)[idx] on group k's lanes, r ascending (as the general kernel)
+#pragma unroll
+                    for (int r = 0; r < W; ++r) back = fma(Wcol[r], readlane_f64(delta, 16 * k + r), back);
+                    if (k > 0) {
+                        const double moved = __shfl_down(back, 16, 64);      // to the lane of group k - 1 that owns z_k[idx]
+                        delta = moved * (1.0 - zk_own * zk_own);
+                    } else back0 = back;
+                }
+            }
+            ds[grp * W + idx] = dkeep;
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gacc[q] += lds[pr[q]] * lds[pz[q]];
+            // mu_t = c_x + F' mu_{t+1} + (d pi/dx)' v   (lanes idx < NX of group 0), then broadcast
+            double m_new = blk[cxo + tl * cxm] + back0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) m_new = fma(blk[fo[k] + tl * fm[k]], mu[k], m_new);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) mu[i] = readlane_f64(m_new, i);
+            wave_lds_sync();                                      // (zs / ds are rewritten by the next step)
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int j = lane + 64 * q; if (j < p) grad[(int64_t)b * p + j] = gacc[q]; }
+    if (lane == 0) loss[b] = J;
+    (void)dpx;
+}
+
+}  // namespace pdp

@@ -16,6 +16,7 @@ namespace pdp { extern __device__ long long g_rb_stamp[16]; }
 #include "pdp_lqr_kernels.h"
 #include "pdp_ocsolve_kernels.h"
 #include "pdp_ocsolve2_kernels.h"
+#include "pdp_cp_mlp_kernels.h"
 #include "pdp_fused3_kernels.h"
 #include <cstdlib>
 
@@ -298,16 +299,24 @@ int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const dou
     hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B, gy), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
     return launched();
 }
+// MLP kernel variants (environment PDP_CP_MLP_VARIANT overrides): 2 = network in registers (pdp_cp_mlp_kernels.h), the default for networks of at
+// most 4 layers of width <= 16; 1 = the general adjoint kernel (any policy up to 8 layers x 32 units)
+inline int cp_mlp_variant() { static const int v = [] { const char* e = std::getenv("PDP_CP_MLP_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
 template <class Mdl>
 int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
         if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;
+        int64_t need = 0;
+        if (cp_mlp16_ok<Mdl>(*pol)) need = (int64_t)B * T * 64 * (int64_t)sizeof(double);       // one double per lane and time step
         bool offload; int rows;
         cp_adjoint_plan<Mdl>(*pol, p, T, B, device_cu_count(), true, offload, rows);
-        if (!offload) return 0;
-        int actw = 0;
-        for (int k = 0; k + 1 < pol->n_layers; ++k) actw += pol->sizes[k];
-        return (int64_t)B * T * actw * (int64_t)sizeof(double);
+        if (offload) {
+            int actw = 0;
+            for (int k = 0; k + 1 < pol->n_layers; ++k) actw += pol->sizes[k];
+            const int64_t a = (int64_t)B * T * actw * (int64_t)sizeof(double);
+            need = a > need ? a : need;
+        }
+        return need;
     } else { return 0; }
 }
 template <class Mdl>
@@ -323,6 +332,16 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 for (int k = 0; k < pol->n_layers; ++k) { if (pol->sizes[k] > MLP_MAX_WIDTH || pol->sizes[k] < 1) return PDP_E_SIZE; cnt += pol->sizes[k] * cols + pol->sizes[k]; cols = pol->sizes[k]; }
                 if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
             } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
+            if (pol->kind == PDP_POLICY_MLP && cp_mlp_variant() == 2 && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
+                const int rows16 = cp_mlp16_rows<Mdl>(T);
+                const size_t lds16 = sizeof(double) * (size_t)cp_mlp16_layout<Mdl>(T, rows16).total;
+                if (rows16 >= 1 && lds16 <= 160 * 1024) {
+                    (void)hipFuncSetAttribute((const void*)cp_step_mlp16_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+                    PDP_CLEAR();
+                    hipLaunchKernelGGL((cp_step_mlp16_kernel<Mdl>), dim3(B), dim3(64), lds16, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, rows16);
+                    return launched();
+                }
+            }
             bool offload; int rows;
             cp_adjoint_plan<Mdl>(*pol, p, T, B, device_cu_count(), ws != nullptr && wsb >= cp_step_ws_bytes<Mdl>(B, T, pol, p), offload, rows);
             const size_t lds = sizeof(double) * (size_t)cp_adjoint_layout<Mdl>(*pol, p, T, offload, rows).total;
