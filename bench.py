@@ -164,11 +164,21 @@ def other_configs(torch):
     res = {}
     rng = np.random.default_rng(0)
 
-    def entry(name, B, ms, flop=None, byts=None, note=None, extra=None):
+    def entry(name, B, ms, flop=None, byts=None, note=None, extra=None, T=None, latency_bound=False, executed_flop=None):
+        """flop: SURVEY.md section 8d's figure for the unit (dense count of the reference formulation).  latency_bound: the kernel runs one serial chain
+        per trajectory far below any throughput roofline (a fraction of the MFMA peak of 0.2 - 5 % says nothing): it is reported as time per time step
+        of one wavefront's chain (ns_per_step: kernel time / T / rounds of one trajectory per SIMD) instead of a roofline fraction."""
         e = {"batch": B, "kernel_ms": ms, "traj_per_s": B / (ms * 1e-3)}
         if flop is not None:
             tf = flop * B / (ms * 1e-3) / 1e12
-            e.update(bound="mfma", algorithmic_flop_per_traj=flop, achieved_tflops=tf, frac=tf / FP64_MFMA_PEAK_TFLOPS)
+            e.update(algorithmic_flop_per_traj=flop, achieved_tflops=tf)
+            if not latency_bound:
+                e.update(bound="mfma", frac=tf / FP64_MFMA_PEAK_TFLOPS)
+        if executed_flop is not None:
+            e.update(executed_flop_per_traj=executed_flop, executed_tflops=executed_flop * B / (ms * 1e-3) / 1e12)
+        if latency_bound and T:
+            rounds = max(1, -(-B // 1024))
+            e.update(bound="latency (one serial chain per trajectory)", ns_per_step=ms * 1e6 / T / rounds, horizon=T)
         if byts is not None:
             gb = byts * B / (ms * 1e-3) / 1e9
             e.update(bound="hbm", algorithmic_bytes_per_traj=byts, achieved_gbps=gb, frac=gb / HBM_PEAK_GBPS)
@@ -200,7 +210,7 @@ def other_configs(torch):
         bufs = {}
         grad_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], buffers=bufs))
         it, itc = sol["iterations"].double(), demo["iterations"].double()
-        entry(key, B, solve_ms + grad_ms, flop=flop,
+        entry(key, B, solve_ms + grad_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
               note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); OC solve (pdp_oc_solve_ms_batched, warm start from the solution at theta*) + fused "
                    "aux/Riccati/gradient unit; the flop figure is section 8d's for the gradient unit (it has none for the solve)",
               extra={"oc_solve_ms": solve_ms, "gradient_ms": grad_ms, "oc_solve_converged": int(sol["converged"].sum()),
@@ -208,7 +218,7 @@ def other_configs(torch):
                      "oc_solve_cold_ms": cold_ms, "oc_solve_cold_converged": int(demo["converged"].sum()),
                      "oc_solve_cold_iterations_mean_max": [float(itc.mean()), float(itc.max())], "oc_solves_per_s_cold": B / (cold_ms * 1e-3)})
         if system == "cartpole":
-            entry("C2_cartpole_gradient_unit_B256", B, grad_ms, flop=flop, note="aux system + Riccati + gradient at a given optimum (quarter-filled GPU)")
+            entry("C2_cartpole_gradient_unit_B256", B, grad_ms, flop=flop, T=T, latency_bound=True, note="aux system + Riccati + gradient at a given optimum (quarter-filled GPU)")
     # ---- C4 shard: rocket T=100, B=512: fused OC unit (p=10) and ControlPlanning.step (Lagrange policy p=18)
     mdl = zoo.get("rocket", "irl")
     B, T = 512, 100
@@ -226,7 +236,7 @@ def other_configs(torch):
     mdl = zoo.get("rocket", "oc")
     p = 18
     thp, pol = rt.dev(0.5 * rng.standard_normal(p)), rt.make_policy("poly", pivots=np.linspace(0, T, 6))
-    entry("C4_rocket_cp_step_T100_p18_B512", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T)), flop=0.95e6, note="one GPU's shard of C4")
+    entry("C4_rocket_cp_step_T100_p18_B512", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T)), flop=0.95e6, T=T, latency_bound=True, note="one GPU's shard of C4")
     # ---- C3 U-CP
     mdl = zoo.get("quadrotor", "oc")
     B, T, p = 1024, 50, 24
@@ -234,7 +244,7 @@ def other_configs(torch):
     x0[:, :3] = rng.uniform(-5, 5, (B, 3))
     x0[:, 6] = 1
     x0d, thp, pol = rt.dev(x0), rt.dev(rng.standard_normal(p)), rt.make_policy("poly", pivots=np.linspace(0, T, 6))
-    entry("C3_quadrotor_cp_step_T50_p24_B1024", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T)), flop=0.70e6)
+    entry("C3_quadrotor_cp_step_T50_p24_B1024", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T)), flop=0.70e6, T=T, latency_bound=True)
     # ---- C5a: SysID.step, quadrotor T=100 p=5, B=1024 (one GPU's shard of 8192)
     mdl = zoo.get("quadrotor", "sysid")
     B, T = 1024, 100
@@ -242,7 +252,7 @@ def other_configs(torch):
     x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (B, 1))
     xobs = mdl.sysid_integrate(x0, u5, np.array([1, 1, 1, 1, .4]))
     th5 = rt.dev(np.array([1.1, .95, 1.08, 1.03, .38]))
-    entry("C5a_quadrotor_sysid_step_T100_p5_B1024", B, _event_ms(torch, lambda: mdl.sysid_step(u5, xobs, th5)), flop=0.18e6, note="one GPU's shard of C5")
+    entry("C5a_quadrotor_sysid_step_T100_p5_B1024", B, _event_ms(torch, lambda: mdl.sysid_step(u5, xobs, th5)), flop=0.18e6, T=T, latency_bound=True, note="one GPU's shard of C5")
     # ---- C5b: neural-policy ControlPlanning.step, hidden [13,13] (p = 420), T=100, B=1024
     mdl = zoo.get("quadrotor", "oc")
     B, T, p = 1024, 100, 420
@@ -250,8 +260,12 @@ def other_configs(torch):
     x0[:, :3] = rng.uniform(-2, 2, (B, 3))
     x0[:, 6] = 1
     x0d, thp, pol = rt.dev(x0), rt.dev(0.1 * rng.standard_normal(p)), rt.make_policy("mlp", layers=[13, 13, 4])
-    entry("C5b_quadrotor_mlp_step_T100_p420_B1024", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T), reps=5, warm=1), flop=24.4e6,
-          note="adjoint kernel: O(T (n^2 + p)) work instead of the O(T n^2 p) forward sensitivities the 24.4 MFLOP figure counts; one GPU's shard of C5")
+    # arithmetic the adjoint kernel executes per time step: network forward and transposed 2 x 2 (13*13 + 13*13 + 4*13), parameter gradient 2 * 420,
+    # G' mu and F' mu 2 (52 + 169), dynamics / cost / Jacobian code ~2 k  ->  ~4.8 kflop per step
+    entry("C5b_quadrotor_mlp_step_T100_p420_B1024", B, _event_ms(torch, lambda: mdl.cp_step(pol, p, x0d, thp, T), reps=5, warm=1), flop=24.4e6, T=T, latency_bound=True,
+          executed_flop=4.8e3 * T,
+          note="register-resident MLP adjoint kernel (cp_step_mlp16_kernel): O(T (n^2 + p)) work - executed_flop_per_traj - instead of the O(T n^2 p) forward "
+               "sensitivities that section 8d's 24.4 MFLOP figure counts and the kernel does not execute; one GPU's shard of C5")
     # ---- the reference's materialised API route on C3 sizes (HBM-bound by construction)
     mdl = zoo.get("quadrotor", "irl")
     B, T = 1024, 50
@@ -282,7 +296,7 @@ def scaling_configs(torch, dist, world, rank, steps):
     distributed = world > 1
     steps = max(3, min(steps, 20))
 
-    def run(name, B_total, p, make_unit, flop, note):
+    def run(name, B_total, p, make_unit, flop, note, T=None, latency_bound=False, executed_flop=None):
         lo, hi = parallel.shard_bounds(B_total, world, rank)
         b = hi - lo
         rng = np.random.default_rng(1234)                     # every rank draws the full batch and keeps its shard: shards do not depend on N
@@ -333,7 +347,14 @@ def scaling_configs(torch, dist, world, rank, steps):
                      "kernel_ms_per_rank": [float(v) for v in allr[:, 0]], "exchange_us_per_rank": [float(v) for v in allr[:, 1]] if distributed else None,
                      "exchange_bytes_per_rank": int(b * (p + 1) * 8) if distributed else 0,
                      "ms_per_step": step_ms, "traj_per_s": B_total / (step_ms * 1e-3),
-                     "algorithmic_flop_per_traj": flop, "achieved_tflops_all_gpus": tf, "frac_of_fp64_mfma_peak": tf / (FP64_MFMA_PEAK_TFLOPS * world), "note": note}
+                     "algorithmic_flop_per_traj": flop, "achieved_tflops_all_gpus": tf, "note": note}
+        if latency_bound:       # one serial chain per trajectory: time per time step of a wavefront's chain instead of a roofline fraction (see other_configs)
+            rounds = max(1, -(-int(allr[:, 3].max()) // 1024))
+            res[name].update(bound="latency (one serial chain per trajectory)", ns_per_step=float(allr[:, 0].max()) * 1e6 / T / rounds, horizon=T)
+        else:
+            res[name].update(bound="mfma", frac_of_fp64_mfma_peak=tf / (FP64_MFMA_PEAK_TFLOPS * world))
+        if executed_flop is not None:
+            res[name].update(executed_flop_per_traj=executed_flop, executed_tflops_all_gpus=executed_flop * B_total / (step_ms * 1e-3) / 1e12)
 
     # ---- C4: rocket powered landing, T = 100, 4096 trajectories in total: fused OC unit (p = 10) and ControlPlanning.step (Lagrange policy, p = 18)
     T4 = 100
@@ -369,7 +390,7 @@ def scaling_configs(torch, dist, world, rank, steps):
         return lambda packed: mdl.cp_step(pol, 18, x0d, thp, T4)
 
     run("C4_rocket_oc_unit_T100_p10_B4096", 4096, 10, c4_oc, 6.9e6, "BASELINE configs[3], U-OC: rollout + costates + aux system + Riccati + gradient")
-    run("C4_rocket_cp_step_T100_p18_B4096", 4096, 18, c4_cp, 0.95e6, "BASELINE configs[3], U-CP: ControlPlanning.step, Lagrange policy")
+    run("C4_rocket_cp_step_T100_p18_B4096", 4096, 18, c4_cp, 0.95e6, "BASELINE configs[3], U-CP: ControlPlanning.step, Lagrange policy", T=T4, latency_bound=True)
 
     # ---- C5: quadrotor, T = 100, 8192 trajectories in total: SysID.step (p = 5) and neural-policy ControlPlanning.step (hidden [13, 13], p = 420)
     T5 = 100
@@ -392,10 +413,11 @@ def scaling_configs(torch, dist, world, rank, steps):
         thp, pol = rt.dev(0.1 * rng.standard_normal(420)), rt.make_policy("mlp", layers=[13, 13, 4])
         return lambda packed: mdl.cp_step(pol, 420, x0d, thp, T5)
 
-    run("C5_quadrotor_sysid_step_T100_p5_B8192", 8192, 5, c5_sysid, 0.18e6, "BASELINE configs[4], U-ID: SysID.step")
+    run("C5_quadrotor_sysid_step_T100_p5_B8192", 8192, 5, c5_sysid, 0.18e6, "BASELINE configs[4], U-ID: SysID.step", T=T5, latency_bound=True)
     run("C5_quadrotor_mlp_step_T100_p420_B8192", 8192, 420, c5_mlp, 24.4e6,
         "BASELINE configs[4], U-CP with the tanh-MLP policy [13, 13] (adjoint kernel: the 24.4 MFLOP figure counts the reference's forward sensitivities, "
-        "which the kernel does not execute); the exchange is %d x 421 doubles per rank" % (8192 // world))
+        "which the kernel does not execute - executed_flop_per_traj is what it runs); the exchange is %d x 421 doubles per rank" % (8192 // world),
+        T=T5, latency_bound=True, executed_flop=4.8e3 * T5)
     return res if rank == 0 else None
 
 

@@ -477,6 +477,59 @@ class ControlPlanning:
         self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon - 1, horizon))
         self.setPolyControl(numpy.linspace(0, self.whorizon, self.whorizon + 1))
 
+    # ---- the symbolic internals of the warped / recovery-matrix variants, for callers that use them directly.  warp_step / recmat_step above do
+    # NOT go through them (they run one adjoint sweep on the GPU); these three build the reference's per-cell Function lists and its whole-horizon
+    # recovery matrix on this package's SX layer, evaluated on the host like the reference's CasADi Functions - one-time setup objects, sized for
+    # the grids the reference uses them on (about ten cells; recmat_init_step(horizon, -1) does not need them here).
+    def warp_dynCost(self, time_grid):                                          # PDP.py:882-915
+        assert hasattr(self, "dyn_fn"), "Please set the dynamics first!"
+        assert hasattr(self, "path_cost_fn"), "Please set the path cost first!"
+        assert hasattr(self, "final_cost_fn"), "Please set the final cost first!"
+        names = ("wdyn_fns", "wdfx_fns", "wdfu_fns", "wpath_cost_fns", "wdcx_fns", "wdcu_fns")
+        for nm in names:
+            setattr(self, nm, [])
+        args = [self.state, self.control]
+        for wt in range(len(time_grid) - 1):
+            xk, cell_cost = self.state, 0
+            for _ in range(int(time_grid[wt]), int(time_grid[wt + 1])):      # the cell's steps composed with ONE control
+                cell_cost = cell_cost + self.path_cost_fn(xk, self.control)
+                xk = self.dyn_fn(xk, self.control)
+            outs = (xk, jacobian(xk, self.state), jacobian(xk, self.control), cell_cost, jacobian(cell_cost, self.state), jacobian(cell_cost, self.control))
+            for nm, o in zip(names, outs):
+                getattr(self, nm).append(sx.Function("%s%d" % (nm[:-1], wt), args, [o]))
+        self.wfinal_cost_fn, self.wdhx_fn = self.final_cost_fn, self.dhx_fn
+
+    def warp_getAuxSys(self, wstate_traj, wcontrol_traj, auxvar_value):         # PDP.py:941-958
+        assert hasattr(self, "wdfx_fns"), "Warp the dynamics first (warp_dynCost / warp_init_step)!"
+        out = {"wdynF": [], "wdynG": [], "wdUx": [], "wdUe": []}
+        for wt in range(numpy.size(wcontrol_traj, 0)):
+            xw, uw = wstate_traj[wt, :], wcontrol_traj[wt, :]
+            out["wdynF"].append(self.wdfx_fns[wt](xw, uw).full())
+            out["wdynG"].append(self.wdfu_fns[wt](xw, uw).full())
+            out["wdUx"].append(self.dpolicy_dx_fn(wt, xw, auxvar_value).full())
+            out["wdUe"].append(self.dpolicy_de_fn(wt, xw, auxvar_value).full())
+        return out
+
+    def recmat_recoveryMatrix(self, whorizon):                                  # PDP.py:1039-1079
+        """The gradient of the warped cost with respect to the stacked cell controls as ONE symbolic expression of (x_0, U_0 .. U_{W-1}):
+        self.recovery_matrix_fn(ini_state, auxvar) -> column of length W * m.  Built by carrying, cell by cell, the row d(cost so far)/dU_j and
+        the matrix d x_cell / dU_j for every earlier cell j (the reference's H1 / H2 lists)."""
+        assert hasattr(self, "wdyn_fns"), "Please warp the dynamics and cost function first by running warp_init_step!"
+        x0 = SX.sym("X0", self.n_state)
+        U = [SX.sym("U_%d" % wt, self.n_control) for wt in range(whorizon)]
+        xk, dcost, dx = x0, [], []           # dcost[j]: d cost / d U_j (1 x m) so far; dx[j]: d x_k / d U_j (n x m)
+        for wt in range(whorizon):
+            Fk, Gk = self.wdfx_fns[wt](xk, U[wt]), self.wdfu_fns[wt](xk, U[wt])
+            cxk, cuk = self.wdcx_fns[wt](xk, U[wt]), self.wdcu_fns[wt](xk, U[wt])
+            dcost = [dcost[j] + sx.mtimes(cxk, dx[j]) for j in range(wt)] + [cuk]
+            dx = [sx.mtimes(Fk, dx[j]) for j in range(wt)] + [Gk]
+            xk = self.wdyn_fns[wt](xk, U[wt])
+        hx = self.wdhx_fn(xk)
+        rows = [dcost[j] + sx.mtimes(hx, dx[j]) for j in range(whorizon)]
+        self.auxvar = sx.vcat(U)
+        self.n_auxvar = self.auxvar.numel()
+        self.recovery_matrix_fn = sx.Function("recovery_matrix_fn", [x0, self.auxvar], [sx.transpose(sx.hcat(rows))])
+
     def recmat_init_step(self, horizon, time_grid=None):                        # PDP.py:1081-1098
         self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon, horizon + 1))
         self.n_auxvar = self.whorizon * self.n_control

@@ -71,9 +71,14 @@ def test_workspace_size_entry_points_are_host_side_and_consistent(built):
     cp = runtime.load_model(codegen.build_problem(zoo.make_problem("quadrotor", "oc"))[0])
     mlp = runtime.make_policy("mlp", layers=[13, 13, 4])
     poly = runtime.make_policy("poly", pivots=np.linspace(0, 100, 6))
-    # MLP [13,13]: 26 stored activations per step, offloaded only when the batch does not fit the CUs at once (256 CUs assumed w/o GPU)
-    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(mlp), 420) == 0
-    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(mlp), 420) == 1024 * 100 * 26 * 8
+    # MLP [13,13] runs on the register-resident kernel: one stored activation per lane and time step, whatever the batch
+    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(mlp), 420) == 16 * 100 * 64 * 8
+    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(mlp), 420) == 1024 * 100 * 64 * 8
+    # a network beyond that kernel (width > 16): the general adjoint kernel, 20 stored activations per step, offloaded only when the batch does not
+    # fit the CUs at once (256 CUs assumed without a GPU)
+    wide = runtime.make_policy("mlp", layers=[20, 4])
+    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(wide), 20 * 13 + 20 + 4 * 20 + 4) == 0
+    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(wide), 20 * 13 + 20 + 4 * 20 + 4) == 1024 * 100 * 20 * 8
     assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(poly), 24) == 0
     assert cp.lib.pdp_oc_solve_workspace_bytes(B, T, 10) == 0 and cp.lib.pdp_oc_pdp_workspace_bytes(B, T) == 0
     # argument validation of the solver entry point happens before any launch
@@ -173,10 +178,58 @@ def test_ocsolver_rejects_finite_bounds_and_new_entry_points_validate_arguments(
     m = runtime.ModelLib(lib)
     B, T = 7, 30
     n0, n1 = m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 0), m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 100)
-    per = (T + 1) * 2 + T * 1 + T * 2 + T * 2 + (T + 1) * 2 + T * 1 + T * (2 * 1 + 1 + 1) + T * (4 + 2 + 1)     # dx du dlam c gradx gradu gains P,W
-    assert n0 == 8 * B * (per + 2) and n1 - n0 == 8 * B * 2 * 100
+    # either kernel variant may serve a call: the larger of the two layouts.  One-wave kernel: dx du dlam c gradx gradu gains P,W; runner / evaluator
+    # kernel: five stage-minor groups of (2 n + m) (T + 1) doubles (two point sets, the step, two residual sets) + gains (K | k) + (P | W)
+    per1 = (T + 1) * 2 + T * 1 + T * 2 + T * 2 + (T + 1) * 2 + T * 1 + T * (2 * 1 + 1 + 1) + T * (4 + 2 + 1)
+    per2 = 5 * (2 * 2 + 1) * (T + 1) + T * (2 * 1 + 1) + T * (4 + 2)
+    assert n0 == 8 * B * (max(per1, per2) + 2) and n1 - n0 == 8 * B * 2 * 100
     opts = runtime.PdpOcMsOpts(1e-10, 100, 0, 0)
     import ctypes
     assert m.lib.pdp_oc_solve_ms_batched(0, T, None, None, 0, None, None, None, None, None, None, None, None, None, None, ctypes.byref(opts), None, 0, None) == -1
     cp = runtime.ModelLib(built[0].build_problem(zoo.make_problem("pendulum", "oc"))[0])
     assert cp.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 10) == 0
+
+
+def test_warp_and_recovery_matrix_internals_on_the_class_surface(golden_dir):
+    """ControlPlanning.warp_dynCost / warp_getAuxSys / recmat_recoveryMatrix (PDP.py:882-958, 1039-1079) exist for callers that use the reference's
+    symbolic internals directly (host-side objects on this package's SX layer; warp_step / recmat_step themselves run on the GPU).  The recovery matrix
+    evaluated at the reference's own run (ref_recmat_pendulum_0.npz, sympy stand-in) must give the reference's gradient; the per-cell Jacobians must be
+    the derivatives of the per-cell maps."""
+    import numpy as np
+    from pdp_amd import PDP, zoo
+    g = np.load(os.path.join(golden_dir, "ref_recmat_pendulum_0.npz"))
+    env, _ = zoo.make_env("pendulum", "oc")
+    cp = PDP.ControlPlanning()
+    cp.setStateVariable(env.X)
+    cp.setControlVariable(env.U)
+    cp.setDyn(env.X + float(g["dt"]) * env.f)
+    cp.setPathCost(env.path_cost)
+    cp.setFinalCost(env.final_cost)
+    tg = g["time_grid"]
+    cp.warp_dynCost(tg)
+    W = len(tg) - 1
+    assert len(cp.wdyn_fns) == W == len(cp.wdfx_fns) == len(cp.wdcu_fns)
+    cp.recmat_recoveryMatrix(W)
+    assert cp.n_auxvar == g["theta"].size
+    grad = cp.recovery_matrix_fn(g["x0"], g["theta"]).full().flatten()
+    assert np.abs(grad - g["grad"]).max() <= 1e-11 * np.abs(g["grad"]).max()
+    # cell maps: cost and end state of the composed cells reproduce the stored rollout; Jacobians against central differences
+    x, cost = g["x0"].copy(), 0.0
+    for wt in range(W):
+        u = g["theta"][wt:wt + 1]
+        cost += float(cp.wpath_cost_fns[wt](x, u))
+        x = cp.wdyn_fns[wt](x, u).full().flatten()
+        assert np.abs(x - g["state"][tg[wt + 1]]).max() <= 1e-12
+    assert abs(cost + float(cp.wfinal_cost_fn(x)) - float(g["loss"])) <= 1e-11 * abs(float(g["loss"]))
+    x, u, eps = g["state"][tg[2]], g["theta"][2:3], 1e-6
+    F = cp.wdfx_fns[2](x, u).full()
+    for k in range(2):
+        e = np.zeros(2)
+        e[k] = eps
+        fd = (cp.wdyn_fns[2](x + e, u).full().flatten() - cp.wdyn_fns[2](x - e, u).full().flatten()) / (2 * eps)
+        assert np.abs(F[:, k] - fd).max() <= 1e-7
+    cp.warp_init_step(int(g["T"]))
+    cp.warp_dynCost(cp.time_grid)
+    ws = np.stack([g["state"][t] for t in cp.time_grid])
+    aux = cp.warp_getAuxSys(ws, np.zeros((cp.whorizon, 1)), np.zeros(cp.n_auxvar))
+    assert len(aux["wdynF"]) == cp.whorizon and aux["wdynF"][0].shape == (2, 2) and aux["wdUe"][0].shape == (1, cp.n_auxvar) and np.all(aux["wdUx"][0] == 0)

@@ -56,6 +56,47 @@ def test_C2_cartpole_irl_batch256_pdp_gradient_is_derivative_through_the_oc_solu
     assert np.abs(2 * g[idx] - fd).max() <= 2e-4 * np.abs(fd).max()
 
 
+def test_C3_quadrotor_planning_T50_batch1024(margins):
+    """C3's ControlPlanning half at full size: quadrotor n=13 m=4, Lagrange policy p=24, T=50, 1024 random initial states, shared theta
+    (bench.py's workload).  Four samples against the oracle (PDP.py:850-878 restated, oracle/pdp_oracle.py) with recorded margins; all samples:
+    finite, independent of the batch they are in; the gradient is the derivative of the rollout cost (central differences); the materialised
+    route of the reference (integrateSys -> getAuxSys -> integrateAuxSys -> chain rule) gives the same numbers."""
+    from oracle import models, pdp_oracle as po
+    from pdp_amd import runtime as rt, zoo
+    mdl = zoo.get("quadrotor", "oc")
+    rng = np.random.default_rng(0)
+    B, T, p = 1024, 50, 24
+    x0 = np.zeros((B, 13))
+    x0[:, :3] = rng.uniform(-5, 5, (B, 3))
+    x0[:, 6] = 1
+    theta = rng.standard_normal(p)
+    pol = rt.make_policy("poly", pivots=np.linspace(0, T, 6))
+    loss, grad, x, u = mdl.cp_step(pol, p, x0, theta, T, want_traj=True)
+    L, G = npy(loss), npy(grad)
+    assert np.all(np.isfinite(L)) and np.all(np.isfinite(G))
+    cp = po.make_cp(models.quadrotor(Jx=1, Jy=1, Jz=1, mass=1, l=0.4, c=0.01, wr=1, wv=1, wq=5, ww=1, wthrust=0.1), 0.1)
+    cp.init_step(T)
+    for i in (0, 341, 682, 1023):
+        l, g = cp.step(x0[i], T, theta)
+        sol = cp.integrateSys(x0[i], T, theta)
+        margins.check("C3 ControlPlanning.step B=1024 sample %d vs oracle: loss (relative)" % i, abs(L[i] - l) / abs(l), 1e-11)
+        margins.check("C3 ControlPlanning.step B=1024 sample %d vs oracle: gradient (relative to its largest entry)" % i, np.abs(G[i] - g).max() / np.abs(g).max(), 1e-10)
+        margins.check("C3 ControlPlanning.step B=1024 sample %d vs oracle: state trajectory (absolute)" % i, np.abs(npy(x)[i] - sol["state_traj"]).max(), 1e-10)
+    l2, g2 = mdl.cp_step(pol, p, x0[500:503], np.tile(theta, (3, 1)), T)
+    assert np.array_equal(npy(l2), L[500:503]) and np.array_equal(npy(g2), G[500:503])
+    l3, g3 = mdl.cp_step_materialised(pol, p, x0[:64], theta, T)
+    assert np.abs(npy(l3) - L[:64]).max() <= 1e-12 * np.abs(L[:64]).max() and np.abs(npy(g3) - G[:64]).max() <= 1e-10 * np.abs(G[:64]).max()
+    eps = 1e-6
+    for k in (0, 11, 23):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += eps
+        tm[k] -= eps
+        lp, _ = mdl.cp_step(pol, p, x0[:8], tp, T)
+        lm, _ = mdl.cp_step(pol, p, x0[:8], tm, T)
+        fd = (npy(lp) - npy(lm)) / (2 * eps)
+        assert np.abs(fd - G[:8, k]).max() <= 1e-6 * np.abs(G[:8, k]).max()
+
+
 def test_C4_rocket_planning_T100_batch512():
     """C4 per-GPU shard: rocket n=13 m=3 T=100, Lagrange policy p=18, 512 random initial states.  ControlPlanning.step returns
     the exact gradient of the rollout cost: checked by finite differences; per-sample results do not depend on the batch."""
@@ -189,9 +230,9 @@ def test_C5_quadrotor_neural_policy_T100_p420():
 
 
 def test_C5_neural_policy_full_shard_equals_small_batch():
-    """C5b at one GPU's shard (B = 1024): the adjoint kernel then keeps the hidden activations in its HBM workspace and uses a smaller
-    evaluation pool (4 wavefronts per CU); the arithmetic per trajectory is the same as in the LDS-resident layout used for small
-    batches - loss and gradient of the first 16 trajectories agree to rounding with the 16-trajectory run."""
+    """C5b at one GPU's shard (B = 1024) through the register-resident MLP kernel (cp_step_mlp16_kernel: every lane keeps its hidden
+    activation of every time step in the HBM workspace, 64 doubles per step): the arithmetic per trajectory does not depend on the batch -
+    loss and gradient of the first 16 trajectories agree to rounding with the 16-trajectory run."""
     from pdp_amd import runtime as rt, zoo
     mdl = zoo.get("quadrotor", "oc")
     rng = np.random.default_rng(3)
@@ -201,8 +242,8 @@ def test_C5_neural_policy_full_shard_equals_small_batch():
     x0[:, :3] = rng.uniform(-2, 2, (B, 3))
     x0[:, 6] = 1.0
     pol = rt.make_policy("mlp", layers=[13, 13, 4])
-    assert mdl.lib.pdp_cp_step_workspace_bytes(B, T, rt.C.byref(pol), p) == B * T * 26 * 8          # offloaded: 13 + 13 activations per step
-    assert mdl.lib.pdp_cp_step_workspace_bytes(16, T, rt.C.byref(pol), p) == 0                      # resident
+    assert mdl.lib.pdp_cp_step_workspace_bytes(B, T, rt.C.byref(pol), p) == B * T * 64 * 8          # one double per lane and time step
+    assert mdl.lib.pdp_cp_step_workspace_bytes(16, T, rt.C.byref(pol), p) == 16 * T * 64 * 8
     L, G = mdl.cp_step(pol, p, x0, theta, T)
     l, g = mdl.cp_step(pol, p, x0[:16], theta, T)
     L, G, l, g = npy(L), npy(G), npy(l), npy(g)

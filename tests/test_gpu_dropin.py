@@ -266,15 +266,19 @@ def test_dense_numeric_linear_model_with_more_than_64_constants():
         assert abs(fd - grad[k]) <= 1e-6 * max(1.0, abs(fd))
 
 
-@pytest.mark.parametrize("fixture", ["ref_warp_pendulum_0", "ref_recmat_pendulum_0", "ref_warp_cartpole_1", "ref_recmat_rocket_2", "ref_recmat_quadrotor_3"])
+@pytest.mark.parametrize("fixture", ["ref_warp_pendulum_0", "ref_recmat_pendulum_0", "ref_warp_cartpole_1", "ref_recmat_rocket_2", "ref_recmat_quadrotor_3",
+                                     "ref_recmat_long_rocket", "ref_recmat_long_quadrotor", "ref_recmat_long_robotarm"])
 def test_warp_and_recmat_variants_match_reference_run(golden_dir, fixture):
     """ControlPlanning.warp_step / recmat_step / *_unwarp (PDP.py:882-1141): the reference composes the dynamics symbolically over
     grid cells; here the same gradient comes from one adjoint (costate) sweep on the GPU.  The rocket / quadrotor fixtures are the
     reference's own recmat_init_step(horizon, -1) runs (Examples/OC/rocket/rocket_PDP_Recmat.py:47-64, uav_PDP_Recmat.py: one cell per
-    time step, their initial states), at the horizon its symbolic recovery matrix can still be composed by the build container's stand-in."""
+    time step, their initial states), at the horizon its symbolic recovery matrix can still be composed by the build container's sympy stand-in
+    (T = 7); the ref_recmat_long_* fixtures are the same reference code at the drivers' REAL horizons - rocket T = 50, quadrotor T = 35,
+    robot arm T = 20 (robotarm_PDP_Recmat.py:49-56) - executed on this package's SX layer as the CasADi stand-in, cross-checked against the
+    sympy runs (tests/golden/make_recmat_long.py)."""
     from pdp_amd import PDP, zoo
     g = load(golden_dir, fixture + ".npz")
-    mode, name = fixture.split("_")[1], fixture.split("_")[2]
+    mode, name = fixture.split("_")[1], fixture.split("_")[-1] if "long" in fixture else fixture.split("_")[2]
     env, _ = zoo.make_env(name, "oc")
     cp = PDP.ControlPlanning()
     cp.setStateVariable(env.X)

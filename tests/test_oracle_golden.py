@@ -61,7 +61,7 @@ def test_pmp_conditions_hold_on_stored_demos(golden_dir, name):
 
 @pytest.mark.parametrize("name,rows", [("pendulum", [0, 3, 9]), ("cartpole", [0, 3, 7]), ("robotarm", [0, 4]),
                                        ("quadrotor", [1, 5, 9]), ("rocket", [0, 3, 8])])
-def test_full_irl_pipeline_matches_stored_trace(golden_dir, name, rows):
+def test_full_irl_pipeline_matches_stored_trace(golden_dir, margins, name, rows):
     """OC solve -> getAuxSys -> lqrSolver -> chain rule reproduces loss_trace[k+1] and (p_k-p_{k+1})/lr."""
     d = _load(golden_dir, "demos_%s.npz" % name)
     tr = _load(golden_dir, "irltrace_%s.npz" % name)
@@ -81,8 +81,9 @@ def test_full_irl_pipeline_matches_stored_trace(golden_dir, name, rows):
         nd = d["state"].shape[0]
         loss, dp = loss / nd, dp / nd
         gref = (tr["param"][j] - tr["param_next"][j]) / float(tr["lr"])
-        assert abs(loss - tr["loss_next"][j]) <= 1e-7 * abs(tr["loss_next"][j])
-        assert np.abs(dp - gref).max() <= 1e-6 * np.abs(gref).max()
+        # restatement against the stored traces <= 1e-9 (loss), <= 1e-7 (gradient)
+        margins.check("oracle vs stored IRL trace, %s row %d: loss (relative)" % (name, j), abs(loss - tr["loss_next"][j]) / abs(tr["loss_next"][j]), 1e-9)
+        margins.check("oracle vs stored IRL trace, %s row %d: gradient (relative to its largest entry)" % (name, j), np.abs(dp - gref).max() / np.abs(gref).max(), 1e-7)
 
 
 def test_quadrotor_oc_stored_rollout_and_cost(golden_dir):
