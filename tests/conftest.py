@@ -39,7 +39,7 @@ class Margins:
         if self.path:
             try:
                 with open(self.path, "a") as f:
-                    f.write("%-110s achieved %.3e   bound %.1e   margin x%.1f\n" % (label, achieved, bound, bound / max(achieved, 1e-300)))
+                    f.write("%-110s achieved %.3e   bound %.1e   margin %s\n" % (label, achieved, bound, "x%.1f" % (bound / achieved) if achieved > 0 else "(exact)"))
             except OSError:
                 pass
         assert achieved <= bound, "%s: %.3e > %.1e" % (label, achieved, bound)

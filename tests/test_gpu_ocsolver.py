@@ -50,7 +50,10 @@ def test_oc_solver_reproduces_stored_ipopt_optimum(golden_dir, name):
     assert np.abs(lam - d["costate"]).max() <= 1e-6 * max(1, np.abs(d["costate"]).max())      # costate[t] = lambda_{t+1}, IPOPT lam_g sign
 
 
-END2END_BOUNDS = {"cartpole": (1e-6, 2e-5), "quadrotor": (1e-6, 2e-5), "pendulum": (1e-6, 2e-5), "robotarm": (1e-6, 2e-5), "rocket": (1e-6, 2e-5)}      # (loss, gradient)
+# (loss, gradient): about ten times what each system achieves (profiles/r03_parity_margins.txt).  Quadrotor, rocket and pendulum sit far inside BASELINE.md
+# section 3's 1e-9 / 1e-7; the cart-pole and the robot arm are limited by the stored side of the comparison - IPOPT stopped those optima at its own 1e-8,
+# and the swing-up / arm problems amplify that into 1e-8 (loss) / 3e-8 (gradient), the same figures the CPU oracle reaches on these rows
+END2END_BOUNDS = {"cartpole": (1e-7, 5e-7), "quadrotor": (1e-12, 1e-9), "pendulum": (1e-11, 1e-8), "robotarm": (2e-8, 2e-7), "rocket": (1e-11, 1e-8)}
 
 
 @pytest.mark.parametrize("name,rows", [("cartpole", [0, 3, 7]), ("quadrotor", [1, 5, 9]), ("pendulum", [0, 9]), ("robotarm", [0, 4]), ("rocket", [0, 3, 8])])
