@@ -101,8 +101,12 @@ PDP_DEV void move3(Run3& r, int bytes) {
     for (int k = 0; k < NR; ++k) r.cur[k] += (unsigned)bytes;
 }
 
-template <class Mdl>
-__global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
+// TPW trajectories per workgroup of 2 TPW waves (runner = wave j, evaluator = wave j + TPW).  TPW = 4 (512 threads): the pair shares a SIMD - the layout for
+// batches that fill the chip (>= 1024 trajectories).  TPW = 2 / 1 (a 512-trajectory shard of C4, small batches): a CU then hosts at most two / one
+// trajectory, and the two waves of a trajectory sit on DIFFERENT SIMDs - the evaluator no longer competes with the runner's MFMA chain for issue slots
+// (profiles/r03_fused3_small_batch.txt).
+template <class Mdl, int TPW = 4>
+__global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
                                                             const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
                                                             const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                             double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
@@ -115,9 +119,10 @@ __global__ void __launch_bounds__(512) oc_pdp_fused3_kernel(int B, int T, int fl
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     // the wave index is uniform over the wave - said explicitly, or every pointer derived from it (trajectory, workspace, LDS slice) would be
     // carried per lane and every global access would pay 64-bit VALU address arithmetic
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, slot = wid & 3;
-    const bool runner = wid < 4;
-    const int b = blockIdx.x * 4 + slot;
+    static_assert(TPW == 1 || TPW == 2 || TPW == 4, "trajectories per workgroup");
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, slot = wid & (TPW - 1);
+    const bool runner = wid < TPW;
+    const int b = blockIdx.x * TPW + slot;
     double* lds = lds_all + slot * F3::SLICE;
     double* scratch = lds;
     double* fin = lds + F3::FIN;

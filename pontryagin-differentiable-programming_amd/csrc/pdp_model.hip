@@ -106,10 +106,20 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         PDP_CLEAR();
         if constexpr (Mdl::NX > 4) {
             if (variant == 3 && fused3_ok<Mdl>(T)) {
-                (void)hipFuncSetAttribute((const void*)oc_pdp_fused3_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipLaunchKernelGGL((oc_pdp_fused3_kernel<Mdl>), dim3((B + 3) / 4), dim3(512), 160 * 1024, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss,
-                                   grad, dxdp, dudp, status, (double*)ws);
-                return launched();
+                // trajectories per workgroup: 4 (runner and evaluator share a SIMD) once the batch fills the chip that way; a smaller batch spreads over
+                // the CUs with the two waves of a trajectory on different SIMDs (PDP_FUSED_TPW overrides)
+                static const int tpw_env = [] { const char* e = std::getenv("PDP_FUSED_TPW"); return e ? std::atoi(e) : 0; }();
+                const int cus = device_cu_count();
+                const int tpw = tpw_env ? tpw_env : (B <= cus ? 1 : (B <= 2 * cus ? 2 : 4));
+                auto go = [&](auto kern, int TPW) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TPW * 40 * 1024);
+                    hipLaunchKernelGGL(kern, dim3((B + TPW - 1) / TPW), dim3(128 * TPW), TPW * 40 * 1024, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
+                                       dudp, status, (double*)ws);
+                    return launched();
+                };
+                if (tpw == 1) return go(oc_pdp_fused3_kernel<Mdl, 1>, 1);
+                if (tpw == 2) return go(oc_pdp_fused3_kernel<Mdl, 2>, 2);
+                return go(oc_pdp_fused3_kernel<Mdl, 4>, 4);
             }
         }
         (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -159,8 +159,10 @@ def test_full_irl_iteration_matches_stored_reference_trace(golden_dir, margins, 
 
 
 def test_fused_pdp_full_size_batch_properties():
-    """BASELINE config C3 size (quadrotor n=13 T=50 B=1024): per-sample results do not depend on the batch they are in,
-    shared theta == replicated theta, status clean."""
+    """BASELINE config C3 size (quadrotor n=13 T=50 B=1024): per-sample results do not depend on the batch they are in, shared theta ==
+    replicated theta, status clean.  Batches that run in the same workgroup shape (the library picks 1, 2 or 4 trajectories per workgroup by
+    batch size, pdp_model.hip) agree BIT FOR BIT; across shapes the instantiations of the kernel may contract a few products differently:
+    agreement to 1e-13."""
     from pdp_amd import zoo
     import torch
     mdl = zoo.get("quadrotor", "irl")
@@ -174,8 +176,10 @@ def test_fused_pdp_full_size_batch_properties():
     o1 = mdl.oc_pdp_grad(u, th, dx, du, x0=x0)
     g1, l1 = npy(o1["grad"]).copy(), npy(o1["loss"]).copy()
     assert int(o1["status"].sum()) == 0 and np.all(np.isfinite(g1))
-    o2 = mdl.oc_pdp_grad(u[:7], np.tile(th, (7, 1)), dx[:7], du[:7], x0=x0[:7])
-    assert np.array_equal(npy(o2["grad"]), g1[:7]) and np.array_equal(npy(o2["loss"]), l1[:7])
+    o2 = mdl.oc_pdp_grad(u[:777], np.tile(th, (777, 1)), dx[:777], du[:777], x0=x0[:777])          # same shape as the full batch (4 per workgroup)
+    assert np.array_equal(npy(o2["grad"]), g1[:777]) and np.array_equal(npy(o2["loss"]), l1[:777])
+    o3 = mdl.oc_pdp_grad(u[:7], np.tile(th, (7, 1)), dx[:7], du[:7], x0=x0[:7])                  # one trajectory per workgroup
+    assert np.abs(npy(o3["grad"]) - g1[:7]).max() <= 1e-13 * np.abs(g1[:7]).max() and np.abs(npy(o3["loss"]) - l1[:7]).max() <= 1e-13 * np.abs(l1[:7]).max()
 
 
 # ------------------------------------------------------------------------------------------------ ControlPlanning
