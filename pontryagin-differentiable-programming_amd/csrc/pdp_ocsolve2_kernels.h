@@ -30,8 +30,16 @@
 // steps re-read only K, k (56 doubles), requested TWO steps ahead through buffer loads (absent tile elements are out-of-range lanes: they
 // load 0 and store nothing, no sink words, no predicated blocks).
 #pragma once
+#include <type_traits>
 #include "pdp_ocsolve_kernels.h"
 #include "pdp_fused3_kernels.h"
+
+#ifndef PDP_MS2_DLAM_STAGED
+#define PDP_MS2_DLAM_STAGED 1      // the multiplier step reads its (P, W) records through an LDS copy (dlam_staged) when four trajectories share a CU; 0: straight from the workspace
+#endif
+#ifndef PDP_MS2_TAILF
+#define PDP_MS2_TAILF 0             // stages of a short last forward chunk (0: equal chunks - measured best, profiles/r03_ms2_variants.txt)
+#endif
 
 namespace pdp {
 
@@ -39,13 +47,18 @@ template <class Mdl>
 struct Ms2Layout {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
     static constexpr bool SMALL = NX <= 4;
+    // AUG: the Newton step in homogeneous form (riccati_backward_aug, pdp_riccati.h): state augmented by a constant 1, NA = NX + 1 <= 16 rows / columns
+    static constexpr bool AUG = !SMALL && NX < 16;
+    static constexpr int NA = AUG ? NX + 1 : NX;
     static constexpr int NS = Mdl::SOL_NVAR, NF = Mdl::SOLF_NVAR;
     // backward pool row: [sol entries | defect c_t (NX) | grad_x L (NX) | grad_u L (NU) | 0.0 | constants]  (uniform rows, see Fused3Layout)
     static constexpr int C0 = NS, RX = NS + NX, RU = NS + 2 * NX, CB0 = NS + 2 * NX + NU;
-    static constexpr int BSTRIDE = (CB0 + 1 + Mdl::SOL_NCONST) | 1;
+    static constexpr int ONEB = CB0 + 1 + Mdl::SOL_NCONST;                 // a 1.0 behind the constants (the homogeneous coordinate of F~)
+    static constexpr int BSTRIDE = (ONEB + 1) | 1;
     // forward pool row: [solf entries | defect c_t (NX) | grad_x L of stage t+1 (NX) | grad_u L (NU) | 0.0 | constants]
     static constexpr int FC0 = NF, FRX = NF + NX, FRU = NF + 2 * NX, CF0 = NF + 2 * NX + NU;
-    static constexpr int FSTRIDE = (CF0 + 1 + Mdl::SOLF_NCONST) | 1;
+    static constexpr int ONEF = CF0 + 1 + Mdl::SOLF_NCONST;
+    static constexpr int FSTRIDE = (ONEF + 1) | 1;
     // a trajectory's LDS slice (doubles)
     static constexpr int FIN = RICCATI_SCRATCH;                          // [0.0 | terminal constants | terminal entries]
     static constexpr int NCFIN = 1 + Mdl::FIN_NCONST;
@@ -58,10 +71,17 @@ struct Ms2Layout {
     static constexpr int ROWS = BUF / BSTRIDE < 64 ? BUF / BSTRIDE : 64;
     static constexpr int ROWSF = BUF / FSTRIDE < 64 ? BUF / FSTRIDE : 64;
     // workspace per stage
-    static constexpr int GSZ = NX * NU + NU;                              // K [NU x NX] | k [NU]
-    static constexpr int PSZ = SMALL ? NX * NX : NX * (NX + 1) / 2;      // P_{t+1}: full (small systems keep it in rep form), else the upper triangle
-    static constexpr int PWSZ = PSZ + NX;                                 //          | W_{t+1} [NX]
-    __host__ __device__ static constexpr int pk(int i, int j) { return SMALL ? i * NX + j : (i <= j ? i * NX - i * (i - 1) / 2 + (j - i) : j * NX - j * (j - 1) / 2 + (i - j)); }
+    // gains: K [NU x NX] | k [NU]; homogeneous form: K~ = [K | k] [NU x NA]
+    static constexpr int GSZ = NX * NU + NU;
+    // P_{t+1}: small systems keep the full matrix (rep form) followed by W_{t+1}; else the upper triangle of P (followed by W), or - homogeneous form -
+    // of P~ = [P W; W' s], which contains W as its last column
+    static constexpr int PSZ = SMALL ? NX * NX : NA * (NA + 1) / 2;
+    static constexpr int PWSZ = AUG ? PSZ : PSZ + NX;
+    __host__ __device__ static constexpr int pk(int i, int j) { return SMALL ? i * NX + j : (i <= j ? i * NA - i * (i - 1) / 2 + (j - i) : j * NA - j * (j - 1) / 2 + (i - j)); }
+    // offsets inside a stage's records: K[i][k], k_i (gains) and W_i (behind / inside P)
+    __host__ __device__ static constexpr int gK(int i, int k) { return AUG ? i * NA + k : i * NX + k; }
+    __host__ __device__ static constexpr int gk(int i) { return AUG ? i * NA + NX : NX * NU + i; }
+    __host__ __device__ static constexpr int pW(int i) { return AUG ? pk(i, NX) : PSZ + i; }
     // Everything the evaluator touches with one lane per stage is kept STAGE-MINOR: element (stage t, component i) at [i * TS + t], TS = T + 1 - a wave
     // instruction of such a pass reads 64 consecutive doubles (4 cache lines).  In the API's stage-major layout [t][i] every lane sits in its own cache
     // line: at B = 1024 (four trajectories per CU) the trial pass alone kept a CU's address unit busy for ~40 k cycles (profiles/r03_ms2_phase_timing_v1.txt).
@@ -145,8 +165,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                                                                   double* __restrict__ iter_log, double* __restrict__ ws) {
     using L = Ms2Layout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
-    constexpr bool SMALL = L::SMALL;
-    constexpr int NRT = SMALL ? 1 : 4;
+    constexpr bool SMALL = L::SMALL, AUG = L::AUG;
+    constexpr int NRT = SMALL ? 1 : 4, NA = L::NA;
     constexpr int GSZ = L::GSZ, PSZ = L::PSZ, PWSZ = L::PWSZ;
     constexpr int BS = L::BSTRIDE, FS = L::FSTRIDE;
     constexpr int U = 4;                                     // backward steps per address update (literal row offsets inside a group)
@@ -190,8 +210,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     const int nchunk = (T + L::ROWS - 1) / L::ROWS;
     const int ch = (T + nchunk - 1) / nchunk;
     auto bchunk = [&](int g, int& t0, int& cnt) { const int c = nchunk - 1 - g; t0 = c * ch; cnt = min(ch, T - t0); };
-    const int nchunkF = (T + L::ROWSF - 1) / L::ROWSF;
-    const int chF = (T + nchunkF - 1) / nchunkF;
+    // forward chunks: equal chunks (optionally, PDP_MS2_TAILF > 0, a short last chunk behind equal chunks over the first T - tailF stages).  The multiplier step
+    // of a chunk runs on the evaluator behind the runner - hidden for every chunk but the last, whose (P, W) records all trajectories of the batch fetch at the
+    // same moment (21 MB in one burst for 25 stages at B = 1024: ~15 k cycles of memory time after the runner has finished).  A short last chunk was tried to
+    // shrink that burst: the evaluator then still owes the multiplier step of the long chunk before it when the runner is done - no gain (profiles/r03_ms2_variants.txt)
+    const int tailF = (PDP_MS2_TAILF > 0 && T > 3 * PDP_MS2_TAILF) ? PDP_MS2_TAILF : 0;
+    const int nbodyF = (T - tailF + L::ROWSF - 1) / L::ROWSF, chF = (T - tailF + nbodyF - 1) / nbodyF;
+    const int nchunkF = nbodyF + (tailF ? 1 : 0);
+    auto fchunk = [&](int c, int& t0, int& cnt) { if (c < nbodyF) { t0 = c * chF; cnt = min(chF, T - tailF - t0); } else { t0 = T - tailF; cnt = tailF; } };
 
     if (runner) {
         // ================================================ runner ================================================
@@ -243,26 +269,36 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // ---- loop-invariant gather / store maps
         auto codeS = [](int mat, int i) { return Mdl::sol_code(mat, i); };       // 0 F, 1 G, 2 Hxx, 3 Hxu, 4 Huu
         Gather3 gF, gY, gHxx, gHX, gHU, gGr, gHux;
+        if constexpr (AUG) {
+            // homogeneous form: F~ = [F c; 0 1], G~ = [G; 0], Hxx~ = [Hxx rx; rx' 0], Hux~ = [Hxu' | ru], Huu
+            make_gather3(gF, lane, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(0, r * NX + c) : ((r < NX && c == NX) ? L::C0 + r : ((r == NX && c == NX) ? L::ONEB : -1)); });
+            make_gather3(gY, lane, L::CB0, [&](int r, int c) { return (r < NX && c < M) ? codeS(1, r * NU + c) : -1; });
+            make_gather3(gHxx, lane, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(2, r * NX + c) : ((r < NX && c == NX) ? L::RX + r : ((r == NX && c < NX) ? L::RX + c : -1)); });
+            make_gather3(gHux, lane, L::CB0, [&](int r, int c) { return (r < M && c < NX) ? codeS(3, c * NU + r) : ((r < M && c == NX) ? L::RU + r : -1); });
+            make_gather3(gHU, lane, L::CB0, [&](int r, int c) { return (r < M && c < M) ? codeS(4, r * NU + c) : -1; });
+            make_gather3(gHX, lane, L::CB0, [&](int r, int c) { return -1; });
+        } else {
         make_gather3(gF, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(0, r * NX + (c & 3)) : -1)
                                                                         : ((r < NX && c < NX) ? codeS(0, r * NX + c) : -1); });
         make_gather3(gY, lane, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(1, r * NU + c) : (c == M ? L::C0 + r : -1)); });
-        make_gather3(gGr, lane, L::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
         make_gather3(gHux, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? codeS(3, (c & 3) * NU + r) : -1)
                                                                           : ((r < M && c < NX) ? codeS(3, c * NU + r) : -1); });
         make_gather3(gHxx, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(2, r * NX + (c & 3)) : -1)
                                                                           : ((r < NX && c < NX) ? codeS(2, r * NX + c) : -1); });
         make_gather3(gHX, lane, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(3, r * NU + c) : (c == M ? L::RX + r : -1)); });
         make_gather3(gHU, lane, L::CB0, [&](int r, int c) { return r >= M ? -1 : (c < M ? codeS(4, r * NU + c) : (c == M ? L::RU + r : -1)); });
+        }
+        make_gather3(gGr, lane, L::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
         const int col = tile_col(lane);
         BufMap mK, mIK, mP, mW, mKT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = tile_row(lane, r);
-            mK.voff[r] = (row < NU && col < NX) ? 8u * (unsigned)(row * NX + col) : MS2_OOB;                          // K [NU x NX] (rep form: first column block)
-            mIK.voff[r] = (row < NU && col == M) ? 8u * (unsigned)(NX * NU + row) : MS2_OOB;                          // k behind it
-            mP.voff[r] = (row < NX && col < NX && (SMALL || row <= col)) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;   // P_{t+1}: full / upper triangle
+            mK.voff[r] = (row < NU && col < NA) ? 8u * (unsigned)L::gK(row, col) : MS2_OOB;                           // K [NU x NX] (rep form: first column block) / K~ [NU x NA]
+            mIK.voff[r] = (row < NU && col == M) ? 8u * (unsigned)(NX * NU + row) : MS2_OOB;                          // k behind K (not in the homogeneous form)
+            mP.voff[r] = (row < NA && col < NA && (SMALL || row <= col)) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;   // P_{t+1}: full / upper triangle (of P~)
             mW.voff[r] = (row < NX && col == M) ? 8u * (unsigned)(PSZ + row) : MS2_OOB;
-            mKT.voff[r] = (row < NX && (col & 3) < NU) ? 8u * (unsigned)((col & 3) * NX + row) : MS2_OOB;             // K read back transposed, replicated in the column blocks
+            mKT.voff[r] = (row < NA && (col & 3) < NU) ? 8u * (unsigned)L::gK(col & 3, row) : MS2_OOB;                // K (K~) read back transposed, replicated in the column blocks
         }
         const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, (int)((int64_t)T * GSZ * 8), 0x00020000);
         const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)pw, 0, (int)((int64_t)T * PWSZ * 8), 0x00020000);
@@ -307,7 +343,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     for (int r = 0; r < 4; ++r) {
                         const int row = tile_row(lane, r);
                         P[r] = hs * P[r] + dw * dgN[r];
-                        if (col == M && row < NX) W2[r] = dlT[row];
+                        if constexpr (AUG) {               // P~_T = [hxx g; g' 0], g = h_x(x_T) - lambda_T
+                            if (col == NX && row < NX) P[r] = dlT[row];
+                            if (row == NX && col < NX) P[r] = dlT[col];
+                        } else if (col == M && row < NX) W2[r] = dlT[row];
                     }
                 }
                 int tl = cnt - 1;
@@ -320,22 +359,39 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 d4 Fa = read3<NRT>(rF, RB), Ya = read3<NRT>(rY, RB), Fb = z, Yb = z;
                 auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                     const int t = t0 + tl;
-                    d4 Hxx = read3<NRT>(rHxx, imm), HX2 = read3<NRT>(rHX, imm), HU2 = read3<1>(rHU, imm), Grep = read3<NRT>(rGr, imm), Hux = read3<1>(rHux, imm);
+                    d4 Hxx = read3<NRT>(rHxx, imm), HX2 = z, HU2 = read3<1>(rHU, imm), Grep = read3<NRT>(rGr, imm), Hux = read3<1>(rHux, imm);
+                    if constexpr (!AUG) HX2 = read3<NRT>(rHX, imm);
                     if (tl > 0) { Fn = read3<NRT>(rF, imm - RB); Yn = read3<NRT>(rY, imm - RB); }
-                    d4 Ys = Yc;
+                    d4 Ys = Yc, Fs = Fc;
                     double Hux0 = Hux[0];
                     if (scaled) {
+                        if constexpr (AUG) {               // Hessian blocks x hs (+ dw I), the gradient row / column and the 1 of F~ as they are, the defect column x hs
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const bool blk_ = tile_row(lane, r) < NX && col < NX;
+                                Hxx[r] = blk_ ? hs * Hxx[r] + dw * dgN[r] : Hxx[r];
+                                Fs[r] = (col == NX && tile_row(lane, r) < NX) ? hs * Fc[r] : Fc[r];
+                            }
+                            HU2[0] = hs * HU2[0] + dw * dgM0[0];
+                            Hux0 = col < NX ? hs * Hux0 : Hux0;
+                        } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { Hxx[r] = hs * Hxx[r] + dw * dgN[r]; HX2[r] *= sU; }
                         HU2[0] = sU * HU2[0] + dw * dgM0[0];
                         Ys = Yc * sC;
                         Hux0 = hs * Hux0;
+                        }
                     }
                     // P_{t+1}, W_{t+1}: the evaluator's multiplier step needs them (dlam_t = P_{t+1} dx_{t+1} + W_{t+1})
                     const unsigned soP = (unsigned)(t * PWSZ) * 8u, soG = (unsigned)(t * GSZ) * 8u;
                     buf_store<NRT>(rsP, soP, mP, P);
-                    buf_store<NRT>(rsP, soP, mW, W2);
-                    if constexpr (SMALL) {
+                    if constexpr (!AUG) buf_store<NRT>(rsP, soP, mW, W2);
+                    if constexpr (AUG) {
+                        RiccatiGains gn;
+                        ok = riccati_backward_aug<M, true>(P, Fs, Ys, Grep, Hxx, HU2[0], Hux0, scratch, lane, gn) && ok;
+                        pdall = pdall && gn.pd;
+                        buf_store<1>(rsG, soG, mK, gn.K);
+                    } else if constexpr (SMALL) {
                         SmallGains gs;
                         double Pr = P[0], Wr = W2[0];
                         ok = riccati_small_backward<M>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, gs) && ok;
@@ -377,7 +433,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         auto forward = [&](double hs) -> double {
             Gather3 gFT, gGT, gE, gRX, gRU;
             make_gather3(gFT, lane, L::CF0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::solf_code(0, (c & 3) * NX + r) : -1)
-                                                                          : ((r < NX && c < NX) ? Mdl::solf_code(0, c * NX + r) : -1); });
+                                                                          : ((r < NX && c < NX) ? Mdl::solf_code(0, c * NX + r)
+                                                                             : (AUG && r == NX && c < NX ? L::FC0 + c : (AUG && r == NX && c == NX ? L::ONEF : -1))); });      // F~' = [F' 0; c' 1]
             make_gather3(gGT, lane, L::CF0, [](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? Mdl::solf_code(1, (c & 3) * NU + r) : -1)
                                                                           : ((r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1); });
             make_gather3(gE, lane, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
@@ -395,15 +452,29 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             struct Gn { d4 KT, k; };
             // (loaded as stored, +K and +k: a negation right behind the load would make the step wait for the loads it has just issued; the sign is
             // absorbed in the products below: V = K x + k = -du, dx+ = F dx + c - G V)
-            auto ldg = [&](int t) { const int tt = t < T ? t : T - 1; Gn s; const unsigned so = (unsigned)(tt * GSZ) * 8u; s.KT = buf_load<NRT>(rsG, so, mKT); s.k = buf_load<1>(rsG, so, mIK); return s; };
+            auto ldg = [&](int t) {
+                const int tt = t < T ? t : T - 1;
+                Gn s;
+                const unsigned so = (unsigned)(tt * GSZ) * 8u;
+                s.KT = buf_load<NRT>(rsG, so, mKT);
+                s.k = z;
+                if constexpr (!AUG) s.k = buf_load<1>(rsG, so, mIK);
+                return s;
+            };
             Gn A = ldg(0), Bn = ldg(1), Cn;
             Cn.KT = z; Cn.k = z;
             d4 X2 = z, Xb = z;
+            if constexpr (AUG) {                            // x~_0 = [dx_0 = 0; 1] in column M
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X2[r] = (col == M && tile_row(lane, r) == NX) ? 1.0 : 0.0;
+            }
             double acc = 0.0;
             const bool scaledE = hs != 1.0;
             constexpr int RF = 8 * FS;
             for (int c = 0; c < nchunkF && !dead; ++c) {
-                const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0);
+                const int g = nchunk + c;
+                int t0, cnt;
+                fchunk(c, t0, cnt);
                 const double* pb = pool + (g & 1) * L::BUF;
                 MS2_T0();
                 if (!ms2_wait_ge(ctl + MS2_PROD, g + 1, ctl)) { dead = true; break; }
@@ -415,10 +486,16 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     fill = ldg(t + 2);
                     d4 FT = read3<NRT>(rFT, imm);
                     d4 GT = read3<1>(rGT, imm);
-                    d4 E2 = read3<NRT>(rE, imm);
+                    d4 E2 = z;
+                    if constexpr (!AUG) E2 = read3<NRT>(rE, imm);
                     d4 RXn = read3<NRT>(rRX, imm);
                     d4 RUc = read3<1>(rRU, imm);
-                    if (scaledE) E2 = E2 * hs;
+                    if (scaledE) {
+                        if constexpr (AUG) {                // the defect sits in row NX of F~'
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) FT[r] = (tile_row(lane, r) == NX && col < NX) ? hs * FT[r] : FT[r];
+                        } else E2 = E2 * hs;
+                    }
                     d4 U2 = z;
                     if constexpr (SMALL) {
                         Xn = z;
@@ -429,8 +506,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         acc += RXn[0] * x1 + RUc[0] * U2[0];
                     } else {
                         d4 V = z;
-                        V[0] = mma4_tn(cur.KT, Xc, cur.k[0]);
-                        Xn = mma_tn(FT, Xc, E2);
+                        V[0] = mma4_tn(cur.KT, Xc, AUG ? 0.0 : cur.k[0]);      // K~ x~ = K dx + k
+                        Xn = mma_tn(FT, Xc, AUG ? z : E2);                     // F~ x~ = [F dx + c; 1]
                         Xn = mms_tn_r0(GT, V, Xn);
                         U2[0] = -V[0];
                         acc += RXn[0] * Xn[0] + RXn[1] * Xn[1] + RXn[2] * Xn[2] + RXn[3] * Xn[3] + RUc[0] * U2[0];
@@ -609,7 +686,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             const bool have = gains_ok && conv && !dead;
             for (int q = lane; q < T * G2; q += 64) {
                 const int t = q / G2, r = q - t * G2;
-                go[q] = !have ? 0.0 : (r < NX * NU ? gw[t * GSZ + (r % NU) * NX + r / NU] : gw[t * GSZ + r]);
+                go[q] = !have ? 0.0 : (r < NX * NU ? gw[t * GSZ + L::gK(r % NU, r / NU)] : gw[t * GSZ + L::gk(r - NX * NU)]);
             }
             if (!have) st |= PDP_MS_NOGAINS;
         }
@@ -719,50 +796,98 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 res[MS2_FIN] = fin_all ? 1.0 : 0.0;
             }
         };
-        // multiplier step of the stages [t0, t0 + cnt): dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (PDP.py:604), lane = stage
+        // multiplier step of the stages [t0, t0 + cnt): dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (PDP.py:604), lane = stage.  `pp`: the stage's (P, W) record,
+        // `d`: dx_{t+1}.  Small systems: the full matrix; else the upper triangle row by row, in batches of rows whose loads are all requested before the
+        // first FMA that needs one; element (j, k), k >= j, serves acc[j] and, off the diagonal, acc[k].
+        auto dlam_row = [&](const double* pp, const double (&d)[NX], double (&acc)[NX]) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = pp[L::pW(i)];
+            if constexpr (SMALL) {
+                double pv[NX * NX];
+#pragma unroll
+                for (int k = 0; k < NX * NX; ++k) pv[k] = pp[k];
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) acc[i] = fma(pv[i * NX + j], d[j], acc[i]);
+            } else {
+                constexpr int RB_ = 4;
+#pragma unroll
+                for (int j0 = 0; j0 < NX; j0 += RB_) {
+                    double pv[RB_][NX];
+#pragma unroll
+                    for (int jj = 0; jj < RB_; ++jj)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) pv[jj][k] = (j0 + jj < NX && k >= j0 + jj) ? pp[L::pk(j0 + jj < NX ? j0 + jj : 0, k)] : 0.0;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int jj = 0; jj < RB_; ++jj)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k)
+                            if (j0 + jj < NX && k >= j0 + jj) {
+                                const int j = j0 + jj;
+                                acc[j] = fma(pv[jj][k], d[k], acc[j]);
+                                if (k != j) acc[k] = fma(pv[jj][k], d[j], acc[k]);
+                            }
+                }
+            }
+        };
+        // route 1 (batches that leave the memory system idle): every lane reads its stage's record straight from the workspace
         auto dlam_chunk = [&](int t0, int cnt) {
             if (lane < cnt) {
                 const int t = t0 + lane;
                 const unsigned o8 = 8u * (unsigned)t;
-                const double* pp = pw + (int64_t)t * PWSZ;
                 double d[NX], acc[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { d[i] = sm_ld(stp + i * TS, o8 + 8u); acc[i] = pp[PSZ + i]; }
-                if constexpr (SMALL) {
-                    double pv[NX * NX];
-#pragma unroll
-                    for (int k = 0; k < NX * NX; ++k) pv[k] = pp[k];
-#pragma unroll
-                    for (int j = 0; j < NX; ++j)
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) acc[i] = fma(pv[i * NX + j], d[j], acc[i]);
-                } else {
-                    // the upper triangle row by row, in batches of rows whose loads are all requested before the first FMA that needs one (interleaved,
-                    // the pass makes a trip to memory per handful of FMAs); element (j, k), k >= j, serves acc[j] and, off the diagonal, acc[k]
-                    constexpr int RB_ = 4;
-#pragma unroll
-                    for (int j0 = 0; j0 < NX; j0 += RB_) {
-                        double pv[RB_][NX];
-#pragma unroll
-                        for (int jj = 0; jj < RB_; ++jj)
-#pragma unroll
-                            for (int k = 0; k < NX; ++k) pv[jj][k] = (j0 + jj < NX && k >= j0 + jj) ? pp[L::pk(j0 + jj < NX ? j0 + jj : 0, k)] : 0.0;
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int jj = 0; jj < RB_; ++jj)
-#pragma unroll
-                            for (int k = 0; k < NX; ++k)
-                                if (j0 + jj < NX && k >= j0 + jj) {
-                                    const int j = j0 + jj;
-                                    acc[j] = fma(pv[jj][k], d[k], acc[j]);
-                                    if (k != j) acc[k] = fma(pv[jj][k], d[j], acc[k]);
-                                }
-                    }
-                }
+                for (int i = 0; i < NX; ++i) d[i] = sm_ld(stp + i * TS, o8 + 8u);
+                dlam_row(pw + (int64_t)t * PWSZ, d, acc);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) sm_st(stp + OL + i * TS, o8, acc[i]);
             }
         };
+        // route 2 (four trajectories per CU): the records of a block of stages are contiguous in the workspace - they are copied into a free pool buffer
+        // with coalesced loads (64 consecutive doubles per wave instruction) and read from LDS by the lane of their stage.  Straight from the workspace every
+        // lane sits in its own 840-byte record: 25 lanes x 105 loads = 2600 cache-line requests per chunk and trajectory, which at four trajectories per
+        // CU kept the address unit busy for ~17 k cycles per chunk (profiles/r03_ms2_phase_timing_v2.txt) - and slowed the runner's own loads beside it.
+        auto dlam_staged = [&](int t0, int cnt, double* sbuf, auto cap_tag) {
+            constexpr int CAP = decltype(cap_tag)::value;             // doubles of LDS at sbuf
+            constexpr int PSTR = PWSZ | 1;                            // odd record stride in LDS (bank spread over the lanes of a block)
+            constexpr int NBMAX = CAP / (PSTR + NX) < 64 ? CAP / (PSTR + NX) : 64;
+            constexpr int NQ = (NBMAX * PWSZ + 63) / 64, NQD = (NBMAX * NX + 63) / 64;      // loads per lane: EVERY load of a block is in flight before the first LDS store
+            const int nblk = (cnt + NBMAX - 1) / NBMAX, nb0 = (cnt + nblk - 1) / nblk;
+            double* dl = sbuf + NBMAX * PSTR;
+            for (int s0 = 0; s0 < cnt; s0 += nb0) {
+                const int nb = min(nb0, cnt - s0), n = nb * PWSZ, nd = nb * NX;
+                const double* src = pw + (int64_t)(t0 + s0) * PWSZ;
+                wave_lds_sync();
+                double v[NQ], w[NQD];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { const int idx = lane + 64 * q; v[q] = src[idx < n ? idx : 0]; }
+#pragma unroll
+                for (int q = 0; q < NQD; ++q) { const int k = lane + 64 * q, kk = k < nd ? k : 0, j = kk / nb, sidx = kk - j * nb; w[q] = stp[j * TS + t0 + s0 + sidx + 1]; }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int idx = lane + 64 * q;
+                    if (idx < n) { if constexpr (PSTR == PWSZ) sbuf[idx] = v[q]; else sbuf[(idx / PWSZ) * PSTR + idx % PWSZ] = v[q]; }
+                }
+#pragma unroll
+                for (int q = 0; q < NQD; ++q) { const int k = lane + 64 * q; if (k < nd) { const int j = k / nb, sidx = k - j * nb; dl[sidx * NX + j] = w[q]; } }
+                wave_lds_sync();
+                if (lane < nb) {
+                    const unsigned o8 = 8u * (unsigned)(t0 + s0 + lane);
+                    double d[NX], acc[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) d[i] = dl[lane * NX + i];
+                    dlam_row(sbuf + lane * PSTR, d, acc);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) sm_st(stp + OL + i * TS, o8, acc[i]);
+                }
+            }
+            wave_lds_sync();
+        };
+        using Cap1 = std::integral_constant<int, L::BUF>;
+        using Cap2 = std::integral_constant<int, 2 * L::BUF>;
         for (;;) {
             if (!ms2_wait_ge(ctl + MS2_SEQ, last + 1, ctl)) break;
             last = ms2_load(ctl + MS2_SEQ);
@@ -830,6 +955,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         PackedSink s{row};
                         Mdl::eval_sol(xc, uc, lc, th, pc, s);
                         row[L::CB0] = 0.0;
+                        row[L::ONEB] = 1.0;
 #pragma unroll
                         for (int i = 0; i < Mdl::SOL_NCONST; ++i) row[L::CB0 + 1 + i] = Mdl::sol_const(i);
                     }
@@ -838,7 +964,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 }
                 // forward chunks: F', G', the defect and the gradients the directional derivative needs; behind each consumed chunk the multiplier step
                 for (int c = 0; c < nchunkF && !stop(); ++c) {
-                    const int g = nchunk + c, t0 = c * chF, cnt = min(chF, T - t0);
+                    const int g = nchunk + c;
+                    int t0, cnt;
+                    fchunk(c, t0, cnt);
                     if (g >= 2) {
                         bool freed = false;
                         int n = 0;
@@ -865,6 +993,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         PackedSink s{row};
                         Mdl::eval_solf(xc, uc, nullptr, th, pc, s);
                         row[L::CF0] = 0.0;
+                        row[L::ONEF] = 1.0;
 #pragma unroll
                         for (int i = 0; i < Mdl::SOLF_NCONST; ++i) row[L::CF0 + 1 + i] = Mdl::solf_const(i);
                     }
@@ -876,7 +1005,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         while (!(got = ms2_load(ctl + MS2_CONS) >= g) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!got) break;
                         MS2_E1(6);
-                        dlam_chunk((c - 1) * chF, min(chF, T - (c - 1) * chF));
+                        // (the consumed chunk's buffer is free until chunk c + 1 is evaluated)
+                        int tp, cp_;
+                        fchunk(c - 1, tp, cp_);
+                        if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool + ((g - 1) & 1) * L::BUF, Cap1{});
+                        else dlam_chunk(tp, cp_);
                         MS2_E1(4);
                     }
                 }
@@ -885,7 +1018,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     int n = 0;
                     while (!(got = ms2_load(ctl + MS2_CONS) >= nchunk + nchunkF) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                     MS2_E1(6);
-                    if (got) dlam_chunk((nchunkF - 1) * chF, min(chF, T - (nchunkF - 1) * chF));
+                    if (got) {          // the last chunk: both pool buffers are free - its records in ONE block, one trip to memory
+                        int tp, cp_;
+                        fchunk(nchunkF - 1, tp, cp_);
+                        if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool, Cap2{});
+                        else dlam_chunk(tp, cp_);
+                    }
                 }
                 __threadfence_block();
                 MS2_E1(4);

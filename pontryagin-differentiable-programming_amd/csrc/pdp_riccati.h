@@ -188,6 +188,91 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     return ok;
 }
 
+// Homogeneous form of the backward step for a problem with ONE affine column (the Newton step of the multiple-shooting OC solver): the state is augmented
+// by a constant 1, x~ = [dx; 1] (n + 1 <= 16), so that the affine terms ride inside the tiles -
+//     F~ = [F c; 0 1]   G~ = [G; 0]   Hxx~ = [Hxx rx; rx' 0]   Hux~ = [Hxu' | ru]   P~ = [P W; W' s]
+// and the step is the plain Riccati step of a purely quadratic problem (same algebra as riccati_backward, K~ = [K | k], P~- = Hxx~ + F~'P~F~ - Qux~'K~,
+// whose (x, 1) block is W- = rx + F'(P c + W) - Qux' k): no separate W recursion, no [G | c] / [Hxu | rx] / [Huu | ru] packing, 13 full-tile and 9
+// four-row MFMAs instead of 18 and 10.  The (1, 1) element of P~ carries the constant of the cost-to-go (never used).
+// Ft = F~ tile, Y = G~ tile (columns < M), Grep = G~ replicated in the four column blocks, HU0 = Huu (rows < M), Hux0 = Hux~ (rows < M, n + 1 columns).
+template <int M, bool WANT_PD = true>
+PDP_DEV bool riccati_backward_aug(d4& P, const d4 Ft, const d4 Y, const d4 Grep, const d4 Hxx, const double HU0, const double Hux0, double* scratch, int lane,
+                                  RiccatiGains& g) {
+    const d4 z = zero4();
+    d4 PF = mma_tn(P, Ft, z);             // P~ F~      (P~ symmetric)
+    d4 PG = mma_tn(P, Y, z);              // P~ G~
+    d4 Q2 = z;
+    Q2[0] = mma4_tn(Grep, PG, HU0);       // Quu = Huu + G'PG   (m x m)
+    d4 Qux = z;
+    Qux[0] = mma4_tn(Grep, PF, Hux0);     // Qux~ = Hux~ + G~'P~F~   (m x (n + 1)): [Qux | Que]
+    d4 Pn = mma_tn(Ft, PF, Hxx);          // Hxx~ + F~'P~F~
+    const int row = lane >> 4, col = lane & 15;
+    double Zrep = 0.0;                    // Quu^-T replicated in every 4-column block
+    bool ok = true;
+    if constexpr (M == 4) {               // lane-parallel cofactor inverse (see riccati_backward)
+        scratch[544 + lane] = Q2[0];
+        wave_lds_sync();
+        const int i = row, j = col & 3;
+        const int r0 = (i == 0) ? 1 : 0, r1 = (i <= 1) ? 2 : 1, r2 = (i <= 2) ? 3 : 2;
+        const int c0 = (j == 0) ? 1 : 0, c1 = (j <= 1) ? 2 : 1, c2 = (j <= 2) ? 3 : 2;
+        const double* q = scratch + 544;
+        const double m00 = q[r0 * 16 + c0], m01 = q[r0 * 16 + c1], m02 = q[r0 * 16 + c2];
+        const double m10 = q[r1 * 16 + c0], m11 = q[r1 * 16 + c1], m12 = q[r1 * 16 + c2];
+        const double m20 = q[r2 * 16 + c0], m21 = q[r2 * 16 + c1], m22 = q[r2 * 16 + c2];
+        double cof = m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+        cof = ((i + j) & 1) ? -cof : cof;
+        const double ac = Q2[0] * cof;
+        const double t0 = readlane_f64(ac, 0), t1 = readlane_f64(ac, 1), t2 = readlane_f64(ac, 2), t3 = readlane_f64(ac, 3);
+        const double det = (t0 + t1) + (t2 + t3), mag = (fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3));
+        if constexpr (WANT_PD) {
+            const double a00 = readlane_f64(Q2[0], 0), a01 = readlane_f64(Q2[0], 1), a10 = readlane_f64(Q2[0], 16), a11 = readlane_f64(Q2[0], 17);
+            g.pd = a00 > 0.0 && a00 * a11 - a01 * a10 > 0.0 && readlane_f64(cof, 51) > 0.0 && det > 0.0;
+        }
+        if (fabs(det) > 1e-10 * mag && fabs(det) <= 1.7e308) {
+            double rdet = __builtin_amdgcn_rcp(det);
+            rdet = fma(fma(-det, rdet, 1.0), rdet, rdet);
+            Zrep = cof * rdet;
+        } else {
+            double a[16], ai[16];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) a[ii * 4 + jj] = readlane_f64(Q2[0], 16 * ii + jj);
+            ok = inverse_small<4>(a, ai);
+            double zz = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) zz = (row == ii && (col & 3) == jj) ? ai[jj * 4 + ii] : zz;
+            Zrep = zz;
+        }
+    } else {
+        double a[M * M], ai[M * M];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) a[i * M + j] = readlane_f64(Q2[0], 16 * i + j);
+        ok = inverse_small_fast<M>(a, ai);
+        if constexpr (WANT_PD) g.pd = posdef_small<M>(a);
+        double zz = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) zz = (row == i && (col & 3) == j) ? ai[j * M + i] : zz;
+        Zrep = zz;
+    }
+    d4 K = z;
+    K[0] = mma4_blk(Zrep, Qux[0], 0.0);   // [K | k] = Quu^-1 Qux~
+    g.K = K;
+    g.Zrep = Zrep;
+    g.Qux = Qux;
+    P = mms_tn_r0(Qux, K, Pn);            // Hxx~ + F~'P~F~ - Qux~'K~
+    tile_to_lds17(scratch + 272, P, lane);
+    wave_lds_sync();
+    P = 0.5 * (P + tile_from_lds17_transposed(scratch + 272, lane));
+    return ok;
+}
+
 // Extra parameter tile j >= 1 (16 columns of E / Hxe / Hue / W, unshifted).  P_old = P before the update.
 PDP_DEV void riccati_backward_extra(const d4 P_old, d4& Wj, const d4 Ft, const d4 Grep, const d4 Ej, const d4 Hxej, const d4 Huej,
                                     const RiccatiGains& g, d4& kj) {
