@@ -170,14 +170,14 @@ class OCSys:
     # ---- PDP.py:121-220 ----------------------------------------------------------------------------------------
     def ocSolver(self, ini_state, horizon, auxvar_value=1, print_level=0, costate_option=0):
         """Reference: multiple-shooting NLP from an all-zero guess, solved by IPOPT.  Here: the same NLP and the same iteration
-        (Newton-KKT step, inertia correction, filter line search) inside one GPU kernel (ocsolver.py, csrc/pdp_ocsolve_kernels.h);
+        (Newton-KKT step, inertia correction, filter line search) inside one GPU kernel (ocsolver.py, csrc/pdp_ocsolve2_kernels.h);
         returns the reference's dict (state_traj_opt, control_traj_opt, costate_traj_opt, auxvar_value, time, horizon, cost).
-        Finite state / control bounds (which the reference passes to IPOPT as lbw / ubw, PDP.py:141-168) are not supported and
-        raise; a solve that did not converge warns (the reference prints IPOPT's exit status instead)."""
+        Finite state / control bounds (which the reference passes to IPOPT as lbw / ubw, PDP.py:141-168) are handled by a log-barrier
+        continuation around the same kernel (ocsolver.solve_batch_bounded); a solve that did not converge warns (the reference prints
+        IPOPT's exit status instead)."""
         from . import ocsolver
         self._require()
-        self._check_unbounded()
-        sol = ocsolver.solve_batch(self, np.asarray(_vec(ini_state))[None], int(horizon), auxvar_value, print_level=print_level)
+        sol = self.ocSolver_batch(np.asarray(_vec(ini_state))[None], int(horizon), auxvar_value, print_level=print_level)
         if not bool(sol["converged"][0]):
             import warnings
             warnings.warn("ocSolver: no convergence (|grad| = %.3e); the returned trajectory is the last iterate" % float(sol["grad_norm"][0]), RuntimeWarning)
@@ -187,21 +187,43 @@ class OCSys:
         return {"state_traj_opt": x, "control_traj_opt": u, "costate_traj_opt": lam, "auxvar_value": auxvar_value,
                 "time": numpy.array([k for k in range(horizon + 1)]), "horizon": horizon, "cost": np.array([[float(sol["cost"][0])]])}
 
-
     def ocSolver_batch(self, ini_state, horizon, auxvar_value, **kwargs):
         """ocSolver for a batch: ini_state [B,n], auxvar_value [p] or [B,p] -> dict of CUDA tensors state [B,T+1,n], control [B,T,m],
-        costate [B,T,n], cost [B], converged [B], ... (ocsolver.solve_batch; kwargs: u_init, warm_start, want_gains, tol, max_iter)"""
+        costate [B,T,n], cost [B], converged [B], ... (ocsolver.solve_batch; kwargs: u_init, warm_start, want_gains, tol, max_iter).
+        With finite bounds: ocsolver.solve_batch_bounded (kwargs: tol, max_iter, print_level)."""
         from . import ocsolver
         self._require()
-        self._check_unbounded()
+        if self.has_bounds():
+            kw = {k: v for k, v in kwargs.items() if k in ("tol", "max_iter", "print_level")}
+            return ocsolver.solve_batch_bounded(self, ini_state, int(horizon), auxvar_value, **kw)
         return ocsolver.solve_batch(self, ini_state, int(horizon), auxvar_value, **kwargs)
 
-    def _check_unbounded(self):
-        """the batched solvers handle the equality-constrained NLP only; +-1e20 (the reference's defaults) means "no bound" to IPOPT too"""
-        for nm in ("state_lb", "state_ub", "control_lb", "control_ub"):
-            v = getattr(self, nm, None)
-            if v is not None and any(abs(float(b)) < 1e19 for b in v):
-                raise NotImplementedError("OCSys.ocSolver: finite %s is not supported by the GPU solvers (the reference hands bounds to IPOPT)" % nm)
+    def has_bounds(self):
+        """any finite state / control bound?  (+-1e20, the reference's defaults, mean "none" - to IPOPT too)"""
+        return any(abs(float(b)) < 1e19 for nm in ("state_lb", "state_ub", "control_lb", "control_ub") for b in getattr(self, nm, []))
+
+    def barrier_model(self):
+        """The device model of the log-barrier sub-problem  min sum_t [c + mu b(x_t, u_t)] + h + mu b(x_T)  s.t. the dynamics:  auxvar = [theta ; mu],
+        b = - sum_i log(v_i - lb_i) - sum_i log(ub_i - v_i) over the finitely bounded components of the state and the control (x_0 is fixed: its term
+        is a constant).  Built by the symbolic front-end like any other cost: the kernels see one more generated model."""
+        if getattr(self, "_bar_model", None) is None:
+            mu = SX.sym("mu_barrier")
+
+            def bar(v, lb, ub):
+                b = 0
+                for i in range(len(lb)):
+                    if abs(float(lb[i])) < 1e19:
+                        b = b - sx.log(v[i] - float(lb[i]))
+                    if abs(float(ub[i])) < 1e19:
+                        b = b - sx.log(float(ub[i]) - v[i])
+                return b
+            bx = bar(self.state, self.state_lb, self.state_ub)
+            pb = codegen.Problem(codegen.KIND_OC, self.state, self.control, self.dyn, sx.vertcat(self.auxvar, mu),
+                                 self.path_cost + mu * (bar(self.control, self.control_lb, self.control_ub) + bx), self.final_cost + mu * bx,
+                                 label=_label(self.project_name) + "_bar")
+            lib, _ = codegen.build_problem(pb)
+            self._bar_model = runtime.load_model(lib)
+        return self._bar_model
 
 
 def _label(name):

@@ -173,3 +173,66 @@ def solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=Non
             sol[k][idx] = sub[k][better]
         sol["iterations"] += don["iterations"] + sub["iterations"] + 2         # sequential iterations executed, retries included
     return sol
+
+
+def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter=300, print_level=0, mu0=0.1):
+    """ocSolver with finite state / control bounds (the reference hands them to IPOPT as lbw / ubw, PDP/PDP.py:141-168).
+
+    Log-barrier continuation around the equality-constrained multiple-shooting kernel: for mu = 0.1, then mu <- max(mu_min, min(0.2 mu, mu^1.5))
+    (IPOPT's monotone barrier schedule, kappa_mu = 0.2, theta_mu = 1.5) the sub-problem  min sum [c + mu b] + h  s.t. the dynamics  - b the log barrier
+    of the bounds, part of the generated cost (OCSys.barrier_model: the symbolic front-end differentiates it like any cost term) - is solved by
+    pdp_oc_solve_ms_batched, warm-started from the previous mu.  The filter line search keeps the iterates strictly inside the bounds by itself: a
+    trial point outside makes the objective non-finite and is rejected (the step is halved).  The first sub-problem starts from IPOPT's starting point:
+    the all-zero guess pushed into the interior (bound_push = bound_frac = 1e-2).  This is the classical primal barrier method (Fiacco & McCormick),
+    not IPOPT's primal-dual iteration: the same solution (to O(mu_min) = tol / 10), a different path to it.  Returns the dict of solve_batch
+    (cost = the ORIGINAL objective along the returned trajectory; costate = multipliers of the dynamics = IPOPT's lam_g)."""
+    torch = runtime.torch_cuda()
+    mdl = oc.model()
+    n, m, T = mdl.n, mdl.m, int(horizon)
+    assert n <= 16 and m <= 4, "bounded ocSolver: the multiple-shooting kernel serves n <= 16, m <= 4"
+    x0 = runtime.dev(ini_state).reshape(-1, n)
+    B = x0.shape[0]
+    th = np.asarray(oc._theta(auxvar_value, B), dtype=np.float64).reshape(-1, oc.n_auxvar)
+    lbx, ubx = np.asarray(oc.state_lb, float), np.asarray(oc.state_ub, float)
+    lbu, ubu = np.asarray(oc.control_lb, float), np.asarray(oc.control_ub, float)
+    x0n = x0.cpu().numpy()
+    if bool(((x0n <= lbx[None]) | (x0n >= ubx[None])).any()):
+        # the reference's NLP does not apply the state bounds to x_0 (PDP.py:144-146), so IPOPT would accept this; a barrier method needs a starting
+        # trajectory strictly inside the bounds, which an x_0 outside them does not give for free
+        raise NotImplementedError("bounded ocSolver: an initial state on or outside the state bounds is not supported")
+    bar = oc.barrier_model()
+
+    def push(z, lb, ub):                    # IPOPT's projection of the starting point into the interior of [lb, ub]
+        lo = np.where(np.abs(lb) < 1e19, lb + np.minimum(1e-2 * np.maximum(1.0, np.abs(lb)), 1e-2 * (ub - lb)), -np.inf)
+        hi = np.where(np.abs(ub) < 1e19, ub - np.minimum(1e-2 * np.maximum(1.0, np.abs(ub)), 1e-2 * (ub - lb)), np.inf)
+        return np.minimum(np.maximum(z, lo), hi)
+    xg = np.tile(push(np.zeros(n), lbx, ubx), (B, T + 1, 1))
+    xg[:, 0] = x0n
+    ug = np.tile(push(np.zeros(m), lbu, ubu), (B, T, 1))
+    warm = (runtime.dev(xg), runtime.dev(ug), torch.zeros((B, T, n), dtype=torch.float64, device="cuda"))
+    mu_min, mu, iters = max(0.1 * tol, 1e-9), float(mu0), 0
+    accepted = None
+    while True:
+        th2 = np.concatenate([np.broadcast_to(th, (B if th.shape[0] == B else 1, th.shape[1])), np.full((B if th.shape[0] == B else 1, 1), mu)], axis=1)
+        sub_tol = max(0.1 * tol, min(1e-4, mu))           # sub-problems only as accurately as their mu deserves (IPOPT: E_mu <= 10 mu)
+        ms = bar.oc_solve_ms(x0, th2 if th2.shape[0] == B and B > 1 else th2[0], T, tol=sub_tol, max_iter=max_iter, warm=warm)
+        iters += int(ms["iterations"].max())
+        # A sub-problem counts as solved when the kernel says so, or when its line search has nothing left to gain at a feasible point whose stationarity
+        # residual is at the floor this method has in fp64: the barrier gradient mu / (bound - v) is formed from a slack that cancels (v within mu / z of
+        # its bound: relative error eps |bound| z / mu in the slack), so below mu ~ 1e-7 the residual stalls around 1e-6 - 1e-5 (IPOPT carries the bound
+        # multipliers as variables of their own and does not have that floor; the trajectory itself keeps converging: cost and controls agree with an
+        # independent solution to 1e-9 / 1e-6, tests/test_gpu_ocsolver.py)
+        lam_scale = 1.0 + ms["costate"].abs().amax(dim=(1, 2))
+        x_scale = 1.0 + torch.maximum(ms["state"].abs().amax(dim=(1, 2)), ms["control"].abs().amax(dim=(1, 2)))
+        floor_ok = (ms["resid"][:, 0] <= tol * x_scale) & (ms["resid"][:, 1] <= 1e-4 * lam_scale) & torch.isfinite(ms["cost"])
+        accepted = ms["converged"] | (floor_ok & (mu < 1e-6))
+        if print_level > 0:
+            print("  barrier mu = %.2e: %d/%d converged (%d accepted), max %d iterations" % (mu, int(ms["converged"].sum()), B, int(accepted.sum()), int(ms["iterations"].max())))
+        warm = (ms["state"], ms["control"], ms["costate"])
+        if mu <= mu_min:
+            break
+        mu = max(mu_min, min(0.2 * mu, mu ** 1.5))
+    xr, cost = mdl.oc_rollout(x0, ms["control"], oc._theta(auxvar_value, B))
+    feas = (xr - ms["state"]).abs().amax(dim=(1, 2)) <= 1e3 * tol * (1 + ms["state"].abs().amax(dim=(1, 2)))
+    return {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": cost, "grad_norm": ms["resid"][:, 1].contiguous(),
+            "converged": accepted & feas, "iterations": iters, "method_ms": ms["converged"].clone(), "status": ms["status"], "barrier_mu": mu}

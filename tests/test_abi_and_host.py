@@ -156,9 +156,9 @@ def test_sx_casadi_semantics():
     assert float(sx.inv(sx.SX(np.array([[2.0, 0.0], [0.0, 4.0]])))[1, 1]) == 0.25
 
 
-def test_ocsolver_rejects_finite_bounds_and_new_entry_points_validate_arguments(built):
-    """(i) the reference passes state / control bounds to IPOPT as lbw / ubw (PDP.py:141-168); the GPU solvers handle the equality-
-    constrained NLP only, so finite bounds raise instead of being silently ignored (the +-1e20 defaults mean "none", as for IPOPT);
+def test_ocsolver_recognises_finite_bounds_and_new_entry_points_validate_arguments(built):
+    """(i) the reference passes state / control bounds to IPOPT as lbw / ubw (PDP.py:141-168): finite bounds are recognised (the +-1e20 defaults mean
+    "none", as for IPOPT) and routed to the barrier continuation (tests/test_gpu_ocsolver.py solves a bounded problem on the GPU);
     (ii) pdp_oc_solve_ms_batched / its workspace entry point are host-side and validate their arguments without a GPU."""
     from pdp_amd import PDP, runtime, zoo
     from pdp_amd.sx import SX, vertcat
@@ -170,10 +170,9 @@ def test_ocsolver_rejects_finite_bounds_and_new_entry_points_validate_arguments(
     oc.setDyn(x + 0.1 * vertcat(x[1], u))
     oc.setPathCost(w * (x[0] * x[0] + u * u))
     oc.setFinalCost(x[0] * x[0])
-    with pytest.raises(NotImplementedError, match="control_lb"):
-        oc.ocSolver([1.0, 0.0], 5, [1.0])
+    assert oc.has_bounds()
     oc.setControlVariable(u)                      # defaults: +-1e20
-    oc._check_unbounded()
+    assert not oc.has_bounds()
     lib, info = built[0].build_problem(zoo.make_problem("pendulum", "irl"))
     m = runtime.ModelLib(lib)
     B, T = 7, 30

@@ -196,3 +196,46 @@ def test_ms_kernel_warm_start_gains_and_per_sample_parameters(golden_dir):
     _, _, J_cl = mdl.oc_rollout_feedback(xp, cold["control"], cold["state"], cold["gains"], torch.zeros((B,), dtype=torch.float64, device="cuda"), th)
     _, J_ol = mdl.oc_rollout(xp, cold["control"], th)
     assert bool((J_cl[ok] <= J_ol[ok] + 1e-9 * J_ol[ok].abs()).all())
+
+
+def test_oc_solver_with_state_and_control_bounds(golden_dir):
+    """OCSys.ocSolver with finite bounds (the reference passes them to IPOPT as lbw / ubw, PDP.py:141-168): pendulum swing-up with |u| <= 12 and dq <= 6,
+    both active.  Known answer: tests/golden/bounded_oc_pendulum.npz, the same problem solved by an independent method on the oracle's model (scipy SLSQP,
+    single shooting: make_bounded_oc.py; its own starts agree to 3e-8 in the cost).  Also: the bounds hold, the returned cost is the original objective
+    along the returned trajectory, the batch entry point with per-sample parameters; an initial state outside the state bounds is refused."""
+    from pdp_amd import PDP, zoo
+    from pdp_amd.sx import vertcat
+    g = load(golden_dir, "bounded_oc_pendulum.npz")
+    env, dt = zoo.make_env("pendulum", "irl")
+    umax, vmax, T = float(g["umax"]), float(g["vmax"]), int(g["T"])
+    oc = PDP.OCSys("pendulum bounded")
+    oc.setAuxvarVariable(vertcat(env.dyn_auxvar, env.cost_auxvar))
+    oc.setStateVariable(env.X, state_lb=[-1e20, -1e20], state_ub=[1e20, vmax])
+    oc.setControlVariable(env.U, control_lb=[-umax], control_ub=[umax])
+    oc.setDyn(env.X + dt * env.f)
+    oc.setPathCost(env.path_cost)
+    oc.setFinalCost(env.final_cost)
+    assert oc.has_bounds()
+    traj = oc.ocSolver(ini_state=g["x0"], horizon=T, auxvar_value=g["theta"])
+    x, u = traj["state_traj_opt"], traj["control_traj_opt"]
+    assert np.all(np.abs(u) <= umax) and np.all(x[1:, 1] <= vmax)
+    assert abs(float(np.asarray(traj["cost"]).squeeze()) - float(g["cost"])) <= 2e-7 * float(g["cost"])
+    assert np.abs(u - g["control"]).max() <= 2e-3 * umax and np.abs(x - g["state"]).max() <= 2e-3 * np.abs(g["state"]).max()
+    assert np.array_equal(np.abs(np.abs(u[:, 0]) - umax) < 1e-5, g["active_u"]) and np.array_equal(np.abs(x[1:, 1] - vmax) < 1e-5, g["active_v"])
+    # cost is the original objective of the rollout of the returned controls
+    xr, cr = oc.rollout_batch(g["x0"][None], u[None], g["theta"])
+    assert abs(float(cr[0]) - float(np.asarray(traj["cost"]).squeeze())) <= 1e-12 * float(cr[0]) and float(np.abs(xr[0].cpu().numpy() - x).max()) <= 1e-6
+    # batch with per-sample parameters and initial states
+    B = 3
+    th = g["theta"][None] * (1 + 0.05 * np.arange(B)[:, None])
+    x0 = np.tile(g["x0"], (B, 1))
+    x0[1, 1] = 2.0
+    x0[2, 0] = 0.3
+    sol = oc.ocSolver_batch(x0, T, th)
+    assert bool(sol["converged"].all())
+    xs, us = sol["state"].cpu().numpy(), sol["control"].cpu().numpy()
+    assert np.all(np.abs(us) <= umax) and np.all(xs[:, 1:, 1] <= vmax + 1e-9)
+    assert np.abs(us[0] - u).max() <= 1e-5 * umax
+    x0[1, 1] = vmax + 1.0
+    with pytest.raises(NotImplementedError, match="outside the state bounds"):
+        oc.ocSolver_batch(x0, T, th)
