@@ -528,7 +528,9 @@ def main():
                        "batch_per_gpu": B, "horizon": T,
                        "exchange": "all_gather([B,10] gradient|loss rows) over RCCL on a side stream, overlapped with the next step's kernel" if distributed else "none (1 GPU)"},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
+                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
+                                           "(probes/profile_bench.sh), not collected in this run", "kernel_ms": kern_ms,
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,
                                                                "frac": FLOP_PER_TRAJ_SCHUR * B / (kern_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

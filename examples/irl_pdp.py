@@ -6,7 +6,7 @@
                            loss, dp = aux system + Riccati + chain rule  (fused kernel)
                            theta_{k+1} = theta_k - lr * mean(dp)
 
-Demonstrations: the reference's stored demos (tests/golden/demos_<sys>.npz), or any `<name>_demos.mat` written by the reference's
+Demonstrations: the reference's stored demos (examples/data/demos_<sys>.npz, copies of the extracts under tests/golden), or any `<name>_demos.mat` written by the reference's
 generate_demos.py (field names trajectories[i].state_traj_opt / control_traj_opt, true_parameter, dt; e.g.
 Examples/IRL/cartpole/generate_demos.py:38-43) through --demos.  Results are saved with the reference's field names
 (results.loss_trace / parameter_trace / learning_rate / time_passed) so its plotting scripts keep working.
@@ -61,7 +61,7 @@ def main():
     oc.setFinalCost(env.final_cost)
     oc.diffPMP()
 
-    demo_x, demo_u, true_parameter = load_demos(a.demos or os.path.join(ROOT, "tests", "golden", "demos_%s.npz" % a.system))
+    demo_x, demo_u, true_parameter = load_demos(a.demos or os.path.join(ROOT, "examples", "data", "demos_%s.npz" % a.system))
     T = demo_u.shape[1]
     rng = np.random.default_rng(a.seed)
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2

@@ -428,6 +428,11 @@ class ModelLib:
         if rc == -2 and self.n <= 32 and self.m <= 8:
             # m + p > 16 (beyond the fused kernel's single parameter tile), n > 16 / m > 4 (beyond one tile per matrix: the generic LQR
             # kernel takes over), or a horizon whose staging exceeds the LDS: the reference's own route, kernel by kernel
+            if not getattr(self, "_warned_materialised", False):
+                import warnings
+                warnings.warn("pdp_oc_pdp_grad_batched: problem outside the fused kernel's limits (n = %d, m = %d, p = %d, T = %d): taking the "
+                              "kernel-by-kernel route through HBM (several launches, roughly ten times slower)" % (self.n, self.m, p, T), RuntimeWarning)
+                self._warned_materialised = True
             self._oc_pdp_grad_materialised(u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp, dudp)
             if packed:
                 pk[:, p].copy_(loss)
