@@ -177,20 +177,27 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
  *     min sum_t c(x_t,u_t) + h(x_T)  over x_1..x_T, u_0..u_{T-1}   s.t.  f(x_t,u_t) - x_{t+1} = 0,  x_0 = ini_state   (PDP.py:131-179)
  * solved from the reference's all-zero initial guess (PDP.py:155,166) by IPOPT's algorithm for the equality-constrained case
  * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search, least-squares initial multipliers;
- * CPU restatement: oracle/ipopt_ms.py).  One persistent wavefront per trajectory runs ALL iterations inside one launch: the
- * Newton step is an LQ problem solved on the MFMA Riccati tiles (one affine column), trial points are evaluated with one lane
- * per stage; no host round trip and no batch-wide synchronisation.
+ * CPU restatement: oracle/ipopt_ms.py).  A persistent pair of wavefronts per trajectory (runner: IPOPT's control flow and the Riccati /
+ * forward chains on the MFMA tiles; evaluator: KKT matrices, trial-point residuals, multiplier step with one lane per stage - csrc/pdp_ocsolve2_kernels.h;
+ * the one-wavefront kernel of round 2, csrc/pdp_ocsolve_kernels.h, stays behind PDP_MS_VARIANT=1) runs ALL iterations inside one launch: the
+ * Newton step is an LQ problem in homogeneous form on the Riccati tiles, trial points are evaluated with one lane per stage; no host round
+ * trip and no batch-wide synchronisation.  Finite bounds on states / controls are not part of this entry point: the Python layer
+ * (ocsolver.solve_batch_bounded) wraps it in a log-barrier continuation.
  *   in    : x0 [B][n], theta;   with PDP_MS_WARM also x, u, lam (starting point, e.g. the solution at a neighbouring theta)
  *   in/out: x [B][T+1][n], u [B][T][m], lam [B][T][n]  (lam[t] = multiplier of f(x_t,u_t) - x_{t+1} = IPOPT's lam_g = costate_traj_opt[t])
  *   out   : cost [B], resid [B][2] (max |defect|, max |grad Lagrangian|), converged [B], iterations [B], status [B], optional
  *           gains [B][T][n m + m] ({K^T, k} of the last Newton step, layout of pdp_oc_rollout_feedback_batched); any may be NULL.
  * Convergence: max|defect| <= tol (1 + max|x|,|u|) and max|grad L| <= tol (1 + max|lam|).  status bits: PDP_STATUS_NONFINITE,
  * PDP_MS_RESTORATION (the line search would enter IPOPT's restoration phase, which is not implemented: fall back to
- * pdp_oc_solve_batched), PDP_MS_MAXITER, PDP_MS_INERTIA (no positive definite reduced Hessian up to dw = 1e20).  n <= 16, m <= 4. */
+ * pdp_oc_solve_batched), PDP_MS_MAXITER, PDP_MS_INERTIA (no positive definite reduced Hessian up to dw = 1e20), PDP_MS_NOGAINS (gains were
+ * requested but the returned point has no complete positive definite sweep - not converged: zeros are written), PDP_MS_INTERNAL (the hand-over
+ * between the two wavefronts timed out: a bug, never expected; the trajectory is returned unconverged instead of hanging).  n <= 16, m <= 4. */
 #define PDP_MS_WARM 1
 #define PDP_MS_RESTORATION 4
 #define PDP_MS_MAXITER 8
 #define PDP_MS_INERTIA 16
+#define PDP_MS_NOGAINS 32
+#define PDP_MS_INTERNAL 64
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;
@@ -252,8 +259,9 @@ int pdp_cp_auxsys_batched(int B, int T, const pdp_policy* pol, int p, const doub
  * (the reference's own formulation); PDP_POLICY_MLP (<= 8 layers of <= 32 units, p <= 512) and larger Lagrange policies: the same
  * gradient by one adjoint sweep, O(T (n^2 + p)) instead of O(T n^2 p).  The materialised route of the reference
  * (integrate -> auxsys -> pdp_cp_aux_integrate_batched -> pdp_cp_grad_contract_batched) stays available for getAuxSys/integrateAuxSys.
- * workspace (optional, NULL = none): pdp_cp_step_workspace_bytes(B,T,pol,p) bytes; given it, the adjoint kernel keeps the hidden
- * activations of an MLP policy there instead of in LDS when that is what limits occupancy (0 bytes = not needed). */
+ * workspace (optional, NULL = none): pdp_cp_step_workspace_bytes(B,T,pol,p) bytes; the hidden activations of an MLP policy live there
+ * (register-resident kernel: 64 doubles per time step; general kernel: when LDS residency would limit occupancy; 0 bytes = not needed).
+ * Without it an MLP policy runs on the general kernel. */
 int64_t pdp_cp_step_workspace_bytes(int B, int T, const pdp_policy* pol, int p);
 int pdp_cp_step_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int theta_bstride,
                         double* loss, double* grad, double* x, double* u, void* workspace, int64_t workspace_bytes, void* stream);

@@ -101,8 +101,6 @@ __host__ __device__ constexpr bool ms2_ok() {
     return Mdl::NX <= 16 && Mdl::NU <= 4 && L::ROWS >= 4 && L::ROWSF >= 4 && Mdl::FIN_NVAR + L::NCFIN + L::PAR <= L::SLICE;
 }
 
-#define PDP_MS_INTERNAL 64      /* status bit: the runner / evaluator hand-over timed out (a bug, never expected) */
-#define PDP_MS_NOGAINS 32       /* status bit: gains were requested but no complete positive definite sweep exists at the returned point (zeros written) */
 
 // mailbox slots (ints) and result slots (doubles behind them)
 enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9 };
