@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         }
         make_gather3(gGr, lane, L::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
         const int col = tile_col(lane);
-        BufMap mK, mIK, mP, mW, mKT;
+        BufMap mK, mIK, mP, mW, mKT, mPld;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = tile_row(lane, r);
@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             mP.voff[r] = (row < NA && col < NA && (SMALL || row <= col)) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;   // P_{t+1}: full / upper triangle (of P~)
             mW.voff[r] = (row < NX && col == M) ? 8u * (unsigned)(PSZ + row) : MS2_OOB;
             mKT.voff[r] = (row < NA && (col & 3) < NU) ? 8u * (unsigned)L::gK(col & 3, row) : MS2_OOB;                // K (K~) read back transposed, replicated in the column blocks
+            mPld.voff[r] = (AUG && row < NA && col < NA) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;                   // P~ read back as a full tile from its upper triangle
         }
         const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, (int)((int64_t)T * GSZ * 8), 0x00020000);
         const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)pw, 0, (int)((int64_t)T * PWSZ * 8), 0x00020000);
@@ -445,9 +446,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 mDX.voff[r] = (col == M && row < NX) ? 8u * (unsigned)(row * TS) : MS2_OOB;
                 mDU.voff[r] = (col == M && row < NU) ? 8u * (unsigned)(OU + row * TS) : MS2_OOB;
             }
-            const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)stp, 0, (int)((int64_t)(NX + NU) * TS * 8), 0x00020000);
+            const auto rsD = __builtin_amdgcn_make_buffer_rsrc((void*)stp, 0, (int)(GRP * 8), 0x00020000);
             // feedback gains of stage t are requested two steps ahead (three register sets in rotation)
-            struct Gn { d4 KT, k; };
+            struct Gn { d4 KT, k, Pt; };                     // Pt (homogeneous form): P~_{t+1} as a full tile, for the multiplier step below
             // (loaded as stored, +K and +k: a negation right behind the load would make the step wait for the loads it has just issued; the sign is
             // absorbed in the products below: V = K x + k = -du, dx+ = F dx + c - G V)
             auto ldg = [&](int t) {
@@ -456,16 +457,26 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const unsigned so = (unsigned)(tt * GSZ) * 8u;
                 s.KT = buf_load<NRT>(rsG, so, mKT);
                 s.k = z;
+                s.Pt = z;
                 if constexpr (!AUG) s.k = buf_load<1>(rsG, so, mIK);
+                if constexpr (AUG) s.Pt = buf_load<4>(rsP, (unsigned)(tt * PWSZ) * 8u, mPld);
                 return s;
             };
             Gn A = ldg(0), Bn = ldg(1), Cn;
-            Cn.KT = z; Cn.k = z;
+            Cn.KT = z; Cn.k = z; Cn.Pt = z;
             d4 X2 = z, Xb = z;
-            if constexpr (AUG) {                            // x~_0 = [dx_0 = 0; 1] in column M
+            if constexpr (AUG) {
+                // x~_0 = [dx_0 = 0; 1], carried in EVERY column of the tile (the products below are column-wise, so every column stays x~_t): as the left
+                // operand of the four-row product the tile then is x~ "replicated in the column blocks", and the multiplier step
+                //     dlam_t' = x~_{t+1}' P~_{t+1}      (first NX entries; PDP.py:604)
+                // costs 4 small MFMAs on the runner, off its dependency chain - against a 16x16x16 product in round 2, or a lane-per-stage pass on the
+                // evaluator whose (P, W) reads arrived as one burst at the end of the sweep (profiles/r03_ms2_variants.txt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) X2[r] = (col == M && tile_row(lane, r) == NX) ? 1.0 : 0.0;
+                for (int r = 0; r < 4; ++r) X2[r] = tile_row(lane, r) == NX ? 1.0 : 0.0;
             }
+            BufMap mDL;                                      // dlam_t: row 0 of the four-row product, entry c to [OL + c TS + t]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mDL.voff[r] = (r == 0 && lane < NX) ? 8u * (unsigned)(OL + lane * TS) : MS2_OOB;
             double acc = 0.0;
             const bool scaledE = hs != 1.0;
             constexpr int RF = 8 * FS;
@@ -509,6 +520,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         Xn = mms_tn_r0(GT, V, Xn);
                         U2[0] = -V[0];
                         acc += RXn[0] * Xn[0] + RXn[1] * Xn[1] + RXn[2] * Xn[2] + RXn[3] * Xn[3] + RUc[0] * U2[0];
+                        if constexpr (AUG) {
+                            d4 Lm = z;
+                            Lm[0] = mma4_tn(Xn, cur.Pt, 0.0);          // x~_{t+1}' P~_{t+1}: rows 0..3 identical, row 0 = [dlam_t' | .]
+                            buf_store<1>(rsD, (unsigned)t * 8u, mDL, Lm);
+                        }
                     }
                     buf_store<1>(rsD, (unsigned)t * 8u, mDU, U2);
                     buf_store<NRT>(rsD, (unsigned)(t + 1) * 8u, mDX, Xn);
@@ -1006,7 +1022,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         // (the consumed chunk's buffer is free until chunk c + 1 is evaluated)
                         int tp, cp_;
                         fchunk(c - 1, tp, cp_);
-                        if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool + ((g - 1) & 1) * L::BUF, Cap1{});
+                        if constexpr (AUG) { (void)tp; (void)cp_; }      // (homogeneous form: the runner forms dlam in its forward steps)
+                        else if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool + ((g - 1) & 1) * L::BUF, Cap1{});
                         else dlam_chunk(tp, cp_);
                         MS2_E1(4);
                     }
@@ -1019,7 +1036,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if (got) {          // the last chunk: both pool buffers are free - its records in ONE block, one trip to memory
                         int tp, cp_;
                         fchunk(nchunkF - 1, tp, cp_);
-                        if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool, Cap2{});
+                        if constexpr (AUG) { (void)tp; (void)cp_; }
+                        else if constexpr (TPW == 4 && PDP_MS2_DLAM_STAGED) dlam_staged(tp, cp_, pool, Cap2{});
                         else dlam_chunk(tp, cp_);
                     }
                 }
