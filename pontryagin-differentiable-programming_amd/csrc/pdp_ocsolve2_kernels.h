@@ -462,8 +462,13 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if constexpr (AUG) s.Pt = buf_load<4>(rsP, (unsigned)(tt * PWSZ) * 8u, mPld);
                 return s;
             };
+            // gains of the next stages: requested two stages ahead into the set that is free, or - small systems, whose step is short against the latency of
+            // the workspace - three stages ahead, a step refilling the set it has just used (the tile forms measured slower that way:
+            // profiles/r03_ms2_variants.txt)
+            constexpr bool AHEAD3 = SMALL;
             Gn A = ldg(0), Bn = ldg(1), Cn;
-            Cn.KT = z; Cn.k = z; Cn.Pt = z;
+            if constexpr (AHEAD3) Cn = ldg(2);
+            else { Cn.KT = z; Cn.k = z; Cn.Pt = z; }
             d4 X2 = z, Xb = z;
             if constexpr (AUG) {
                 // x~_0 = [dx_0 = 0; 1], carried in EVERY column of the tile (the products below are column-wise, so every column stays x~_t): as the left
@@ -490,9 +495,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 MS2_T1(2);
                 Run3 rFT = run3_at(gFT, pb), rGT = run3_at(gGT, pb), rE = run3_at(gE, pb), rRX = run3_at(gRX, pb), rRU = run3_at(gRU, pb);
                 auto move_all = [&](int bytes) { move3<NRT>(rFT, bytes); move3<1>(rGT, bytes); move3<NRT>(rE, bytes); move3<NRT>(rRX, bytes); move3<1>(rRU, bytes); };
-                auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, const Gn& cur, Gn& fill) {
+                auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, Gn& cur, Gn& fill) {
                     const int t = t0 + tl;
-                    fill = ldg(t + 2);
+                    if constexpr (!AHEAD3) fill = ldg(t + 2);
                     d4 FT = read3<NRT>(rFT, imm);
                     d4 GT = read3<1>(rGT, imm);
                     d4 E2 = z;
@@ -528,6 +533,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     }
                     buf_store<1>(rsD, (unsigned)t * 8u, mDU, U2);
                     buf_store<NRT>(rsD, (unsigned)(t + 1) * 8u, mDX, Xn);
+                    if constexpr (AHEAD3) cur = ldg(t + 3);
                 };
                 int tl = 0;
                 for (; tl + 3 <= cnt; tl += 3) {
@@ -537,7 +543,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     X2 = Xb;
                     move_all(3 * RF);
                 }
-                for (; tl < cnt; ++tl) { fstep(tl, 0u, X2, Xb, A, Cn); X2 = Xb; A = Bn; Bn = Cn; move_all(RF); }
+                for (; tl < cnt; ++tl) { fstep(tl, 0u, X2, Xb, A, Cn); X2 = Xb; const Gn nx = A; A = Bn; Bn = Cn; Cn = nx; move_all(RF); }
                 f3_signal(ctl + MS2_CONS, g + 1);       // release: dx, du of the chunk are in memory
                 MS2_T1(3);
             }
