@@ -13,12 +13,21 @@
 //     evaluator  everything that is lane-per-stage: the KKT matrices of a chunk of stages one chunk AHEAD of the runner (double-buffered
 //                pool), the residuals of every trial point (defects, Lagrangian gradients, objective - ONE pass gives the line search its
 //                (theta, phi) and, when the point is accepted, the next iteration its convergence test and right-hand sides: no separate
-//                residual pass, no dyn / costate / H_u re-evaluation inside the sweep), the multiplier step dlam_t = P_{t+1} dx_{t+1} +
-//                W_{t+1} with one lane per stage behind the runner's forward chunks (169 FMAs per lane instead of a 256-cycle MFMA product
-//                on the runner's chain, and P never comes back to the runner), the update of (x, u, lambda).
-// The runner sends commands (sweep / trial / update / exit) through a mailbox in LDS; chunks are handed over with produced / consumed
+//                residual pass, no dyn / costate / H_u re-evaluation inside the sweep).
+// The runner sends commands (sweep / trial / trial-then-sweep / exit) through a mailbox in LDS; chunks are handed over with produced / consumed
 // counters (release / acquire at workgroup scope); every wait has a watchdog (a protocol error ends the trajectory with PDP_MS_INTERNAL
 // instead of hanging the GPU).
+//
+// What else changed against the one-wave kernel (each step measured, profiles/r03_ms2_phase_timing_v*.txt, r03_ms2_variants.txt):
+//   * homogeneous form of the Newton step for 4 < n < 16 (riccati_backward_aug): the affine column of the LQ problem becomes row / column n + 1 of
+//     F~ = [F c; 0 1], Hxx~ = [Hxx rx; rx' 0], P~ = [P W; W' s] - 13 + 9 MFMAs per backward step instead of 18 + 10, and one record per stage;
+//   * the multiplier step dlam_t' = x~_{t+1}' P~_{t+1} is four small MFMAs on the runner, off its dependency chain (x~ is carried in every tile column);
+//     the evaluator's lane-per-stage version of it (dlam_staged / dlam_chunk below) remains for the n <= 4 and n = 16 forms;
+//   * the iterate exists twice, stage-minor (Ms2Layout::group_doubles): a trial point is written into the other point set, accepting it is an index
+//     flip - there is no update pass;
+//   * the line search issues TRIAL_SWEEP: the evaluator continues with the first chunks of the next sweep at the trial point while the runner
+//     decides; a rejected trial costs an abort of that sweep;
+//   * the trial pass works with one NODE per lane and hands x_{t+1} - f(x_t, u_t) up with __shfl_up; stores are range-checked buffer stores.
 //
 // Placement.  TPW trajectories per workgroup of 2 TPW waves, runner = wave j, evaluator = wave j + TPW.  TPW = 4 (512 threads): the pair
 // shares a SIMD (probes/wave_placement_probe.hip) - 1024 trajectories fill the chip with every SIMD running one runner and its
@@ -26,9 +35,10 @@
 // the CU, nothing is shared but the LDS.
 //
 // Workspace traffic.  Per stage the sweep leaves K [m x n], k [m], W_{t+1} [n] and P_{t+1} - for n > 4 only its upper triangle (P is
-// symmetrised every step, so the two halves are bit-identical): 160 instead of 238 doubles for the quadrotor.  The runner's forward
-// steps re-read only K, k (56 doubles), requested TWO steps ahead through buffer loads (absent tile elements are out-of-range lanes: they
-// load 0 and store nothing, no sink words, no predicated blocks).
+// symmetrised every step, so the two halves are bit-identical); in the homogeneous form K~ = [K | k] (m x (n+1)) and the upper triangle of
+// P~ ((n+1)(n+2)/2): 56 + 105 doubles for the quadrotor against 238.  The runner's forward steps re-read them, requested TWO steps ahead
+// (three for n <= 4) through buffer loads (absent tile elements are out-of-range lanes: they load 0 and store nothing, no sink words, no
+// predicated blocks).
 #pragma once
 #include <type_traits>
 #include "pdp_ocsolve_kernels.h"
