@@ -188,16 +188,23 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
  *   out   : cost [B], resid [B][2] (max |defect|, max |grad Lagrangian|), converged [B], iterations [B], status [B], optional
  *           gains [B][T][n m + m] ({K^T, k} of the last Newton step, layout of pdp_oc_rollout_feedback_batched); any may be NULL.
  * Convergence: max|defect| <= tol (1 + max|x|,|u|) and max|grad L| <= tol (1 + max|lam|).  status bits: PDP_STATUS_NONFINITE,
- * PDP_MS_RESTORATION (the line search would enter IPOPT's restoration phase, which is not implemented: fall back to
- * pdp_oc_solve_batched), PDP_MS_MAXITER, PDP_MS_INERTIA (no positive definite reduced Hessian up to dw = 1e20), PDP_MS_NOGAINS (gains were
+ * PDP_MS_RESTORATION (the line search fell below alpha_min and no restoration was possible - see below: fall back to
+ * pdp_oc_solve_batched), PDP_MS_RESTORED (informational: a restoration took place), PDP_MS_MAXITER, PDP_MS_INERTIA (no positive definite reduced Hessian up to dw = 1e20), PDP_MS_NOGAINS (gains were
  * requested but the returned point has no complete positive definite sweep - not converged: zeros are written), PDP_MS_INTERNAL (the hand-over
- * between the two wavefronts timed out: a bug, never expected; the trajectory is returned unconverged instead of hanging).  n <= 16, m <= 4. */
+ * between the two wavefronts timed out: a bug, never expected; the trajectory is returned unconverged instead of hanging).  n <= 16, m <= 4.
+ * Restoration (round 3, runner / evaluator kernel only).  Where IPOPT's line search switches to its feasibility restoration phase (alpha < alpha_min), the
+ * kernel adds the current point to the filter, keeps the controls and replaces the states by their rollout from x0 (constraint violation 0, acceptable to
+ * every filter entry - what the filter method requires of a restoration phase; IPOPT's own restoration NLP is not restated), resets the multipliers to the
+ * least-squares estimate as IPOPT does after a restoration, and continues; the iteration counts as one.  Not possible at a feasible point or when the rollout
+ * overflows: PDP_MS_RESTORATION as before.  opts.flags & PDP_MS_NO_RESTORATION switches it off. */
 #define PDP_MS_WARM 1
+#define PDP_MS_NO_RESTORATION 2   /* opts.flags: return PDP_MS_RESTORATION instead of restoring (the behaviour before round 3) */
 #define PDP_MS_RESTORATION 4
 #define PDP_MS_MAXITER 8
 #define PDP_MS_INERTIA 16
 #define PDP_MS_NOGAINS 32
 #define PDP_MS_INTERNAL 64
+#define PDP_MS_RESTORED 128       /* informational: the line search fell below alpha_min at least once and the feasibility restoration below was used */
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;

@@ -17,7 +17,9 @@ large-scale nonlinear programming", Math. Program. 106 (2006) - specialised to t
   * equality multipliers move with the primal step length, lam+ = lam + alpha dlam; initial multipliers from the least-squares
     estimate, set to zero when its max-norm exceeds 1000                                                         (section 3.6)
 Not restated (never active on the reference's problems, checked on all stored demos and IRL traces): second-order correction,
-watchdog, restoration phase (a step that would need it raises).
+watchdog.  Restoration phase: IPOPT's own restoration algorithm is not restated; a step that would enter it (one stored demo: robot arm 3)
+is answered by the structure-specific feasibility restoration described in `solve` (states <- rollout of the controls), which satisfies what the
+filter method asks of a restoration phase and lands in IPOPT's stored optimum on that demo; `restoration=False` raises there instead.
 
 The KKT system is solved stage by stage: the Newton step is the solution of an LQ problem with affine terms (defects c_t in the
 dynamics, Lagrangian gradients in the cost), i.e. the same backward Riccati / forward rollout as `LQR.lqrSolver`
@@ -118,9 +120,15 @@ def least_squares_multipliers(ev, n, m):
     return dl
 
 
-def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None):
-    """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations`.
-    log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type)."""
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True):
+    """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations` and `restorations`.
+    log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type).
+    restoration: what happens when the line search falls below alpha_min, where IPOPT switches to its feasibility restoration phase.  IPOPT's own
+    restoration algorithm (an interior-point solve of min ||c||_1 + zeta/2 ||D_R (x - x_R)||^2) is not restated; what the filter method requires of
+    that phase is a point that is acceptable to the filter with a smaller constraint violation (Waechter & Biegler 2006, section 3.3), and the
+    multiple-shooting structure offers one directly: keep the controls, replace the states by the ROLLOUT x_{t+1} = f(x_t, u_t) from the fixed x_0
+    (theta = 0, acceptable to every filter entry).  As in IPOPT the current point is added to the filter first and the multipliers are reset to the
+    least-squares estimate afterwards (zero if larger than constr_mult_reset_threshold = 1000).  False: raise instead (the pre-round-3 behaviour)."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
@@ -139,8 +147,10 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     filt = []
     dw_last = 0.0
     it = 0
+    n_rest = 0
     for it in range(max_iter + 1):
         f, theta = ev["f"], ev["theta"]
+        inf_pr_it, inf_du_it = ev["inf_pr"], ev["inf_du"]
         scale = 1.0 + max(np.abs(xs).max(), np.abs(us).max())
         lscale = 1.0 + np.abs(lam).max()
         if ev["inf_pr"] <= tol * scale and ev["inf_du"] <= tol * lscale:
@@ -188,7 +198,25 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
                 break
             alpha *= o["alpha_red_factor"]
         if not accepted:
-            raise RuntimeError("ipopt_ms: line search would enter the restoration phase (not restated)")
+            if not restoration:
+                raise RuntimeError("ipopt_ms: line search would enter the restoration phase (not restated)")
+            if theta == 0.0:
+                raise RuntimeError("ipopt_ms: restoration phase called at a feasible point")
+            filt.append(((1.0 - o["gamma_theta"]) * theta, f - o["gamma_phi"] * theta))
+            xr = xs.copy()
+            for t in range(T):
+                xr[t + 1] = _vec(oc.dyn_fn(xr[t], us[t], e))
+            if not np.all(np.isfinite(xr)) or not np.isfinite(oc.cost(xr, us, e)):
+                raise RuntimeError("ipopt_ms: restoration phase failed (the rollout of the current controls is not finite)")
+            xs = xr
+            ev = evaluate(oc, xs, us, np.zeros((T, n)), e)
+            lam0 = least_squares_multipliers(ev, n, m)
+            lam = lam0 if (np.all(np.isfinite(lam0)) and np.abs(lam0).max() <= o["constr_mult_init_max"]) else np.zeros((T, n))
+            ev = evaluate(oc, xs, us, lam, e)
+            n_rest += 1
+            if log is not None:
+                log.append(dict(it=it, f=f, inf_pr=inf_pr_it, inf_du=inf_du_it, dw=dw, alpha=0.0, ftype=False, gd=gd, theta=theta, restoration=True))
+            continue
         if not ftype:
             filt.append(((1.0 - o["gamma_theta"]) * theta, f - o["gamma_phi"] * theta))
         if log is not None:
@@ -196,5 +224,5 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
                             dx=dx, du=du, dlam=dl))
         xs, us, lam = xt, ut, lam + alpha * dl
         ev = evaluate(oc, xs, us, lam, e)
-    return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it,
+    return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it, "restorations": n_rest,
             "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"]}

@@ -116,7 +116,8 @@ __host__ __device__ constexpr bool ms2_ok() {
 enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9 };
 // SWEEP: chunks of the iterate in set CUR.  TRIAL: residuals of CUR + alpha step -> set DST.  TRIAL_SWEEP: the same trial, then - speculating that the
 // runner accepts the point - straight on with the sweep of set DST (the runner aborts it otherwise)
-enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_TRIAL_SWEEP = 3 };
+// RESTORE: the states of set CUR replaced by the rollout of its controls, its multipliers by zero, then the residuals of that point (as TRIAL with alpha = 0)
+enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_TRIAL_SWEEP = 3, MS2_CMD_RESTORE = 4 };
 enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, MS2_L = 6, MS2_LC = 7, MS2_FIN = 8 };
 
 // Mailbox values come out of LDS in vector registers although every lane reads the same word: said explicitly (v_readfirstlane), or every pointer and
@@ -670,7 +671,26 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? alpha : 0.0; row[6] = gd; row[7] = theta;
             }
 #endif
-            if (!accepted) { st |= PDP_MS_RESTORATION; break; }      // (every rejected trial's sweep has been aborted above)
+            if (!accepted) {                            // (every rejected trial's sweep has been aborted above)
+                // alpha < alpha_min: IPOPT switches to its feasibility restoration phase.  What the filter method needs from that phase is a point with a smaller
+                // constraint violation that the filter accepts; multiple shooting offers one directly - keep the controls, replace the states by their rollout
+                // from x_0 (theta = 0) - and as in IPOPT the current point joins the filter first and the multipliers are reset to the least-squares estimate
+                // afterwards (phase 0 again).  oracle/ipopt_ms.py does the same, and reaches IPOPT's stored optimum this way on the one stored demo that gets
+                // here (robot arm demo 3).  Not available: at a feasible point (nothing to restore), with PDP_MS_NO_RESTORATION, or when the rollout overflows.
+                if (!(theta > 0.0) || (op.flags & PDP_MS_NO_RESTORATION)) { st |= PDP_MS_RESTORATION; break; }
+                if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
+                ++nfilt;
+                __threadfence_block();
+                issue(MS2_CMD_RESTORE, 0.0, cur, cur);
+                wait_done();
+                if (dead) break;
+                read_res();
+                if (!finite) { st |= PDP_MS_RESTORATION; break; }
+                st |= PDP_MS_RESTORED;
+                phase = 0; hs = 0.0; dw = 1.0; gains_ok = false;
+                ++it;
+                continue;
+            }
             if (!ftype) {                               // (at most one entry per iteration: the workspace holds max_iter + 1)
                 if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
                 ++nfilt;
@@ -826,6 +846,32 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 res[MS2_FIN] = fin_all ? 1.0 : 0.0;
             }
         };
+        // Restoration (see the runner's line search): x_{t+1} = f(x_t, u_t) from the fixed x_0 in point set `cur`, multipliers zeroed.  The one serial pass of this
+        // solver - every lane computes the same recursion, the controls of 64 stages are fetched by one coalesced load per component and broadcast per step.
+        auto restore = [&](int cur) {
+            PDP_MS2_PAR();
+            double* __restrict__ ps = Pt(cur);
+            double xr[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xr[i] = uni(ps[i * TS]);
+            for (int base = 0; base < T; base += 64) {
+                const int tl_ = base + lane < T ? base + lane : T - 1;
+                double ul[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) ul[i] = ps[OU + i * TS + tl_];
+                const int cnt = T - base < 64 ? T - base : 64;
+                for (int s_ = 0; s_ < cnt; ++s_) {
+                    double uc[NU], v[NX];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) uc[i] = readlane_f64(ul[i], s_);
+                    Mdl::dyn(xr, uc, th, pc, v);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { xr[i] = v[i]; if (lane == 0) ps[i * TS + base + s_ + 1] = v[i]; }
+                }
+            }
+            for (int q = lane; q < NX * TS; q += 64) ps[OL + q] = 0.0;
+            __threadfence_block();
+        };
         // multiplier step of the stages [t0, t0 + cnt): dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (PDP.py:604), lane = stage.  `pp`: the stage's (P, W) record,
         // `d`: dx_{t+1}.  Small systems: the full matrix; else the upper triangle row by row, in batches of rows whose loads are all requested before the
         // first FMA that needs one; element (j, k), k >= j, serves acc[j] and, off the diagonal, acc[k].
@@ -926,7 +972,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             const double alpha = uni(res[MS2_ALPHA]);
             if (type == MS2_CMD_EXIT) break;
             MS2_E0();
-            if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP) {
+            if (type == MS2_CMD_RESTORE) restore(cur);
+            if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP || type == MS2_CMD_RESTORE) {
                 trial(alpha, cur, dst);
                 __threadfence_block();
                 MS2_E1(0);

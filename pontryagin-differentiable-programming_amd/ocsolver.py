@@ -3,9 +3,10 @@ IPOPT (PDP/PDP.py:121-220).
 
 Default path (solve_batch with no starting controls): the reference's own formulation - the multiple-shooting NLP from the
 all-zero initial guess (PDP.py:155,166), iterated the way IPOPT does (primal-dual Newton step, inertia correction, filter line
-search; csrc/pdp_ocsolve_kernels.h, pdp_oc_solve_ms_batched): one persistent wavefront per trajectory, every iteration inside
-one launch.  It reproduces the optima the reference stored from a cold start on all five benchmark systems.  Trajectories whose
-line search would enter IPOPT's restoration phase (not implemented) fall back to the single-shooting solver below.
+search; csrc/pdp_ocsolve2_kernels.h, pdp_oc_solve_ms_batched): a persistent pair of wavefronts per trajectory, every iteration inside
+one launch.  It reproduces the optima the reference stored from a cold start on all five benchmark systems.  A trajectory whose
+line search falls below IPOPT's alpha_min is restored inside the kernel (states <- rollout of its controls; include/pdp_hip.h); whatever still
+comes back unconverged (no restoration possible, iteration limit) falls back to the single-shooting solver below.
 
 Single-shooting path (starting controls given, or as the fallback): stagewise Newton / iLQR, every trajectory of the batch in
 parallel; the iteration loop runs inside the model library (pdp_oc_solve_batched, see _solve below), plus the choice of the
@@ -71,7 +72,7 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     """ocSolver for a batch.  method "auto": the multiple-shooting solver (the reference's formulation, IPOPT's iteration) unless
     starting controls `u_init` are given; "ms" / "single" force one.  warm_start: a previous solution of the same batch (dict with
     state, control, costate[, gains]) - the multiple-shooting solver starts from that point.  Samples the multiple-shooting solver
-    returns unconverged (restoration phase needed, iteration limit) are re-solved by the single-shooting path.
+    returns unconverged (no restoration possible, iteration limit) are re-solved by the single-shooting path.
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
     torch = runtime.torch_cuda()

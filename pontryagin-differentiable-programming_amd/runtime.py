@@ -329,11 +329,12 @@ class ModelLib:
             out["gains"] = gains
         return out
 
-    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0):
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True):
         """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
-        (pdp_oc_solve_ms_batched: one persistent wavefront per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
-        from a given point instead (x[:, 0] is replaced by x0).  Returns dict(state, control, costate, cost, resid [B,2], converged (bool),
-        iterations [B], status [B][, gains])."""
+        (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
+        from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
+        PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  Returns dict(state, control, costate, cost,
+        resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
         B, T = x0.shape[0], int(T)
@@ -350,7 +351,7 @@ class ModelLib:
         nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T, int(max_iter))
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
-        opts = PdpOcMsOpts(float(tol), int(max_iter), 1 if warm is not None else 0, int(log_rows))
+        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2), int(log_rows))
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}

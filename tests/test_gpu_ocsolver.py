@@ -32,17 +32,16 @@ def make_oc(name):
 def test_oc_solver_reproduces_stored_ipopt_optimum(golden_dir, name):
     """Cold start on all five systems, called like the reference calls ocSolver (no starting controls): the multiple-shooting NLP from
     the all-zero guess (PDP.py:155,166) iterated the way IPOPT does lands in the optimum IPOPT stored - including the non-convex rocket
-    landing problem, where single shooting from u = 0 ends in another basin.  (robot arm demo 3 needs IPOPT's restoration phase, which
-    the kernel reports instead of implementing: that sample is re-solved by the single-shooting path and reaches the stored optimum too.)"""
+    landing problem, where single shooting from u = 0 ends in another basin.  Every sample stays on the multiple-shooting path: robot arm demo 3,
+    whose line search falls below alpha_min, goes through the kernel's feasibility restoration (round 3; before: single-shooting fallback)."""
     from pdp_amd import ocsolver
     d = load(golden_dir, "demos_%s.npz" % name)
     oc = make_oc(name)
     sol = ocsolver.solve_batch(oc, d["state"][:, 0], d["control"].shape[1], d["true_parameter"])
     assert bool(sol["converged"].all())
-    expect_ms = np.ones(d["state"].shape[0], bool)
-    if name == "robotarm":
-        expect_ms[3] = False
-    assert (sol["method_ms"].cpu().numpy() == expect_ms).all()
+    assert bool(sol["method_ms"].all())
+    restored = (sol["status"].cpu().numpy() & 128) != 0                      # PDP_MS_RESTORED
+    assert (restored == ((np.arange(d["state"].shape[0]) == 3) if name == "robotarm" else np.zeros(d["state"].shape[0], bool))).all()
     x, u, lam, cost = (sol[k].cpu().numpy() for k in ("state", "control", "costate", "cost"))
     assert np.abs(cost - d["cost"]).max() <= 1e-9 * np.abs(d["cost"]).max()
     assert np.abs(x - d["state"]).max() <= 1e-6 * max(1, np.abs(d["state"]).max())
@@ -153,6 +152,36 @@ def test_ms_kernel_follows_the_oracle_iteration_by_iteration(golden_dir, name):
     assert np.abs(sol["state"][0].cpu().numpy() - ref["state_traj_opt"]).max() <= 1e-9 * sc(ref["state_traj_opt"])
     assert np.abs(sol["control"][0].cpu().numpy() - ref["control_traj_opt"]).max() <= 1e-9 * sc(ref["control_traj_opt"])
     assert np.abs(sol["costate"][0].cpu().numpy() - ref["costate_traj_opt"]).max() <= 1e-9 * sc(ref["costate_traj_opt"])
+
+
+def test_ms_kernel_restoration_follows_the_oracle(golden_dir):
+    """robot arm demo 3 (the one stored demo whose line search falls below alpha_min): the kernel's iteration log equals the restatement's row by row -
+    eight Newton iterations, the restoration (step length 0 in the log), the least-squares multiplier reset, twelve more iterations - and ends in the optimum
+    IPOPT stored; with PDP_MS_NO_RESTORATION the trajectory is returned with PDP_MS_RESTORATION where the restoration would have started."""
+    from oracle import ipopt_ms, models, pdp_oracle as po
+    from pdp_amd import zoo
+    d = load(golden_dir, "demos_robotarm.npz")
+    st = models.IRL_SETUP["robotarm"]
+    oc = po.make_oc(models.REGISTRY["robotarm"](**st["kwargs"]), st["dt"])
+    T = d["control"].shape[1]
+    log = []
+    ref = ipopt_ms.solve(oc, d["state"][3, 0], T, d["true_parameter"], tol=1e-10, log=log)
+    mdl = zoo.get("robotarm", "irl")
+    x0 = np.repeat(d["state"][3:4, 0], 5, axis=0)                            # a few copies: also through the TPW = 1 workgroup shape with company
+    out = mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10, log_rows=64)
+    assert bool(out["converged"].all()) and (out["status"].cpu().numpy() == 128).all()
+    assert (out["iterations"].cpu().numpy() == ref["iterations"]).all() and ref["restorations"] == 1
+    kl = out["log"].cpu().numpy()[0]
+    for r, l in enumerate(log):
+        assert kl[r, 0] == l["it"] and kl[r, 4] == l["dw"] and kl[r, 5] == l["alpha"], (r, kl[r], l["dw"], l["alpha"])
+        assert abs(kl[r, 1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(kl[r, 2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
+        assert abs(kl[r, 3] - l["inf_du"]) <= 1e-8 * max(1.0, l["inf_du"])
+    assert [l["alpha"] for l in log].index(0.0) == 8
+    for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+        assert np.abs(out[k].cpu().numpy() - ref[kr][None]).max() <= 1e-9 * max(1.0, np.abs(ref[kr]).max())
+    assert np.abs(out["state"].cpu().numpy()[0] - d["state"][3]).max() <= 1e-6 and abs(float(out["cost"][0]) - d["cost"][3]) <= 1e-9 * d["cost"][3]
+    off = mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10, log_rows=64, restoration=False)
+    assert not bool(off["converged"].any()) and (off["status"].cpu().numpy() == 4).all() and (off["iterations"].cpu().numpy() == 8).all()
 
 
 def test_ms_kernel_warm_start_gains_and_per_sample_parameters(golden_dir):

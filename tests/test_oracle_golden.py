@@ -221,10 +221,23 @@ def test_ipopt_restatement_reproduces_the_stored_rocket_irl_trace(golden_dir):
         assert abs(loss - tr["loss_next"][j]) <= 1e-9 * abs(tr["loss_next"][j])
 
 
-def test_ipopt_restatement_reports_the_restoration_phase(golden_dir):
-    """robot arm demo 3 starts at an equilibrium of the zero guess: IPOPT's line search runs into the restoration phase, which is not
-    restated (the product reports PDP_MS_RESTORATION and falls back to its single-shooting solver)"""
+def test_ipopt_restatement_restoration_phase(golden_dir):
+    """robot arm demo 3 starts at an equilibrium of the zero guess: the line search falls below alpha_min after 8 iterations, where IPOPT enters its
+    restoration phase.  The restatement's restoration (states <- rollout of the current controls, current point into the filter, multipliers from the
+    least-squares estimate; oracle/ipopt_ms.py: solve) continues from there and lands in the optimum the real IPOPT stored for this demo; switched
+    off, the restatement reports the point where it would have been needed."""
     from oracle import ipopt_ms
     d = _load(golden_dir, "demos_robotarm.npz")
+    oc, T = _oc("robotarm"), d["control"].shape[1]
     with pytest.raises(RuntimeError, match="restoration"):
-        ipopt_ms.solve(_oc("robotarm"), d["state"][3, 0], d["control"].shape[1], d["true_parameter"])
+        ipopt_ms.solve(oc, d["state"][3, 0], T, d["true_parameter"], restoration=False)
+    log = []
+    s = ipopt_ms.solve(oc, d["state"][3, 0], T, d["true_parameter"], log=log)
+    assert s["restorations"] == 1 and [bool(l.get("restoration")) for l in log].index(True) == 8
+    assert abs(s["cost"] - d["cost"][3]) <= 1e-12 * abs(d["cost"][3])
+    assert np.abs(s["state_traj_opt"] - d["state"][3]).max() <= 1e-9 and np.abs(s["control_traj_opt"] - d["control"][3]).max() <= 1e-9
+    assert np.abs(s["costate_traj_opt"] - d["costate"][3]).max() <= 1e-9 * max(1.0, np.abs(d["costate"][3]).max())
+    # the demos that never get there are untouched by the switch
+    s0 = ipopt_ms.solve(oc, d["state"][0, 0], T, d["true_parameter"])
+    assert s0["restorations"] == 0
+
