@@ -113,7 +113,8 @@ __host__ __device__ constexpr bool ms2_ok() {
 
 
 // mailbox slots (ints) and result slots (doubles behind them)
-enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9 };
+enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9,
+       MS2_PDONE = 10 };       // PDONE: the runner's (primal) half of a line-search trial is in memory
 // SWEEP: chunks of the iterate in set CUR.  TRIAL: residuals of CUR + alpha step -> set DST.  TRIAL_SWEEP: the same trial, then - speculating that the
 // runner accepts the point - straight on with the sweep of set DST (the runner aborts it otherwise)
 // RESTORE: the states of set CUR replaced by the rollout of its controls, its multipliers by zero, then the residuals of that point (as TRIAL with alpha = 0)
@@ -227,6 +228,122 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     const int nbodyF = (T - tailF + L::ROWSF - 1) / L::ROWSF, chF = (T - tailF + nbodyF - 1) / nbodyF;
     const int nchunkF = nbodyF + (tailF ? 1 : 0);
     auto fchunk = [&](int c, int& t0, int& cnt) { if (c < nbodyF) { t0 = c * chF; cnt = min(chF, T - tailF - t0); } else { t0 = T - tailF; cnt = tailF; } };
+
+    // ---- the trial pass (both waves use it).  Residuals of the point (x, u, lambda) + a (dx, du, dlam), lane = NODE t = 0 .. T (T + 1 of them): node t < T
+    // evaluates stage t at its own (x_t, u_t, lambda_{t+1}); what couples neighbouring stages - the defect c_{t-1} = f(x_{t-1}, u_{t-1}) - x_t and the
+    // stationarity row grad_x L_t = H_x(t) - lambda_t - is formed by node t from ITS x_t and the previous node's f and lambda, handed up one lane (node 0 of a
+    // later pass: from lane 63 of the pass before, through scalar registers); node T does the terminal terms.  No lane reads another stage's rows:
+    // 2 (2 NX + NU) coalesced loads per pass, and every store is a range-checked buffer store (inactive lanes: out-of-range offset), so the pass has no
+    // conditional block around memory operations.  a = 0: the current point (dx, du, dlam are not read into the result).
+    // PART 0: everything (TRIAL / RESTORE commands, on the evaluator).  The line search splits the pass between the two waves - the runner would only wait:
+    // PART 1, runner: the PRIMAL half - trial (x, u) into set `dst`, defects, objective, theta, the convergence measures of the primal side; it is all the
+    //         filter needs, so the runner decides on the trial point without waiting for anybody;
+    // PART 2, evaluator: the DUAL half - trial lambda, grad_x L, grad_u L and their measures (used once the point is accepted), then on with the sweep.
+    double a_f = 0.0, a_th = 0.0, a_pr = 0.0, a_du = 0.0, a_z = 0.0, a_l = 0.0, a_lc = 0.0;
+    bool fin_all = true;
+    auto trial_pass = [&](auto part_tag, double a, int cur, int dst) {
+        constexpr int PART = decltype(part_tag)::value;
+        constexpr bool PRIMAL = PART != 2, DUAL = PART != 1;
+        PDP_MS2_PAR();
+        const bool stepped = a != 0.0, put = dst != cur;
+        const double* __restrict__ ps = Pt(cur);
+        const auto rsPd = __builtin_amdgcn_make_buffer_rsrc((void*)Pt(dst), 0, (int)(GRP * 8), 0x00020000);
+        const auto rsRd = __builtin_amdgcn_make_buffer_rsrc((void*)Rs(dst), 0, (int)(GRP * 8), 0x00020000);      // grad_x L (T + 1 nodes; node 0: x_0 is fixed) | grad_u L | c
+        auto bst = [](auto rs, unsigned soff, unsigned voff, double v_) {
+            pdp_u2 w;
+            w.x = (unsigned)__double2loint(v_); w.y = (unsigned)__double2hiint(v_);
+            __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
+        };
+        a_f = 0.0; a_th = 0.0; a_pr = 0.0; a_du = 0.0; a_z = 0.0; a_l = 0.0; a_lc = 0.0;
+        bool fin = true;
+        double vprev[NX], lprev[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { vprev[i] = 0.0; lprev[i] = 0.0; }
+        for (int base = 0; base <= T; base += 64) {
+            const int t = base + lane;
+            const bool node = t <= T, stage = t < T, last = t == T;
+            const unsigned o8 = 8u * (unsigned)(node ? t : T);      // (lanes behind the horizon read node T's slots and store nothing)
+            const unsigned on = node ? o8 : MS2_OOB, os = stage ? o8 : MS2_OOB, oc = (node && t > 0) ? o8 - 8u : MS2_OOB;
+            double xc[NX], uc[NU], lc[NX], v[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double xa = sm_ld(ps + i * TS, o8), xd = sm_ld(stp + i * TS, o8), la = sm_ld(ps + OL + i * TS, o8), ld = sm_ld(stp + OL + i * TS, o8);
+                xc[i] = stepped ? fma(a, xd, xa) : xa;
+                lc[i] = stepped ? fma(a, ld, la) : la;                 // (slot T of the lambda / u rows exists and is unused: node T reads it and drops it)
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { const double ua = sm_ld(ps + OU + i * TS, o8), ud = sm_ld(stp + OU + i * TS, o8); uc[i] = stepped ? fma(a, ud, ua) : ua; }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if constexpr (PRIMAL) { a_z = fmax(a_z, node ? fabs(xc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(i * TS) * 8u, on, xc[i]); }
+                if constexpr (DUAL) { a_l = fmax(a_l, stage ? fabs(lc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OL + i * TS) * 8u, os, lc[i]); }
+            }
+            if constexpr (PRIMAL) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { a_z = fmax(a_z, stage ? fabs(uc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OU + i * TS) * 8u, os, uc[i]); }
+            }
+            double nl[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {                              // the previous node's lambda
+                nl[i] = __shfl_up(lc[i], 1, 64);
+                if (lane == 0) nl[i] = lprev[i];
+                lprev[i] = readlane_f64(lc[i], 63);
+            }
+            if constexpr (PRIMAL) {
+                Mdl::dyn(xc, uc, th, pc, v);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double nv = __shfl_up(v[i], 1, 64);                  // the previous node's f(x, u)
+                    if (lane == 0) nv = vprev[i];
+                    vprev[i] = readlane_f64(v[i], 63);
+                    const double ci = nv - xc[i];                        // defect of stage t - 1
+                    bst(rsRd, (unsigned)(OL + i * TS) * 8u, oc, ci);
+                    const bool has = node && t > 0;
+                    a_th += has ? fabs(ci) : 0.0; a_pr = fmax(a_pr, has ? fabs(ci) : 0.0); a_lc += has ? nl[i] * ci : 0.0;
+                    fin = fin && (!has || fabs(ci) <= 1.7e308);
+                }
+                double fT = 0.0;
+                if (last) fT = Mdl::final_cost(xc, th, pc);              // (arithmetic only inside the branch)
+                const double pcst = Mdl::path_cost(xc, uc, th, pc);
+                a_f += stage ? pcst : (last ? fT : 0.0);
+            }
+            if constexpr (DUAL) {
+                Mdl::costate_step(xc, uc, lc, th, pc, v);
+                double hT[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) hT[i] = 0.0;
+                if (last) Mdl::dhx(xc, th, pc, hT);                      // terminal node: h_x(x_T)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double g = last ? hT[i] - nl[i] : ((stage && t > 0) ? v[i] - nl[i] : 0.0);      // grad_x L of node t (x_0 is fixed: no row)
+                    bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
+                    a_du = fmax(a_du, node ? fabs(g) : 0.0);
+                    fin = fin && (!node || fabs(g) <= 1.7e308);
+                }
+                double hu[NU];
+                Mdl::dHu(xc, uc, lc, th, pc, hu);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OU + i * TS) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
+            }
+        }
+        if constexpr (PRIMAL) { a_f = wave_sum(a_f); a_th = wave_sum(a_th); a_lc = wave_sum(a_lc); a_pr = wave_max(a_pr); a_z = wave_max(a_z); }
+        if constexpr (DUAL) { a_du = wave_max(a_du); a_l = wave_max(a_l); }
+        fin_all = __all(fin);
+        if constexpr (DUAL) {                                        // (the runner keeps its half in registers)
+            if (lane == 0) {
+                if constexpr (PRIMAL) { res[MS2_F] = a_f; res[MS2_TH] = a_th; res[MS2_PR] = a_pr; res[MS2_Z] = a_z; res[MS2_LC] = a_lc; }
+                res[MS2_DU] = a_du; res[MS2_L] = a_l;
+                res[MS2_FIN] = fin_all ? 1.0 : 0.0;
+            }
+        }
+    };
+    // The split pays where the two halves are comparable and the runner has registers to spare - the small systems (cart-pole cold solve 4.18 -> 3.94 ms).  For the
+    // tile forms it does not: the quadrotor's trial pass is mostly `dyn`, and inside the runner's register allocation (256 VGPRs, gather maps of both sweeps live)
+    // that half alone took longer than the whole pass on the evaluator (line search 23 k -> 30 k cycles, spills into the sweeps: 0.318 -> 0.340 ms; profiles/r03_ms2_variants.txt)
+    constexpr bool SPLIT = SMALL;
+    using PartAll = std::integral_constant<int, 0>;
+    using PartPrimal = std::integral_constant<int, 1>;
+    using PartDual = std::integral_constant<int, 2>;
 
     if (runner) {
         // ================================================ runner ================================================
@@ -638,13 +755,20 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             }
             amin *= 0.05;
             double alpha = 1.0, ft = 0.0, tht = 0.0;
-            bool accepted = false, ftype = false;
+            bool accepted = false, ftype = false, fin_p = true;
             while (alpha >= amin && alpha > 1e-300) {      // (the second bound only guards against amin = 0)
                 issue(MS2_CMD_TRIAL_SWEEP, alpha, cur, cur ^ 1);
-                wait_slot(MS2_TDONE);
-                if (dead) break;
-                wave_lds_sync();
-                ft = uni(res[MS2_F]); tht = uni(res[MS2_TH]);
+                if constexpr (SPLIT) {
+                    trial_pass(PartPrimal{}, alpha, cur, cur ^ 1); // this wave's half: (theta, phi) of the trial point - all the filter asks for
+                    fin_p = fin_all;
+                    f3_signal(ctl + MS2_PDONE, seq);               // release: trial (x, u) and defects are in memory
+                    ft = a_f; tht = a_th;
+                } else {
+                    wait_slot(MS2_TDONE);
+                    if (dead) break;
+                    wave_lds_sync();
+                    ft = uni(res[MS2_F]); tht = uni(res[MS2_TH]);
+                }
                 bool okf = fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308 && tht <= theta_max;
                 if (okf) {
                     bool dominated = false;
@@ -696,7 +820,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 ++nfilt;
                 __threadfence_block();
             }
-            read_res();                                 // the accepted trial's residuals are the new iterate's ...
+            // the accepted trial's residuals are the new iterate's: the primal side from this wave's half of the pass, the dual side from the evaluator's
+            if constexpr (SPLIT) {
+                f_cur = a_f; th_cur = a_th; inf_pr = a_pr; zmax = a_z; lamc = a_lc;
+                wait_slot(MS2_TDONE);
+                if (dead) break;
+                wave_lds_sync();
+                inf_du = uni(res[MS2_DU]); lmax = uni(res[MS2_L]);
+                finite = fin_p && uni(res[MS2_FIN]) != 0.0;
+            } else read_res();
             cur ^= 1;                                   // ... and the trial pass left the point itself in the other set
             MS2_T1(6);
 #ifdef PDP_MS_TIMING
@@ -754,98 +886,6 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #define MS2_E0()
 #define MS2_E1(k)
 #endif
-        double a_f, a_th, a_pr, a_du, a_z, a_l, a_lc;
-        bool fin_all;
-        // Residuals of the point (x, u, lambda) + a (dx, du, dlam), lane = stage: defects, Lagrangian gradients (into residual set `dst`), objective,
-        // constraint violation, the convergence measures.  a = 0: the current point (dx, du, dlam are not read into the result).
-        auto trial = [&](double a, int cur, int dst) {
-            PDP_MS2_PAR();
-            const bool stepped = a != 0.0, put = dst != cur;
-            const double* __restrict__ ps = Pt(cur);
-            // lane = NODE t = 0 .. T (T + 1 of them): node t < T evaluates stage t at its own (x_t, u_t, lambda_{t+1}); what couples neighbouring stages - the
-            // defect c_{t-1} = f(x_{t-1}, u_{t-1}) - x_t and the stationarity row grad_x L_t = H_x(t) - lambda_t - is formed by node t from ITS x_t and
-            // the previous node's f and lambda, handed up one lane (node 0 of a later pass: from lane 63 of the pass before, through scalar
-            // registers); node T does the terminal terms.  No lane reads another stage's rows: 2 (2 NX + NU) coalesced loads per pass, and every
-            // store is a range-checked buffer store (inactive lanes: out-of-range offset), so the pass has no conditional block around memory operations.
-            const auto rsPd = __builtin_amdgcn_make_buffer_rsrc((void*)Pt(dst), 0, (int)(GRP * 8), 0x00020000);
-            const auto rsRd = __builtin_amdgcn_make_buffer_rsrc((void*)Rs(dst), 0, (int)(GRP * 8), 0x00020000);      // grad_x L (T + 1 nodes; node 0: x_0 is fixed) | grad_u L | c
-            auto bst = [](auto rs, unsigned soff, unsigned voff, double v_) {
-                pdp_u2 w;
-                w.x = (unsigned)__double2loint(v_); w.y = (unsigned)__double2hiint(v_);
-                __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 0);
-            };
-            a_f = 0.0; a_th = 0.0; a_pr = 0.0; a_du = 0.0; a_z = 0.0; a_l = 0.0; a_lc = 0.0;
-            bool fin = true;
-            double vprev[NX], lprev[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { vprev[i] = 0.0; lprev[i] = 0.0; }
-            for (int base = 0; base <= T; base += 64) {
-                const int t = base + lane;
-                const bool node = t <= T, stage = t < T, last = t == T;
-                const unsigned o8 = 8u * (unsigned)(node ? t : T);      // (lanes behind the horizon read node T's slots and store nothing)
-                const unsigned on = node ? o8 : MS2_OOB, os = stage ? o8 : MS2_OOB, oc = (node && t > 0) ? o8 - 8u : MS2_OOB;
-                double xc[NX], uc[NU], lc[NX], v[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double xa = sm_ld(ps + i * TS, o8), xd = sm_ld(stp + i * TS, o8), la = sm_ld(ps + OL + i * TS, o8), ld = sm_ld(stp + OL + i * TS, o8);
-                    xc[i] = stepped ? fma(a, xd, xa) : xa;
-                    lc[i] = stepped ? fma(a, ld, la) : la;                 // (slot T of the lambda / u rows exists and is unused: node T reads it and drops it)
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { const double ua = sm_ld(ps + OU + i * TS, o8), ud = sm_ld(stp + OU + i * TS, o8); uc[i] = stepped ? fma(a, ud, ua) : ua; }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    a_z = fmax(a_z, node ? fabs(xc[i]) : 0.0); a_l = fmax(a_l, stage ? fabs(lc[i]) : 0.0);
-                    if (put) { bst(rsPd, (unsigned)(i * TS) * 8u, on, xc[i]); bst(rsPd, (unsigned)(OL + i * TS) * 8u, os, lc[i]); }
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { a_z = fmax(a_z, stage ? fabs(uc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OU + i * TS) * 8u, os, uc[i]); }
-                Mdl::dyn(xc, uc, th, pc, v);
-                double nl[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    // the previous node's f(x, u) and lambda
-                    double nv = __shfl_up(v[i], 1, 64);
-                    nl[i] = __shfl_up(lc[i], 1, 64);
-                    if (lane == 0) { nv = vprev[i]; nl[i] = lprev[i]; }
-                    vprev[i] = readlane_f64(v[i], 63); lprev[i] = readlane_f64(lc[i], 63);
-                    const double ci = nv - xc[i];                        // defect of stage t - 1
-                    bst(rsRd, (unsigned)(OL + i * TS) * 8u, oc, ci);
-                    const bool has = node && t > 0;
-                    a_th += has ? fabs(ci) : 0.0; a_pr = fmax(a_pr, has ? fabs(ci) : 0.0); a_lc += has ? nl[i] * ci : 0.0;
-                    fin = fin && (!has || fabs(ci) <= 1.7e308);
-                }
-                Mdl::costate_step(xc, uc, lc, th, pc, v);
-                double hT[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) hT[i] = 0.0;
-                double fT = 0.0;
-                if (last) {                                              // terminal node: h_x(x_T), h(x_T)   (arithmetic only inside the branch)
-                    Mdl::dhx(xc, th, pc, hT);
-                    fT = Mdl::final_cost(xc, th, pc);
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double g = last ? hT[i] - nl[i] : ((stage && t > 0) ? v[i] - nl[i] : 0.0);      // grad_x L of node t (x_0 is fixed: no row)
-                    bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
-                    a_du = fmax(a_du, node ? fabs(g) : 0.0);
-                    fin = fin && (!node || fabs(g) <= 1.7e308);
-                }
-                double hu[NU];
-                Mdl::dHu(xc, uc, lc, th, pc, hu);
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OU + i * TS) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
-                const double pcst = Mdl::path_cost(xc, uc, th, pc);
-                a_f += stage ? pcst : (last ? fT : 0.0);
-            }
-            a_f = wave_sum(a_f); a_th = wave_sum(a_th); a_lc = wave_sum(a_lc);
-            a_pr = wave_max(a_pr); a_du = wave_max(a_du); a_z = wave_max(a_z); a_l = wave_max(a_l);
-            fin_all = __all(fin);
-            if (lane == 0) {
-                res[MS2_F] = a_f; res[MS2_TH] = a_th; res[MS2_PR] = a_pr; res[MS2_DU] = a_du; res[MS2_Z] = a_z; res[MS2_L] = a_l; res[MS2_LC] = a_lc;
-                res[MS2_FIN] = fin_all ? 1.0 : 0.0;
-            }
-        };
         // Restoration (see the runner's line search): x_{t+1} = f(x_t, u_t) from the fixed x_0 in point set `cur`, multipliers zeroed.  The one serial pass of this
         // solver - every lane computes the same recursion, the controls of 64 stages are fetched by one coalesced load per component and broadcast per step.
         auto restore = [&](int cur) {
@@ -974,7 +1014,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             MS2_E0();
             if (type == MS2_CMD_RESTORE) restore(cur);
             if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP || type == MS2_CMD_RESTORE) {
-                trial(alpha, cur, dst);
+                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP) trial_pass(PartDual{}, alpha, cur, dst);       // (the line search: the runner does the primal half meanwhile)
+                else trial_pass(PartAll{}, alpha, cur, dst);
                 __threadfence_block();
                 MS2_E1(0);
 #ifdef PDP_MS_TIMING
@@ -982,6 +1023,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) res[12 + k_] = (double)et[k_];
 #endif
                 f3_signal(ctl + MS2_TDONE, last);
+                // the sweep below reads the trial (x, u) and the defects the runner's half of the pass writes
+                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP && !ms2_wait_ge(ctl + MS2_PDONE, last, ctl)) break;
             }
             if (type == MS2_CMD_SWEEP || type == MS2_CMD_TRIAL_SWEEP) {
                 const int sw = type == MS2_CMD_SWEEP ? cur : dst;          // the set the sweep linearises at
