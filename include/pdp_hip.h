@@ -199,6 +199,8 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
  * overflows: PDP_MS_RESTORATION as before.  opts.flags & PDP_MS_NO_RESTORATION switches it off. */
 #define PDP_MS_WARM 1
 #define PDP_MS_NO_RESTORATION 2   /* opts.flags: return PDP_MS_RESTORATION instead of restoring (the behaviour before round 3) */
+#define PDP_MS_FROM_CONTROLS 8    /* opts.flags, with PDP_MS_WARM (runner / evaluator kernel): start from the controls in u only - x becomes their rollout from x0,
+                                     lam the least-squares multiplier estimate; the contents of x and lam on entry are ignored */
 #define PDP_MS_RESTORATION 4
 #define PDP_MS_MAXITER 8
 #define PDP_MS_INERTIA 16

@@ -120,7 +120,7 @@ def least_squares_multipliers(ev, n, m):
     return dl
 
 
-def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True):
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None):
     """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations` and `restorations`.
     log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type).
     restoration: what happens when the line search falls below alpha_min, where IPOPT switches to its feasibility restoration phase.  IPOPT's own
@@ -128,13 +128,19 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     that phase is a point that is acceptable to the filter with a smaller constraint violation (Waechter & Biegler 2006, section 3.3), and the
     multiple-shooting structure offers one directly: keep the controls, replace the states by the ROLLOUT x_{t+1} = f(x_t, u_t) from the fixed x_0
     (theta = 0, acceptable to every filter entry).  As in IPOPT the current point is added to the filter first and the multipliers are reset to the
-    least-squares estimate afterwards (zero if larger than constr_mult_reset_threshold = 1000).  False: raise instead (the pre-round-3 behaviour)."""
+    least-squares estimate afterwards (zero if larger than constr_mult_reset_threshold = 1000).  False: raise instead (the pre-round-3 behaviour).
+    u_init [T, m]: start from these controls and their rollout instead of the reference's all-zero guess (not something the reference does - it is
+    the starting point PDP_MS_FROM_CONTROLS gives the kernel, restated here so that path has a checker)."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
     xs = np.zeros((T + 1, n))
     xs[0] = _vec(ini_state)
     us = np.zeros((T, m))                               # w0 = 0.5 (lb + ub) = 0   (PDP.py:155, 166)
+    if u_init is not None:
+        us = np.array(u_init, dtype=float).reshape(T, m)
+        for t in range(T):
+            xs[t + 1] = _vec(oc.dyn_fn(xs[t], us[t], e))
     lam = np.zeros((T, n))
     ev = evaluate(oc, xs, us, lam, e)
     # initial multipliers: least-squares estimate from grad f (rdx / rdu at lam = 0)

@@ -255,8 +255,10 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
     if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= 16 && Mdl::NU <= 4) {
         if (B <= 0 || T <= 0 || !x0 || !th || !x || !u || !lam || !op || !ws) return PDP_E_ARG;
         if (op->max_iter < 0 || wsb < oc_solve_ms_ws_bytes<Mdl>(B, T, op->max_iter)) return PDP_E_ARG;
+        const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
+        if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
         if constexpr (ms2_ok<Mdl>()) {
-            if (ms_variant() == 2) {
+            if (ms_variant() == 2 || needs_pair) {
                 // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
                 // batches spread over the CUs with the two waves of a trajectory on different SIMDs
                 const int cus = device_cu_count();
@@ -265,6 +267,7 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
                 return oc_solve_ms2_launch<Mdl, 4>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
             }
         }
+        if (needs_pair) return PDP_E_SIZE;
         const size_t lds = ms_lds_bytes<Mdl>();
         if (lds > 160 * 1024) return PDP_E_SIZE;
         (void)hipFuncSetAttribute((const void*)oc_solve_ms_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -681,11 +681,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // ---- main loop (IPOPT's order: convergence test, sweep with inertia correction, line search).
         // phase 0 (cold start only): the least-squares multiplier estimate (constr_mult_init_max = 1000),
         //     [I A'; A 0] [w; lambda] = -[grad f; 0]  - the same sweep with W = I and no defects; phase 1: the iteration.
-        int st = 0, it = 0, nfilt = 0, conv = 0, phase = warm ? 1 : 0, cur = 0;
-        double hs = warm ? 1.0 : 0.0, dw = warm ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
+        // PDP_MS_FROM_CONTROLS (with PDP_MS_WARM): only the caller's controls count - the states become their rollout, the multipliers the least-squares
+        // estimate (the RESTORE command, then phase 0 like a cold start)
+        const bool from_u = warm && (op.flags & PDP_MS_FROM_CONTROLS) != 0;
+        const bool ph1 = warm && !from_u;
+        int st = 0, it = 0, nfilt = 0, conv = 0, phase = ph1 ? 1 : 0, cur = 0;
+        double hs = ph1 ? 1.0 : 0.0, dw = ph1 ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
         bool gains_ok = false, pending = false;         // pending: the evaluator is already on the sweep of the current iterate (TRIAL_SWEEP)
         // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays)
-        issue(MS2_CMD_TRIAL, 0.0, cur, cur);
+        issue(from_u ? MS2_CMD_RESTORE : MS2_CMD_TRIAL, 0.0, cur, cur);
         wait_done();
         read_res();
         for (;;) {

@@ -70,7 +70,8 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
 def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,
                 warm_start=None, want_gains=False, method="auto"):
     """ocSolver for a batch.  method "auto": the multiple-shooting solver (the reference's formulation, IPOPT's iteration) unless
-    starting controls `u_init` are given; "ms" / "single" force one.  warm_start: a previous solution of the same batch (dict with
+    starting controls `u_init` are given; "ms" / "single" force one ("ms" with `u_init`: the multiple-shooting iteration started from those controls, their rollout
+    and the least-squares multipliers).  warm_start: a previous solution of the same batch (dict with
     state, control, costate[, gains]) - the multiple-shooting solver starts from that point.  Samples the multiple-shooting solver
     returns unconverged (no restoration possible, iteration limit) are re-solved by the single-shooting path.
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
@@ -85,7 +86,8 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     B = x0.shape[0]
     th = oc._theta(auxvar_value, B)
     warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])
-    ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains)
+    ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains,
+                         u_init=u_init if warm is None else None)      # method "ms" with starting controls: PDP_MS_FROM_CONTROLS
     sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
            "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
     if want_gains:

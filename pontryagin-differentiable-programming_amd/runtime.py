@@ -329,11 +329,12 @@ class ModelLib:
             out["gains"] = gains
         return out
 
-    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True):
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None):
         """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
         (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
         from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
-        PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  Returns dict(state, control, costate, cost,
+        PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  u_init [B, T, m] (instead of warm): start from these
+        controls, their rollout and the least-squares multiplier estimate (PDP_MS_FROM_CONTROLS).  Returns dict(state, control, costate, cost,
         resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
@@ -341,8 +342,13 @@ class ModelLib:
         th, tb = self._theta(theta, B)
         f64 = dict(dtype=torch.float64, device="cuda")
         if warm is not None:
+            assert u_init is None, "warm and u_init exclude each other"
             x, u, lam = (dev(a).clone().contiguous() for a in warm)
             assert x.shape == (B, T + 1, self.n) and u.shape == (B, T, self.m) and lam.shape == (B, T, self.n)
+        elif u_init is not None:
+            u = dev(u_init).clone().contiguous()
+            assert u.shape == (B, T, self.m)
+            x, lam = torch.zeros((B, T + 1, self.n), **f64), torch.zeros((B, T, self.n), **f64)
         else:
             x, u, lam = torch.empty((B, T + 1, self.n), **f64), torch.empty((B, T, self.m), **f64), torch.empty((B, T, self.n), **f64)
         cost, resid = torch.empty((B,), **f64), torch.empty((B, 2), **f64)
@@ -351,7 +357,7 @@ class ModelLib:
         nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T, int(max_iter))
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
-        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2), int(log_rows))
+        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0), int(log_rows))
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}

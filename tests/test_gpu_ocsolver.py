@@ -184,6 +184,34 @@ def test_ms_kernel_restoration_follows_the_oracle(golden_dir):
     assert not bool(off["converged"].any()) and (off["status"].cpu().numpy() == 4).all() and (off["iterations"].cpu().numpy() == 8).all()
 
 
+def test_ms_kernel_from_controls_follows_the_oracle_at_a_long_horizon(golden_dir):
+    """PDP_MS_FROM_CONTROLS: the solve starts from a control guess alone - states from the rollout (the restoration pass, here over a horizon of more than one
+    64-stage block), multipliers from the least-squares estimate - and from there follows the restatement started the same way (oracle/ipopt_ms.py: u_init)
+    iteration by iteration; rocket landing, T = 100, hover-thrust guess."""
+    from oracle import ipopt_ms, models, pdp_oracle as po
+    from pdp_amd import zoo
+    d = load(golden_dir, "demos_rocket.npz")
+    st = models.IRL_SETUP["rocket"]
+    oc = po.make_oc(models.REGISTRY["rocket"](**st["kwargs"]), st["dt"])
+    T = 100
+    rng = np.random.default_rng(11)
+    u0 = np.tile(np.array([9.0, 0.0, 0.0]), (T, 1)) + 0.05 * rng.standard_normal((T, 3))
+    log = []
+    ref = ipopt_ms.solve(oc, d["state"][0, 0], T, d["true_parameter"], tol=1e-10, log=log, u_init=u0)
+    mdl = zoo.get("rocket", "irl")
+    B = 3
+    sol = mdl.oc_solve_ms(np.repeat(d["state"][:1, 0], B, axis=0), d["true_parameter"], T, tol=1e-10, log_rows=len(log) + 4, u_init=np.repeat(u0[None], B, axis=0))
+    assert bool(sol["converged"].all()) and (sol["iterations"].cpu().numpy() == ref["iterations"]).all() and ref["iterations"] == len(log)
+    kl = sol["log"][B - 1].cpu().numpy()
+    for r, l in zip(kl, log):
+        assert r[5] == l["alpha"] and abs(r[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (l["it"], r[4], r[5], l["dw"], l["alpha"])
+        assert abs(r[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
+    assert log[0]["inf_pr"] <= 1e-12                                           # the starting point is the rollout: feasible
+    sc = lambda a: max(1.0, np.abs(a).max())
+    for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+        assert np.abs(sol[k].cpu().numpy() - ref[kr][None]).max() <= 1e-8 * sc(ref[kr])
+
+
 def test_ms_kernel_warm_start_gains_and_per_sample_parameters(golden_dir):
     """256 cart-pole problems with per-sample parameters (BASELINE config C2): cold solve, then a warm start (PDP_MS_WARM) from that
     solution at perturbed parameters converges in a few iterations to a KKT point of the new problem; the gains output drives a
