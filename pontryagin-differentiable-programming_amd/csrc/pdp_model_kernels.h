@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 if constexpr (SMALL) {
                     SmallGains g;
                     double Pr = P[0], Wr = W2[0];
-                    ok = riccati_small_backward<M>(Pr, Wr, Fu[0], Yu[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux[0], lane, tlane, NP, g) && ok;
+                    ok = riccati_small_backward<M, true>(Pr, Wr, Fu[0], Yu[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux[0], lane, tlane, NP, g) && ok;
                     P[0] = Pr; W2[0] = Wr;
                     d4 Kt = z, IKt = z;
                     Kt[0] = (lane & 12) == 0 ? g.K : 0.0;      // K arrives in rep form: its first column block is K [NU x NX]; the replicas must not

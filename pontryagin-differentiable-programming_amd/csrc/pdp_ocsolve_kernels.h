@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(64) oc_solve_ms_kernel(int B, int T, pdp_oc_ms
                     store_all<1>(pw + t * PWSZ + NX * NX, mW, W2);
                     SmallGains g;
                     double Pr = P[0], Wr = W2[0];
-                    ok = riccati_small_backward<M>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, g) && ok;
+                    ok = riccati_small_backward<M, true>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, g) && ok;
                     P[0] = Pr; W2[0] = Wr;
                     pdall = pdall && g.pd;
                     d4 Kt = z, IKt = z;

@@ -32,7 +32,11 @@ struct SmallGains {
 // One backward step for ONE trajectory (one register of each packed tile).  Prep: P in rep form (symmetric), W2: [0 | W].
 // Frep, Hxxrep: rep form; Y2 = [G | E], HX2 = [Hxu | Hxe], HU2 = [Huu | Hue] (rows < m): R4; Grep: lane (k, 4b + i) = G[k][i] (i < m);
 // Huxrep: lane (i, 4b + k) = Hxu[k][i] (i < m).  Returns false on a vanishing / non-finite pivot of the m x m system.
-template <int M>
+// TSYM: how P- is symmetrised.  false: (P- + shuffle-transposed P-)/2 - two ds_bpermute round trips at the end of the step's dependency chain.  true: the transpose is
+// COMPUTED beside P-, (Pn - Qux'K)' = (Hxx + (PF)'F) - K'Qux, two more small MFMAs that run in the shadow of the ones they mirror - the same products summed in the same
+// order, so with a bitwise symmetric Hxx (generated Hessians: the two halves share one pool slot) the result is bit-identical to the shuffle's; callers whose
+// Hxx is user data (lqr_solve_small_kernel) keep the shuffle, which is symmetric whatever it is given.
+template <int M, bool TSYM = false>
 PDP_DEV bool riccati_small_backward(double& Prep, double& W2, double Frep, double Y2, double Grep, double Hxxrep, double HX2, double HU2, double Huxrep,
                                     int lane, int tlane, int p0, SmallGains& g) {
     static_assert(M >= 1 && M <= 4, "the small-system algebra keeps the m x m control block in rows 0..3 of a tile: m <= 4");
@@ -84,7 +88,12 @@ PDP_DEV bool riccati_small_backward(double& Prep, double& W2, double Frep, doubl
     const bool pcol = col >= M && col < M + p0;
     W2 = pcol ? Wn : 0.0;                                 // the control columns are zero only up to rounding: masked (see pdp_riccati.h)
     g.IK = pcol ? IK : 0.0;
-    Prep = 0.5 * (Pm + small_transpose(Pm, tlane));       // P <- (P + P')/2: the skew rounding error would be amplified step by step
+    // P <- (P + P')/2: the skew rounding error would be amplified step by step
+    if constexpr (TSYM) {
+        const double PnT = mma4_blk(PF, Frep, Hxxrep);    // Hxx + (P F)' F = Pn'
+        const double PmT = mma4_blk(-g.K, Qux, PnT);      // Pn' - K' Qux = (Pn - Qux' K)'
+        Prep = 0.5 * (Pm + PmT);
+    } else Prep = 0.5 * (Pm + small_transpose(Pm, tlane));
     return ok;
 }
 

@@ -281,7 +281,10 @@ PDP_DEV bool inverse_small_fast(const double* a, double* inv) {
         c[14] = -a[12] * s3 + a[13] * s1 - a[14] * s0; c[15] = a[8] * s3 - a[9] * s1 + a[10] * s0;
     }
     if (!(fabs(det) > 1e-10 * fabs(dprod)) || !(fabs(det) <= 1.7e308)) return inverse_small<M>(a, inv);   // ill-conditioned / singular: pivoted path
-    const double id = 1.0 / det;
+    // 1 / det: hardware reciprocal + one Newton step - the IEEE division sequence is a 12-instruction dependent chain in the middle of every backward step, and det
+    // (guarded above against vanishing / overflowing) is nowhere near the ranges that sequence exists for; same form as the 4 x 4 path of riccati_backward
+    double id = __builtin_amdgcn_rcp(det);
+    id = fma(fma(-det, id, 1.0), id, id);
 #pragma unroll
     for (int i = 0; i < M * M; ++i) inv[i] = c[i] * id;
     return true;
