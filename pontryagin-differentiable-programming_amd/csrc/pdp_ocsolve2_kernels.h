@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     } else if constexpr (SMALL) {
                         SmallGains gs;
                         double Pr = P[0], Wr = W2[0];
-                        ok = riccati_small_backward<M>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, gs) && ok;
+                        ok = riccati_small_backward<M, true>(Pr, Wr, Fc[0], Ys[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux0, lane, tlane, 1, gs) && ok;
                         P[0] = Pr; W2[0] = Wr;
                         pdall = pdall && gs.pd;
                         d4 Kt = z, IKt = z;
