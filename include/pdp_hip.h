@@ -36,6 +36,8 @@ extern "C" {
 
 #define PDP_STATUS_NONFINITE 1
 #define PDP_STATUS_PIVOT 2
+#define PDP_STATUS_INDEFINITE 256 /* pdp_lqr_solve_batched, generic kernel (n > 16 or m > 4) only: some Quu_t = Huu + G'PG of the sweep is not positive definite - the result is
+                                     the stationary point of the LQ problem, not its minimiser (the inertia test of the multiple-shooting OC route for large systems) */
 
 /* library identification: returns a static string "pdp_hip <version> gfx950" */
 const char* pdp_hip_version(void);
@@ -134,6 +136,13 @@ int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, cons
 int pdp_oc_rollout_feedback_batched(int B, int T, const double* x0, const double* ubar, const double* xbar, const double* gains,
                                     const double* alpha, const double* theta, int theta_bstride, double* x, double* u, double* cost,
                                     void* stream);
+
+/* Residuals of ocSolver's multiple-shooting NLP (PDP.py:131-182) at a point (x, u, lam), lam[t] = multiplier of f(x_t,u_t) - x_{t+1}: defects c [B][T][n],
+ * Lagrangian gradients rx [B][T+1][n] (node 0: 0 - x_0 is fixed; 0 < t < T: H_x(x_t,u_t,lam_t) - lam_{t-1}; T: h_x(x_T) - lam_{T-1}) and ru [B][T][m] = H_u,
+ * stage costs cost [B][T+1] (final cost at T).  Size-generic (any n, m): with pdp_oc_auxsys_batched and pdp_lqr_solve_batched the building block of the
+ * kernel-by-kernel multiple-shooting route for problems beyond the solver kernel's n <= 16, m <= 4 (ocsolver.solve_batch_ms_generic). */
+int pdp_oc_ms_residuals_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta, int theta_bstride,
+                                double* c, double* rx, double* ru, double* cost, void* stream);
 
 /* PMP costate recursion, ocSolver costate_option=1 (PDP.py:199-209): lam[T-1] = h_x(x_T),
  * lam[k-1] = c_x(x_k,u_k) + f_x(x_k,u_k)^T lam[k].  lam [B][T][n] with lam[t] = lambda_{t+1}. */

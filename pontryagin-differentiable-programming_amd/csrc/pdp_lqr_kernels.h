@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
 // ---------------------------------------------------------------------------------------------------------------------------------------
 constexpr int GEN_NMAX = 32, GEN_MMAX = 8, GEN_PMAX = 32;
 __host__ __device__ inline size_t lqr_generic_lds_doubles(int n, int m, int p) {
-    return (size_t)3 * n * n + (size_t)2 * n * p + (size_t)n * m + (size_t)m * (m + n + p) + (size_t)m * n + (size_t)m * p + 2 * (size_t)n * p + 8;
+    return (size_t)3 * n * n + (size_t)2 * n * p + (size_t)n * m + (size_t)m * (m + n + p) + (size_t)m * n + (size_t)m * p + 2 * (size_t)n * p + 8 + (size_t)GEN_MMAX * GEN_MMAX;
 }
 
 __global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo, double* __restrict__ Lo,
@@ -407,8 +407,9 @@ __global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem p
     double* kk = Kk + m * n;
     double* Xc = kk + m * p;         // n x p  (forward state)
     double* Xn = Xc + n * p;
+    double* Sq = Xn + n * p + 8;     // m x m: copy of Quu for the definiteness test
     const int gsz = n * m + m * p, pwsz = n * n + n * p;
-    bool ok = true, finite = true;
+    bool ok = true, finite = true, posdef = true;
     const double* hxx = mat_at(pr.hxx, b, 0);
     const double* hxe = mat_at(pr.hxe, b, 0);
     for (int q = lane; q < n * n; q += 64) P[q] = hxx[q];
@@ -439,7 +440,20 @@ __global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem p
         wave_lds_sync();
         // keep Qux' for the corrections: PG is free now -> Qux (m x n) copy in Kk ... the elimination turns A's Qux block into K
         for (int q = lane; q < m * n; q += 64) Kk[q] = A[(q / n) * wa + m + (q % n)];
+        for (int q = lane; q < m * m; q += 64) Sq[q] = 0.5 * (A[(q / m) * wa + (q % m)] + A[(q % m) * wa + (q / m)]);
         wave_lds_sync();
+        // Quu positive definite?  Pivots of the unpivoted elimination of its symmetric part (every lane runs the same m^3 / 3 operations on the LDS copy; the
+        // writes of different lanes carry identical values)
+        for (int c = 0; c < m; ++c) {
+            const double d = Sq[c * m + c];
+            posdef = posdef && d > 0.0;
+            const double id = 1.0 / d;
+            for (int r = c + 1; r < m; ++r) {
+                const double f = Sq[r * m + c] * id;
+                for (int j = c + 1; j < m; ++j) Sq[r * m + j] -= f * Sq[c * m + j];
+            }
+            wave_lds_sync();
+        }
         for (int c = 0; c < m; ++c) {                       // Gauss-Jordan with partial pivoting (uniform control flow)
             int piv = c;
             double best = fabs(A[c * wa + c]);
@@ -514,6 +528,7 @@ __global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem p
     int st = 0;
     if (!__all(finite)) st |= PDP_STATUS_NONFINITE;
     if (!ok) st |= PDP_STATUS_PIVOT;
+    if (!posdef) st |= PDP_STATUS_INDEFINITE;
     if (lane == 0 && status) status[b] = st;
 }
 

@@ -72,6 +72,17 @@ int oc_rollout_fb(int B, int T, const double* x0, const double* ubar, const doub
     } else { return PDP_E_MODE; }
 }
 template <class Mdl>
+int oc_ms_residuals(int B, int T, const double* x, const double* u, const double* lam, const double* th, int tb, double* c, double* rx, double* ru, double* cost,
+                    void* st) {
+    if constexpr (Mdl::KIND == PDP_KIND_OC) {
+        if (B <= 0 || T <= 0 || !x || !u || !lam || !th || !c || !rx || !ru || !cost) return PDP_E_ARG;
+        PDP_CLEAR();
+        const int64_t nthr = (int64_t)B * (T + 1);
+        hipLaunchKernelGGL((oc_ms_residuals_kernel<Mdl>), dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, S(st), B, T, x, u, lam, th, tb, c, rx, ru, cost);
+        return launched();
+    } else return PDP_E_MODE;
+}
+template <class Mdl>
 int oc_costate(int B, int T, const double* x, const double* u, const double* th, int tb, double* lam, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_OC) {
         if (B <= 0 || T <= 0 || !x || !u || !th || !lam) return PDP_E_ARG;
@@ -433,6 +444,10 @@ int pdp_oc_rollout_batched(int B, int T, const double* x0, const double* u, cons
 int pdp_oc_rollout_feedback_batched(int B, int T, const double* x0, const double* ubar, const double* xbar, const double* gains, const double* alpha,
                                     const double* theta, int tb, double* x, double* u, double* cost, void* stream) {
     return oc_rollout_fb<PdpModel>(B, T, x0, ubar, xbar, gains, alpha, theta, tb, x, u, cost, stream);
+}
+int pdp_oc_ms_residuals_batched(int B, int T, const double* x, const double* u, const double* lam, const double* theta, int tb, double* c, double* rx,
+                                double* ru, double* cost, void* stream) {
+    return oc_ms_residuals<PdpModel>(B, T, x, u, lam, theta, tb, c, rx, ru, cost, stream);
 }
 int pdp_oc_costate_batched(int B, int T, const double* x, const double* u, const double* theta, int tb, double* lam, void* stream) {
     return oc_costate<PdpModel>(B, T, x, u, theta, tb, lam, stream);

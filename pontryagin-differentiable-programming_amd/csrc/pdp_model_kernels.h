@@ -169,6 +169,59 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
     }
 }
 
+// Residuals of the multiple-shooting NLP of OCSys.ocSolver (reference PDP/PDP.py:131-182) at a point (x, u, lam), lam[t] = multiplier of f(x_t, u_t) - x_{t+1}:
+//     c [B][T][n]      defects f(x_t, u_t) - x_{t+1}
+//     rx [B][T+1][n]   grad_x of the Lagrangian: node 0: 0 (x_0 is fixed), node 0 < t < T: H_x(x_t, u_t, lam_t) - lam_{t-1}, node T: h_x(x_T) - lam_{T-1}
+//     ru [B][T][m]     H_u(x_t, u_t, lam_t)
+//     cost [B][T+1]    path cost of stage t, final cost at T
+// One lane per (trajectory, node): size-generic (any n, m the model has), the building block of the kernel-by-kernel multiple-shooting route for problems
+// beyond the solver kernels' tiles (ocsolver.solve_batch_ms_generic); same quantities as the trial pass of oc_solve_ms2_kernel.
+template <class Mdl>
+__global__ void oc_ms_residuals_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ lam,
+                                       const double* __restrict__ theta, int tb, double* __restrict__ c, double* __restrict__ rx, double* __restrict__ ru,
+                                       double* __restrict__ cost) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * (T + 1)) return;
+    const int b = (int)(idx / (T + 1)), t = (int)(idx - (int64_t)b * (T + 1));
+    double th[Mdl::NP > 0 ? Mdl::NP : 1];
+    load_theta<Mdl>(theta, b, tb, th);
+    double pc[Mdl::NPC];
+    Mdl::precompute(th, pc);
+    const double* xb = x + ((int64_t)b * (T + 1) + t) * NX;
+    double xc[NX], v[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = xb[i];
+    double* rxb = rx + ((int64_t)b * (T + 1) + t) * NX;
+    if (t < T) {
+        const double* ub = u + ((int64_t)b * T + t) * NU;
+        const double* lb = lam + ((int64_t)b * T + t) * NX;
+        double uc[NU], lc[NX], hu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uc[i] = ub[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lc[i] = lb[i];
+        Mdl::dyn(xc, uc, th, pc, v);
+        double* cb = c + ((int64_t)b * T + t) * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) cb[i] = v[i] - xb[NX + i];
+        Mdl::costate_step(xc, uc, lc, th, pc, v);               // c_x + f_x' lam_t = H_x
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rxb[i] = t > 0 ? v[i] - lb[i - NX] : 0.0;
+        Mdl::dHu(xc, uc, lc, th, pc, hu);
+        double* rub = ru + ((int64_t)b * T + t) * NU;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) rub[i] = hu[i];
+        cost[(int64_t)b * (T + 1) + t] = Mdl::path_cost(xc, uc, th, pc);
+    } else {
+        Mdl::dhx(xc, th, pc, v);
+        const double* lb = lam + ((int64_t)b * T + (T - 1)) * NX;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rxb[i] = v[i] - lb[i];
+        cost[(int64_t)b * (T + 1) + T] = Mdl::final_cost(xc, th, pc);
+    }
+}
+
 // OCSys.getAuxSys, materialised.  One wavefront per (trajectory, chunk of CHUNK time steps): lane = time step evaluates the
 // generated code into the packed LDS pool (as in the fused kernel), then the wave expands every matrix family into the dense
 // API layout [B][T][rows][cols] with COALESCED stores - the chunk's slice of a family is one contiguous run of cnt*rows*cols

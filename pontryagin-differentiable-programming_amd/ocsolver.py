@@ -77,7 +77,18 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
     torch = runtime.torch_cuda()
-    big = oc.model().n > 16 or oc.model().m > 4          # beyond the multiple-shooting kernel's tiles: single shooting on the generic LQ kernel
+    big = oc.model().n > 16 or oc.model().m > 4          # beyond the multiple-shooting kernel's tiles
+    if big and method != "single" and u_init is None and warm_start is None and oc.model().n <= 32 and oc.model().m <= 8:
+        # the same NLP and iteration, kernel by kernel (solve_batch_ms_generic); what it leaves unconverged goes on to single shooting below
+        ms = solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, print_level=print_level)
+        if bool(ms["converged"].all()) or method == "ms":
+            sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
+                   "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
+            if want_gains:                                   # (the LQR gains of the last Newton step are not kept on this route: single-shooting refinement provides them)
+                sub = solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=ms["control"], tol=tol, max_iter=max_iter, print_level=print_level,
+                                                  neighbor_retries=0, want_gains=True)
+                sol["gains"] = sub["gains"]
+            return sol
     if method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start):
         return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
                                            neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)
@@ -113,6 +124,171 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
         sol["status"][idx] = 0                                 # the multiple-shooting status bits no longer describe these rows
         sol["iterations"] += int(sub["iterations"])
     return sol
+
+
+def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, print_level=0, restoration=True, log_rows=0):
+    """The multiple-shooting NLP of OCSys.ocSolver (PDP.py:131-182) iterated the way IPOPT does - the algorithm of pdp_oc_solve_ms_batched and of its CPU restatement
+    oracle/ipopt_ms.py - for problems BEYOND that kernel's tiles (16 < n <= 32 or 4 < m <= 8), kernel by kernel: residuals of the NLP (pdp_oc_ms_residuals_batched),
+    KKT matrices (pdp_oc_auxsys_batched), the Newton step as an LQ problem with one affine column on the generic LQR kernel (pdp_lqr_solve_batched, whose status
+    reports whether every Quu was positive definite = the inertia test), the restoration by rollout (pdp_oc_rollout_batched).  Only IPOPT's bookkeeping - inertia
+    correction schedule, filter, step lengths, per sample - is tensor arithmetic here.  Several launches per iteration: a route for sizes the fast kernel does not
+    take (before round 3 these problems were solved by single shooting, i.e. a different iterate path), not a fast path.
+    Returns the dict of ModelLib.oc_solve_ms (status bits PDP_MS_*; log [B, log_rows, 8] with log_rows > 0)."""
+    torch = runtime.torch_cuda()
+    mdl = oc.model()
+    n, m, T = mdl.n, mdl.m, int(horizon)
+    x0 = runtime.dev(ini_state).reshape(-1, n)
+    B = x0.shape[0]
+    th = oc._theta(auxvar_value, B)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    x, u, lam = torch.zeros((B, T + 1, n), **f64), torch.zeros((B, T, m), **f64), torch.zeros((B, T, n), **f64)       # w0 = 0 (PDP.py:155,166) ...
+    x[:, 0] = x0                                                                                                      # ... x_0 = ini_state
+    eye_n, eye_m = torch.eye(n, **f64), torch.eye(m, **f64)
+    G_TH, G_PH, EPS = 1e-5, 1e-8, 2.220446049250313e-16                                                               # gamma_theta, gamma_phi (IPOPT defaults)
+
+    def resid(x_, u_, l_):
+        r = mdl.oc_ms_residuals(x_, u_, l_, th)
+        r["f"], r["theta"], r["inf_pr"] = r["cost"].sum(1), r["c"].abs().sum((1, 2)), r["c"].abs().amax((1, 2))
+        r["inf_du"] = torch.maximum(r["rx"].abs().amax((1, 2)), r["ru"].abs().amax((1, 2)))
+        return r
+
+    def matrices(x_, u_, l_):
+        return mdl.oc_auxsys(x_, u_, l_, th, only=("dynF", "dynG", "Hxx", "Hxu", "Huu", "hxx"))
+
+    def kkt(A, r, dw, ls=False):
+        """Newton step of the KKT system [W + dw I, A'; A, 0] as the LQ problem with affine terms; ls: the least-squares multiplier estimate (W = I, no defects)."""
+        if ls:
+            Hxx, Huu, Hxu, hxx, E = eye_n.expand(B, T, n, n).contiguous(), eye_m.expand(B, T, m, m).contiguous(), None, eye_n.expand(B, n, n).contiguous(), None
+        else:
+            Hxx, Huu, Hxu = A["Hxx"] + dw.view(B, 1, 1, 1) * eye_n, A["Huu"] + dw.view(B, 1, 1, 1) * eye_m, A["Hxu"]
+            hxx, E = A["hxx"] + dw.view(B, 1, 1) * eye_n, r["c"].unsqueeze(-1).contiguous()
+        X, U, L, st = runtime.lqr_solve(A["dynF"], A["dynG"], Hxx, Huu, hxx, r["rx"][:, T].unsqueeze(-1).contiguous(), E=E, Hxu=Hxu,
+                                        Hxe=r["rx"][:, :T].unsqueeze(-1).contiguous(), Hue=r["ru"].unsqueeze(-1).contiguous(), T=T)
+        return X[..., 0], U[..., 0], L[..., 0], (st & (256 | 2 | 1)) == 0
+
+    def put(dst, src, mask):
+        dst.copy_(torch.where(mask.view(-1, *([1] * (dst.dim() - 1))), src, dst))
+
+    def ls_multipliers(x_, u_, r):
+        _, _, l0, _ = kkt(matrices(x_, u_, torch.zeros_like(lam)), r, None, ls=True)
+        good = torch.isfinite(l0).all(dim=(1, 2)) & (l0.abs().amax((1, 2)) <= 1000.0)                                # constr_mult_init_max
+        return torch.where(good.view(B, 1, 1), l0, torch.zeros_like(l0))
+
+    r = resid(x, u, lam)
+    lam = ls_multipliers(x, u, r)
+    r = resid(x, u, lam)
+    theta_max, theta_min = 1e4 * r["theta"].clamp(min=1.0), 1e-4 * r["theta"].clamp(min=1.0)
+    K = max_iter + 2
+    fth, fph, nf = torch.zeros((B, K), **f64), torch.zeros((B, K), **f64), torch.zeros((B,), dtype=torch.int64, device="cuda")
+    kidx = torch.arange(K, device="cuda").view(1, K)
+    conv, status = torch.zeros((B,), dtype=torch.bool, device="cuda"), torch.zeros((B,), dtype=torch.int32, device="cuda")
+    restored = torch.zeros_like(conv)
+    iters, dw_last = torch.zeros((B,), dtype=torch.int32, device="cuda"), torch.zeros((B,), **f64)
+    log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
+    rkeys = ("c", "rx", "ru", "cost", "f", "theta", "inf_pr", "inf_du")
+
+    def filter_add(mask, theta, f):
+        rows = torch.nonzero(mask).flatten()
+        fth[rows, nf[rows]] = (1.0 - G_TH) * theta[rows]
+        fph[rows, nf[rows]] = f[rows] - G_PH * theta[rows]
+        nf[rows] += 1
+
+    for it in range(max_iter + 1):
+        active = ~conv & (status == 0)
+        scale = 1.0 + torch.maximum(x.abs().amax((1, 2)), u.abs().amax((1, 2)))
+        lscale = 1.0 + lam.abs().amax((1, 2))
+        fin = torch.isfinite(r["f"]) & torch.isfinite(r["inf_pr"]) & torch.isfinite(r["inf_du"])
+        status = torch.where(active & ~fin, status | 1, status)                                                      # PDP_STATUS_NONFINITE
+        conv = conv | (active & fin & (r["inf_pr"] <= tol * scale) & (r["inf_du"] <= tol * lscale))
+        active = ~conv & (status == 0)
+        if not bool(active.any()):
+            break
+        if it == max_iter:
+            status = torch.where(active, status | 8, status)                                                         # PDP_MS_MAXITER
+            break
+        iters = torch.where(active, iters + 1, iters)
+        # ---- search direction with inertia correction (Algorithm IC), every sample on its own dw
+        dw, need = torch.zeros((B,), **f64), active.clone()
+        dx, du, dl = torch.zeros_like(x), torch.zeros_like(u), torch.zeros_like(lam)
+        A = matrices(x, u, lam)
+        while True:
+            X, U, L, ok = kkt(A, r, dw)
+            got = need & ok
+            put(dx, X, got); put(du, U, got); put(dl, L, got)
+            need = need & ~ok
+            if not bool(need.any()):
+                break
+            first = dw_last == 0.0
+            dw_new = torch.where(dw == 0.0, torch.where(first, torch.full_like(dw, 1e-4), (dw_last / 3.0).clamp(min=1e-20)), dw * torch.where(first, 100.0, 8.0))
+            dw = torch.where(need, dw_new, dw)
+            dead = need & (dw > 1e20)
+            status = torch.where(dead, status | 16, status)                                                          # PDP_MS_INERTIA
+            need = need & ~dead
+            if not bool(need.any()):
+                break
+        active = active & (status == 0)
+        dw_last = torch.where(active & (dw > 0.0), dw, dw_last)
+        gd = (r["rx"] * dx).sum((1, 2)) + (r["ru"] * du).sum((1, 2)) + (lam * r["c"]).sum((1, 2))                     # grad phi' d = rd' d + lam' c   (A d = -c)
+        # ---- backtracking filter line search (Algorithm A)
+        f, theta = r["f"], r["theta"]
+        neg = gd < 0.0
+        ngd = (-gd).clamp(min=1e-300)
+        amin = torch.where(neg, torch.minimum(torch.full_like(gd, G_TH), G_PH * theta / ngd), torch.full_like(gd, G_TH))
+        amin = torch.where(neg & (theta <= theta_min), torch.minimum(amin, theta ** 1.1 / ngd ** 2.3), amin) * 0.05
+        alpha, searching = torch.ones((B,), **f64), active.clone()
+        accepted, ftype = torch.zeros_like(conv), torch.zeros_like(conv)
+        xn, un, ln = x.clone(), u.clone(), lam.clone()
+        rn = {k: r[k].clone() for k in rkeys}
+        while bool(searching.any()):
+            a3 = alpha.view(B, 1, 1)
+            xt, ut, lt = x + a3 * dx, u + a3 * du, lam + a3 * dl
+            rt = resid(xt, ut, lt)
+            ft, tht = rt["f"], rt["theta"]
+            dominated = ((kidx < nf.view(B, 1)) & (tht.view(B, 1) >= fth) & (ft.view(B, 1) >= fph)).any(dim=1)
+            okf = torch.isfinite(ft) & torch.isfinite(tht) & (tht <= theta_max) & ~dominated
+            switching = neg & (alpha * ngd ** 2.3 > theta ** 1.1)
+            c1 = (theta <= theta_min) & switching
+            acc = searching & okf & torch.where(c1, ft <= f + 1e-8 * alpha * gd + 10.0 * EPS * f.abs(), (tht <= (1.0 - G_TH) * theta) | (ft <= f - G_PH * theta))
+            put(xn, xt, acc); put(un, ut, acc); put(ln, lt, acc)
+            for k in rkeys:
+                put(rn[k], rt[k], acc)
+            ftype, accepted = ftype | (acc & c1), accepted | acc
+            searching = searching & ~acc
+            alpha = torch.where(searching, alpha * 0.5, alpha)
+            searching = searching & (alpha >= amin) & (alpha > 1e-300)
+        if log is not None and it < log_rows:
+            row = torch.stack([torch.full_like(f, float(it)), f, r["inf_pr"], r["inf_du"], dw, torch.where(accepted, alpha, torch.zeros_like(alpha)), gd, theta], dim=1)
+            log[:, it] = torch.where(active.view(B, 1), row, log[:, it])
+        failed = active & ~accepted
+        filter_add(accepted & ~ftype, theta, f)
+        x, u, lam, r = xn, un, ln, rn
+        if bool(failed.any()):
+            # ---- restoration (oracle/ipopt_ms.py: solve; include/pdp_hip.h): current point into the filter, states <- rollout of the controls, multipliers reset
+            can = failed & (theta > 0.0) if restoration else torch.zeros_like(failed)
+            status = torch.where(failed & ~can, status | 4, status)                                                   # PDP_MS_RESTORATION
+            if bool(can.any()):
+                filter_add(can, theta, f)
+                xr, _ = mdl.oc_rollout(x0, u, th, want_cost=False)
+                finr = torch.isfinite(xr).all(dim=(1, 2))
+                status = torch.where(can & ~finr, status | 4, status)
+                can = can & finr
+                put(x, xr, can)
+                put(lam, torch.zeros_like(lam), can)
+                r0 = resid(x, u, lam)
+                l0 = ls_multipliers(x, u, r0)
+                put(lam, l0, can)
+                r1 = resid(x, u, lam)
+                for k in rkeys:
+                    put(r[k], r1[k], can)
+                restored = restored | can
+        if print_level > 0:
+            print("  ms-generic iteration %3d: %d / %d converged" % (it, int(conv.sum()), B))
+    status = torch.where(restored, status | 128, status)                                                             # PDP_MS_RESTORED (informational)
+    out = {"state": x, "control": u, "costate": lam, "cost": r["f"], "resid": torch.stack([r["inf_pr"], r["inf_du"]], dim=1), "converged": conv,
+           "iterations": iters, "status": status}
+    if log is not None:
+        out["log"] = log
+    return out
 
 
 def solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,

@@ -50,7 +50,8 @@ class PdpPolicy(C.Structure):
 
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
                 "pdp_sysid_aux_integrate_batched"]
-MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_auxsys_batched",
+MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_ms_residuals_batched",
+                 "pdp_oc_auxsys_batched",
                  "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched", "pdp_oc_solve_ms_workspace_bytes", "pdp_oc_solve_ms_batched",
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
@@ -222,6 +223,7 @@ _MODEL_SIGS = {
     "pdp_model_get_info": (None, [C.POINTER(PdpModelInfo)]),
     "pdp_oc_rollout_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pdp_oc_costate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pdp_oc_ms_residuals_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "pdp_oc_rollout_feedback_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_oc_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _VP, _I, C.POINTER(PdpOcAuxsys), _VP]),
     "pdp_oc_solve_workspace_bytes": (_I64, [_I, _I, _I]),
@@ -375,6 +377,20 @@ class ModelLib:
         lam = torch.empty((B, T, self.n), dtype=torch.float64, device="cuda")
         check(self.lib.pdp_oc_costate_batched(B, T, ptr(x), ptr(u), ptr(th), tb, ptr(lam), current_stream_ptr()), "pdp_oc_costate_batched")
         return lam
+
+    def oc_ms_residuals(self, x, u, lam, theta):
+        """Residuals of ocSolver's multiple-shooting NLP at (x, u, lam) (pdp_oc_ms_residuals_batched): dict(c [B,T,n] defects, rx [B,T+1,n], ru [B,T,m] Lagrangian
+        gradients, cost [B,T+1] stage costs with the final cost last)."""
+        torch = torch_cuda()
+        x, u, lam = dev(x), dev(u), dev(lam)
+        B, T = u.shape[0], u.shape[1]
+        th, tb = self._theta(theta, B)
+        f64 = dict(dtype=torch.float64, device="cuda")
+        out = {"c": torch.empty((B, T, self.n), **f64), "rx": torch.empty((B, T + 1, self.n), **f64), "ru": torch.empty((B, T, self.m), **f64),
+               "cost": torch.empty((B, T + 1), **f64)}
+        check(self.lib.pdp_oc_ms_residuals_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, ptr(out["c"]), ptr(out["rx"]), ptr(out["ru"]), ptr(out["cost"]),
+                                                   current_stream_ptr()), "pdp_oc_ms_residuals_batched")
+        return out
 
     def oc_auxsys(self, x, u, lam, theta, only=None):
         """materialised OCSys.getAuxSys; `only` = iterable of keys to produce (others are skipped), may include 'dHu'"""

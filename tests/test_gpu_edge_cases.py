@@ -334,6 +334,74 @@ def test_user_model_with_20_states_runs_the_whole_class_surface():
     assert np.abs(F0[:, 3] - fd).max() < 1e-8
 
 
+def _mass_chain(nm, m, dt, lib):
+    """the mass chain of the test above in a symbolic library `lib` with the calls both have (pdp_amd.sx for the product, sympy for the oracle)"""
+    if lib == "sx":
+        from pdp_amd.sx import SX, vertcat, dot
+        q, v, U, w = SX.sym("q", nm), SX.sym("v", nm), SX.sym("u", m), SX.sym("w", 6)
+        qs, vs, us, ws = [q[i] for i in range(nm)], [v[i] for i in range(nm)], [U[i] for i in range(m)], [w[i] for i in range(6)]
+    else:
+        import sympy as sp
+        qs, vs, us, ws = (list(sp.symbols("%s0:%d" % (nme, k), real=True)) for nme, k in (("q", nm), ("v", nm), ("u", m), ("w", 6)))
+    acc = []
+    for i in range(nm):
+        left = qs[i - 1] if i > 0 else 0.0
+        right = qs[i + 1] if i + 1 < nm else 0.0
+        a = ws[0] * (left - 2 * qs[i] + right) - ws[1] * vs[i] - 0.3 * qs[i] * qs[i] * qs[i]
+        if i % 2 == 0:
+            a = a + us[i // 2]
+        acc.append(a)
+    sq = lambda xs: sum((z * z for z in xs[1:]), xs[0] * xs[0])
+    path, final = ws[2] * sq(qs) + ws[3] * sq(vs) + ws[4] * sq(us), ws[5] * sq(qs)
+    f = [qs[i] + dt * vs[i] for i in range(nm)] + [vs[i] + dt * acc[i] for i in range(nm)]
+    return qs + vs, us, ws, f, path, final
+
+
+def test_multiple_shooting_route_for_20_states_follows_the_oracle():
+    """ocSolver for n = 20, m = 5 (beyond the solver kernel's tiles) runs the SAME multiple-shooting iteration kernel by kernel - NLP residuals
+    (pdp_oc_ms_residuals_batched), KKT matrices (pdp_oc_auxsys_batched), Newton step on the generic LQR kernel with its positive-definiteness report
+    (PDP_STATUS_INDEFINITE), IPOPT's bookkeeping on tensors (ocsolver.solve_batch_ms_generic) - and follows the CPU restatement of IPOPT's algorithm
+    (oracle/ipopt_ms.py) iteration by iteration: same inertia corrections, same step lengths, same solution.  Before round 3 these sizes were handed to single shooting."""
+    import sympy as sp
+    from oracle import ipopt_ms, pdp_oracle as po
+    from pdp_amd import PDP, ocsolver
+    from pdp_amd.sx import vertcat
+    nm, m, dt, B = 10, 5, 0.05, 3
+    X, U, w, f, path, final = _mass_chain(nm, m, dt, "sx")
+    oc = PDP.OCSys("mass chain ms")
+    oc.setAuxvarVariable(vertcat(*w))
+    oc.setStateVariable(vertcat(*X))
+    oc.setControlVariable(vertcat(*U))
+    oc.setDyn(vertcat(*f))
+    oc.setPathCost(path)
+    oc.setFinalCost(final)
+    Xs, Us, ws_, fs, paths, finals = _mass_chain(nm, m, dt, "sympy")
+    ref_oc = po.OCSysOracle(sp.Matrix(Xs), sp.Matrix(Us), list(ws_), sp.Matrix(fs), paths, finals)
+    # (a) convex weights, far initial states: step lengths below 1 in the first iterations; (b) a negative state weight: inertia corrections on most iterations
+    seen_dw, seen_alpha = False, False
+    for scale, T, th in ((5.0, 30, np.array([2.0, 0.3, 1.0, 0.5, 0.2, 3.0])), (2.0, 25, np.array([2.0, 0.3, -2.0, 0.5, 0.02, 3.0]))):
+        rng = np.random.default_rng(5)
+        x0 = (scale * rng.standard_normal((B, 2 * nm)))[:2 if scale == 5.0 else B]
+        out = ocsolver.solve_batch_ms_generic(oc, x0, T, th, tol=1e-10, log_rows=40)
+        assert bool(out["converged"].all()) and int(out["status"].sum()) == 0
+        for b in range(x0.shape[0]):
+            log = []
+            ref = ipopt_ms.solve(ref_oc, x0[b], T, th, tol=1e-10, log=log)
+            assert int(out["iterations"][b]) == ref["iterations"] == len(log)
+            kl = npy(out["log"])[b]
+            for r_, l in zip(kl, log):
+                assert r_[5] == l["alpha"] and abs(r_[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (b, l["it"], r_[4], r_[5], l["dw"], l["alpha"])
+                assert abs(r_[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r_[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
+                seen_dw, seen_alpha = seen_dw or l["dw"] > 0.0, seen_alpha or l["alpha"] < 1.0
+            for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+                assert np.abs(npy(out[k])[b] - ref[kr]).max() <= 1e-8 * max(1.0, np.abs(ref[kr]).max())
+    assert seen_dw and seen_alpha
+    # the class surface takes this route for such sizes (and reports it as the multiple-shooting method)
+    sol = oc.ocSolver_batch(x0, T, th)
+    assert bool(sol["converged"].all()) and bool(sol["method_ms"].all())
+    assert float((sol["state"] - out["state"]).abs().max()) <= 1e-8
+
+
 def test_oc_solver_small_state_many_controls_takes_the_generic_lq_kernel():
     """n = 3 <= 4 but m = 5 > 4: the packed small-system LQ kernel keeps the m x m control block in four tile rows, so this shape must reach the
     generic LDS kernel (round-2 advisor finding: the dispatch looked at n alone and silently produced wrong Newton steps).  The problem is
