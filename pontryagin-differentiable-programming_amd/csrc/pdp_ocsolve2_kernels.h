@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         Hux0 = hs * Hux0;
                         }
                     }
-                    // P_{t+1}, W_{t+1}: the evaluator's multiplier step needs them (dlam_t = P_{t+1} dx_{t+1} + W_{t+1})
+                    // P_{t+1}, W_{t+1} (homogeneous form: P~_{t+1}): the multiplier step dlam_t = P_{t+1} dx_{t+1} + W_{t+1} of the forward sweep needs them
                     const unsigned soP = (unsigned)(t * PWSZ) * 8u, soG = (unsigned)(t * GSZ) * 8u;
                     buf_store<NRT>(rsP, soP, mP, P);
                     if constexpr (!AUG) buf_store<NRT>(rsP, soP, mW, W2);
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             return pdall;
         };
 
-        // Forward pass of the LQ problem over the forward chunks: dx, du into the workspace (the evaluator follows with dlam);
+        // Forward pass of the LQ problem over the forward chunks: dx, du (homogeneous form: and dlam) into the workspace; in the other forms the evaluator follows with dlam;
         // returns grad(phi)' d = grad(L)' d + lambda' c  (A d = -c)
         auto forward = [&](double hs) -> double {
             Gather3 gFT, gGT, gE, gRX, gRU;
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             }
             const double gd = forward(hs);
             MS2_T0();
-            wait_done();                                // the evaluator has finished dlam
+            wait_done();                                // the evaluator is through with the sweep (forms other than the homogeneous one: it has finished dlam)
             MS2_T1(4);
             if (dead) break;
             if (phase == 0) {
