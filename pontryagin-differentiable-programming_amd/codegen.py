@@ -449,7 +449,7 @@ def tuned(name):
 def compile_model(name, force=False, plain_twin=False):
     """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree).  plain_twin: the same model built with
     CORE_FLAGS whatever tuned() says, as lib/libpdp_model_<name>__plain.so - the reference build tests/test_gpu_flag_fence.py compares with."""
-    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_ocsolve2_kernels.h", "pdp_cp_mlp_kernels.h", "pdp_fused3_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
+    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_ocsolve2_kernels.h", "pdp_cp_mlp_kernels.h", "pdp_cp_pair_kernels.h", "pdp_fused3_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
     # -amdgpu-mfma-vgpr-form (hidden LLVM option, +4 % on the headline kernel, but see CORE_FLAGS above) only for the exact benchmark models

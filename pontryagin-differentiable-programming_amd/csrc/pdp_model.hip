@@ -18,6 +18,7 @@ namespace pdp { extern __device__ long long g_rb_stamp[16]; }
 #include "pdp_ocsolve2_kernels.h"
 #include "pdp_cp_mlp_kernels.h"
 #include "pdp_fused3_kernels.h"
+#include "pdp_cp_pair_kernels.h"
 #include <cstdlib>
 
 using namespace pdp;
@@ -323,6 +324,18 @@ int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const dou
     hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B, gy), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
     return launched();
 }
+// Lagrange-policy kernel variants (environment PDP_CP_POLY_VARIANT overrides): 2 = rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h) for
+// batches above one trajectory per CU, the default; 3 = the pair for every batch; 1 = one wavefront per trajectory and group of parameter tiles (cp_step_poly_kernel)
+inline int cp_poly_variant() { static const int v = [] { const char* e = std::getenv("PDP_CP_POLY_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
+template <class Mdl, int NT, int TPW>
+int cp_step2_launch(int B, int gy, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x,
+                    double* u, int slice, void* st) {
+    const int lds = slice * TPW * (int)sizeof(double);
+    (void)hipFuncSetAttribute((const void*)cp_step_poly2_kernel<Mdl, NT, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    PDP_CLEAR();
+    hipLaunchKernelGGL((cp_step_poly2_kernel<Mdl, NT, TPW>), dim3((B + TPW - 1) / TPW, gy), dim3(128 * TPW), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, slice);
+    return launched();
+}
 // MLP kernel variants (environment PDP_CP_MLP_VARIANT overrides): 2 = network in registers (pdp_cp_mlp_kernels.h), the default for networks of at
 // most 4 layers of width <= 16; 1 = the general adjoint kernel (any policy up to 8 layers x 32 units)
 inline int cp_mlp_variant() { static const int v = [] { const char* e = std::getenv("PDP_CP_MLP_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
@@ -385,6 +398,33 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
         gy = gy < 1 ? 1 : (gy > nt ? nt : gy);
         const int per = (nt + gy - 1) / gy;
         gy = (nt + per - 1) / per;
+        // rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h) once the batch exceeds one trajectory per CU; below that the one-wave kernel with its
+        // parameter tiles spread over grid.y does as well (profiles/r03_pair_pipeline.txt).  PDP_CP_POLY_VARIANT=3 takes the pair for every batch (tests)
+        if ((cp_poly_variant() == 2 && B > device_cu_count()) || cp_poly_variant() == 3) {
+            const int cus = device_cu_count();
+            const int slice = cp_pair_slice<Mdl>(T, pol->n_pivots);
+            const int tpw = B <= cus ? 1 : (B <= 2 * cus ? 2 : 4);
+            if ((size_t)slice * tpw * sizeof(double) <= 160 * 1024) {
+                int gy2 = (int)((int64_t)2 * device_cu_count() / B);          // tiles spread over several pairs only while whole CUs would idle (measured: C4 shard, 0.090 ms against 0.111 with twice as many pairs)
+                gy2 = gy2 < 1 ? 1 : (gy2 > nt ? nt : gy2);
+                const int per2 = (nt + gy2 - 1) / gy2;
+                gy2 = (nt + per2 - 1) / per2;
+                switch (per2 * 10 + tpw) {
+                    case 11: return cp_step2_launch<Mdl, 1, 1>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 12: return cp_step2_launch<Mdl, 1, 2>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 14: return cp_step2_launch<Mdl, 1, 4>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 21: return cp_step2_launch<Mdl, 2, 1>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 22: return cp_step2_launch<Mdl, 2, 2>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 24: return cp_step2_launch<Mdl, 2, 4>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 31: return cp_step2_launch<Mdl, 3, 1>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 32: return cp_step2_launch<Mdl, 3, 2>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 34: return cp_step2_launch<Mdl, 3, 4>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 41: return cp_step2_launch<Mdl, 4, 1>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    case 42: return cp_step2_launch<Mdl, 4, 2>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                    default: return cp_step2_launch<Mdl, 4, 4>(B, gy2, T, pol, p, x0, th, tb, loss, grad, x, u, slice, st);
+                }
+            }
+        }
         switch (per) {
             case 1: return cp_step_launch<Mdl, 1>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
             case 2: return cp_step_launch<Mdl, 2>(B, gy, T, pol, p, x0, th, tb, loss, grad, x, u, st);
@@ -418,8 +458,25 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
     if constexpr (Mdl::KIND == PDP_KIND_SYSID && Mdl::NX <= 16 && Mdl::NP <= 64) {
         if (B <= 0 || T <= 0 || !u || !xobs || !th || !loss || !grad) return PDP_E_ARG;
         constexpr int NT = (Mdl::NP + 15) / 16;
-        const size_t lds = sizeof(double) * (1 + Mdl::PATH_NCONST + Mdl::CHUNK * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (size_t)(T + 1) * Mdl::NX + Mdl::NX + 8);
+        const size_t lds = sizeof(double) * (size_t)sysid_slice<Mdl>(T);
         if (lds > 150 * 1024) return PDP_E_SIZE;
+        // PDP_SYSID_VARIANT: 2 = rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h), the default; 1 = one wavefront per trajectory
+        static const int variant = [] { const char* e = std::getenv("PDP_SYSID_VARIANT"); return e ? std::atoi(e) : 2; }();
+        // the pair pays while SIMDs would idle (B = 256, T = 200: 0.105 -> 0.072 ms); once every SIMD has a trajectory the two waves only share what one had
+        // (B = 1024: 0.0667 against 0.0685 ms, profiles/r03_pair_pipeline.txt) - the one-wave kernel stays for those batches
+        if (variant == 2 && B <= 2 * device_cu_count()) {
+            const int cus = device_cu_count(), slice = sysid_slice<Mdl>(T);
+            const int tpw = B <= cus ? 1 : 2;
+            const int lds2 = slice * tpw * (int)sizeof(double);
+            if (lds2 <= 160 * 1024) {
+                PDP_CLEAR();
+                if (tpw == 1) { (void)hipFuncSetAttribute((const void*)sysid_step2_kernel<Mdl, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                                hipLaunchKernelGGL((sysid_step2_kernel<Mdl, NT, 1>), dim3(B), dim3(128), lds2, S(st), B, T, u, xobs, th, tb, loss, grad, slice); }
+                else { (void)hipFuncSetAttribute((const void*)sysid_step2_kernel<Mdl, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                       hipLaunchKernelGGL((sysid_step2_kernel<Mdl, NT, 2>), dim3((B + 1) / 2), dim3(256), lds2, S(st), B, T, u, xobs, th, tb, loss, grad, slice); }
+                return launched();
+            }
+        }
         (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
         hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad);

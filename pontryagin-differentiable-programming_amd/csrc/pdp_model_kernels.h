@@ -1132,37 +1132,47 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     if (lane == 0) blk[0] = 0.0;
     for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     __syncthreads();
-    // ---- rollout (uniform)
+    // ---- the controls: the Lagrange policy is OPEN-LOOP, u_t = sum_i b_i(t) theta_i depends on t alone - all of them at once, lane = time step, before the rollout.
+    // (Evaluated inside the rollout, the np x m parameter loads from global memory sat in the serial chain: ~2.8 k cycles per step, 80 % of this kernel's time.)
+    for (int t = lane; t < T; t += 64) {
+        double uc[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) uc[j] = 0.0;
+        for (int i = 0; i < np; ++i) {
+            double bi = basis[t * np + i];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uc[j] += bi * th[i * NU + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) us[t * NU + j] = uc[j];
+    }
+    __syncthreads();
+    // ---- rollout (uniform); u_{t+1} is requested from the staging one step ahead
     double J = 0.0;
     {
-        double xc[NX], xn[NX], uc[NU];
+        double xc[NX], xn[NX], uc[NU], un[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x0[(int64_t)b * NX + i];
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xs[i] = xc[i];
         }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) un[j] = us[j];
         for (int t = 0; t < T; ++t) {
+            const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
-            for (int j = 0; j < NU; ++j) uc[j] = 0.0;
-            for (int i = 0; i < np; ++i) {
-                double bi = basis[t * np + i];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) uc[j] += bi * th[i * NU + j];
-            }
+            for (int j = 0; j < NU; ++j) { uc[j] = un[j]; un[j] = us[tn * NU + j]; }
             Mdl::dyn(xc, uc, nullptr, pc, xn);
             J += Mdl::path_cost(xc, uc, nullptr, pc);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
-            // x_{t+1}, u_t into the LDS staging from lane 0 WITHOUT a conditional block (it would make the wait in front of the next step's basis
+            // x_{t+1} into the LDS staging from lane 0 WITHOUT a conditional block (it would make the wait in front of the next step's LDS
             // reads a full lgkmcnt(0)): every lane stores, the others into a private dump word behind the staging
             {
                 double* dx_ = lane == 0 ? xs + (t + 1) * NX : dump + lane;
-                double* du_ = lane == 0 ? us + t * NU : dump + lane;
 #pragma unroll
                 for (int i = 0; i < NX; ++i) dx_[i] = xn[i];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) du_[j] = uc[j];
             }
         }
         J += Mdl::final_cost(xc, nullptr, pc);
@@ -1557,6 +1567,13 @@ __global__ void sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, 
     Mdl::eval_path(xc, uc, nullptr, th, pc, s);
 }
 
+// doubles of LDS per trajectory of the fused SysID.step kernels (sysid_step_kernel below, sysid_step2_kernel in pdp_cp_pair_kernels.h):
+// [cpool | pool CH rows | x (T+1) x NX | dlT NX + 1 | u T x NU | dump 64 + NX | hand-over counter, padding]
+template <class Mdl>
+__host__ __device__ inline int sysid_slice(int T) {
+    const int n = 1 + Mdl::PATH_NCONST + Mdl::CHUNK * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (T + 1) * Mdl::NX + Mdl::NX + 1 + T * Mdl::NU + 64 + Mdl::NX + 8;
+    return (n + 1) & ~1;
+}
 // Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
 template <class Mdl, int NT>
 __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const double* __restrict__ u, const double* __restrict__ xobs,
@@ -1568,6 +1585,8 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     double* pool = blk + NC;
     double* xs = pool + CH * STRIDE;         // (T+1) x NX
     double* dlT = xs + (T + 1) * NX;         // NX
+    double* us = dlT + NX + 1;               // T x NU: the given controls, staged once with coalesced loads
+    double* dump = us + T * NU;              // 64 + NX words nobody reads (see the rollout)
     const int b = blockIdx.x, lane = threadIdx.x;
     const d4 z = zero4();
     double th[NP];
@@ -1578,24 +1597,30 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     const double* ob = xobs + (int64_t)b * (T + 1) * NX;
     if (lane == 0) blk[0] = 0.0;
     for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
+    for (int q = lane; q < T * NU; q += 64) us[q] = ub[q];
+    __syncthreads();
     {
-        double xc[NX], xn[NX], uc[NU];
+        // rollout (uniform).  u_t comes from the LDS staging, requested one step ahead (read from global memory inside the loop every step waited for a round
+        // trip to memory); x_{t+1} goes to the staging from lane 0 without a conditional block (cp_step_poly_kernel)
+        double xc[NX], xn[NX], uc[NU], un[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = ob[i];                       // ini_state = batch_states[i][0] (PDP.py:1269)
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) xs[i] = xc[i];
         }
-        for (int t = 0; t < T; ++t) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+        for (int i = 0; i < NU; ++i) un[i] = us[i];
+        for (int t = 0; t < T; ++t) {
+            const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { uc[i] = un[i]; un[i] = us[tn * NU + i]; }
             Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xn[i];
-            if (lane == 0) {
+            double* dx_ = lane == 0 ? xs + (t + 1) * NX : dump + lane;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xs[(t + 1) * NX + i] = xn[i];
-            }
+            for (int i = 0; i < NX; ++i) dx_[i] = xn[i];
         }
     }
     __syncthreads();
@@ -1621,7 +1646,7 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
 #pragma unroll
             for (int i = 0; i < NX; ++i) { xc[i] = xs[t * NX + i]; double d = xc[i] - ob[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = ub[t * NU + i];
+            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
             PackedSink s{row};
             Mdl::eval_path(xc, uc, nullptr, th, pc, s);
         }
