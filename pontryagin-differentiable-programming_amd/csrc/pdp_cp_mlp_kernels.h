@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
         for (int tl = cnt - 1; tl >= 0; --tl) {
             const int t = t0 + tl;
             const double zk_own = znext;                          // this lane's activation of step t
-            if (t > 0) znext = actg[(t - 1) * 64 + lane];          // ... and of the step the sweep visits next, requested now
+            znext = actg[(t > 0 ? t - 1 : 0) * 64 + lane];         // ... and of the step the sweep visits next, requested now - WITHOUT a branch: a conditional block
+                                                                  // around the load makes the wait behind it a vmcnt(0), i.e. every step waits for the load it has just issued
             // layer inputs of the step into LDS (factors of the parameter gradient): z_0 = x_t, z_{k+1} = the activations of group k
             if (lane < NX) zs[lane] = xs[t * NX + lane];
             if (grp + 1 < nl) zs[(grp + 1) * W + idx] = zk_own;
