@@ -246,6 +246,24 @@ int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const dou
                             double* loss, double* grad, double* dxdp, double* dudp, int32_t* status,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same unit with the solution of the auxiliary control system kept: besides dxdp / dudp (X_t, U_t = state_traj_opt / control_traj_opt of
+ * LQR.lqrSolver, PDP.py:611-613) the Riccati matrices of every stage, riccati [B][T][n n + n p + 1] = P_{t+1} [n][n] | W_{t+1} [n][p] | one scratch word
+ * (PP[t], WW[t] of PDP.py:561-580; the costate sensitivities are Lambda_t = P_{t+1} X_{t+1} + W_{t+1}, PDP.py:604).  Any of the three may be NULL.
+ * pdp_oc_riccati_doubles() = n n + n p + 1 of this model. */
+int64_t pdp_oc_riccati_doubles(void);
+int pdp_oc_pdp_grad_sens_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta,
+                                 int theta_bstride, const double* demo_x, const double* demo_u, double* x, double* lam,
+                                 double* loss, double* grad, double* dxdp, double* dudp, double* riccati, int32_t* status,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* First-order prediction of the optimal trajectory at theta + dtheta from those outputs - the derivative the auxiliary control system IS
+ * (PDP.py:582-608), used as the starting point of the next OCSys.ocSolver call of an IRL loop (Examples/IRL/quadrotor/uav_PDP.py:52-62: theta moves by
+ * lr * gradient per iteration) so that pdp_oc_solve_ms_batched with PDP_MS_WARM needs one Newton iteration fewer:
+ *     x_t += X_t dtheta,  u_t += U_t dtheta,  lam_t += P_{t+1} (X_{t+1} dtheta) + W_{t+1} dtheta          in place
+ * dtheta [B][p] (dtheta_bstride = p) or shared [p] (stride 0).  riccati and lam may both be NULL: states and controls only. */
+int pdp_oc_predict_batched(int B, int T, const double* dtheta, int dtheta_bstride, const double* dxdp, const double* dudp,
+                           const double* riccati, double* x, double* u, double* lam, void* stream);
+
 /* ---- PDP_KIND_CP ------------------------------------------------------------------------------------ */
 
 /* Policy descriptor: Lagrange polynomial (ControlPlanning.setPolyControl, PDP.py:699-725; theta =

@@ -120,7 +120,7 @@ def least_squares_multipliers(ev, n, m):
     return dl
 
 
-def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None):
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None):
     """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations` and `restorations`.
     log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type).
     restoration: what happens when the line search falls below alpha_min, where IPOPT switches to its feasibility restoration phase.  IPOPT's own
@@ -130,7 +130,9 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     (theta = 0, acceptable to every filter entry).  As in IPOPT the current point is added to the filter first and the multipliers are reset to the
     least-squares estimate afterwards (zero if larger than constr_mult_reset_threshold = 1000).  False: raise instead (the pre-round-3 behaviour).
     u_init [T, m]: start from these controls and their rollout instead of the reference's all-zero guess (not something the reference does - it is
-    the starting point PDP_MS_FROM_CONTROLS gives the kernel, restated here so that path has a checker)."""
+    the starting point PDP_MS_FROM_CONTROLS gives the kernel, restated here so that path has a checker).
+    warm = (state [T+1, n], control [T, m], costate [T, n]): start the iteration AT that point (x_0 replaced by ini_state, no least-squares multiplier estimate) -
+    what PDP_MS_WARM does in the kernel; with the point predict_start below returns, the start of an IRL loop's next solve."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
@@ -142,12 +144,18 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
         for t in range(T):
             xs[t + 1] = _vec(oc.dyn_fn(xs[t], us[t], e))
     lam = np.zeros((T, n))
-    ev = evaluate(oc, xs, us, lam, e)
-    # initial multipliers: least-squares estimate from grad f (rdx / rdu at lam = 0)
-    lam0 = least_squares_multipliers(ev, n, m)
-    if np.all(np.isfinite(lam0)) and np.abs(lam0).max() <= o["constr_mult_init_max"]:
-        lam = lam0
+    if warm is not None:
+        assert u_init is None
+        xs, us, lam = (np.array(a, dtype=float) for a in warm)
+        xs[0] = _vec(ini_state)
         ev = evaluate(oc, xs, us, lam, e)
+    else:
+        ev = evaluate(oc, xs, us, lam, e)
+        # initial multipliers: least-squares estimate from grad f (rdx / rdu at lam = 0)
+        lam0 = least_squares_multipliers(ev, n, m)
+        if np.all(np.isfinite(lam0)) and np.abs(lam0).max() <= o["constr_mult_init_max"]:
+            lam = lam0
+            ev = evaluate(oc, xs, us, lam, e)
     theta_max = o["theta_max_fact"] * max(1.0, ev["theta"])
     theta_min = o["theta_min_fact"] * max(1.0, ev["theta"])
     filt = []
@@ -232,3 +240,19 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
         ev = evaluate(oc, xs, us, lam, e)
     return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it, "restorations": n_rest,
             "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"]}
+
+
+def predict_start(oc, state, control, costate, auxvar_value, dtheta, with_costate=True):
+    """First-order prediction of the optimal (x, u, lambda) at auxvar_value + dtheta from the solution at auxvar_value: the auxiliary control system of PDP
+    (PDP.py:272-314 getAuxSys, 557-608 lqrSolver) IS that derivative - X_t = dx_t/dtheta, U_t = du_t/dtheta, Lambda_t = P_{t+1} X_{t+1} + W_{t+1} =
+    dlambda_{t+1}/dtheta - so  (x, u, lambda) + (X, U, Lambda) dtheta  is what pdp_oc_predict_batched computes from the gradient unit's outputs.  An IRL
+    loop (Examples/IRL/quadrotor/uav_PDP.py:52-62) solves at theta_k, differentiates there, moves theta by lr * gradient: started from this point instead of
+    the previous solution, `solve(..., warm=...)` needs one Newton iteration fewer (the first iteration of a plain warm start only re-derives this step).
+    with_costate=False: multipliers left as they are (the variant without the Riccati record)."""
+    from .pdp_oracle import lqr_from_aux
+    T = np.size(control, 0)
+    d = _vec(dtheta)
+    aux = oc.getAuxSys(state, control, costate, auxvar_value)
+    lq = lqr_from_aux(aux, oc.n, oc.p, T)
+    X, U, L = np.stack(lq["state_traj_opt"]), np.stack(lq["control_traj_opt"]), np.stack(lq["costate_traj_opt"])
+    return state + X @ d, control + U @ d, (costate + L @ d) if with_costate else np.array(costate, dtype=float)

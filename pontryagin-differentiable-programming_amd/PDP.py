@@ -34,6 +34,12 @@ class OCSys:
     def __init__(self, project_name="my optimal control system"):
         self.project_name = project_name
         self._model = None
+        self._bar_model = None
+
+    def _invalidate(self):
+        """the compiled models (problem and log-barrier sub-problem) describe the previous set-up: drop them"""
+        self._model = None
+        self._bar_model = None
 
     # ---- set-up (PDP.py:62-119) -------------------------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -42,25 +48,28 @@ class OCSys:
         else:
             self.auxvar = auxvar
         self.n_auxvar = self.auxvar.numel()
+        self._invalidate()
 
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
         self.state = state
         self.n_state = self.state.numel()
         self.state_lb = state_lb if len(state_lb) == self.n_state else self.n_state * [-1e20]
         self.state_ub = state_ub if len(state_ub) == self.n_state else self.n_state * [1e20]
+        self._invalidate()
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
         self.control = control
         self.n_control = self.control.numel()
         self.control_lb = control_lb if len(control_lb) == self.n_control else self.n_control * [-1e20]
         self.control_ub = control_ub if len(control_ub) == self.n_control else self.n_control * [1e20]
+        self._invalidate()
 
     def setDyn(self, ode):
         if not hasattr(self, "auxvar"):
             self.setAuxvarVariable()
         self.dyn = ode
         self.dyn_fn = sx.Function("dynamics", [self.state, self.control, self.auxvar], [self.dyn])
-        self._model = None
+        self._invalidate()
 
     def setPathCost(self, path_cost):
         if not hasattr(self, "auxvar"):
@@ -68,7 +77,7 @@ class OCSys:
         assert path_cost.numel() == 1, "path_cost must be a scalar function"
         self.path_cost = path_cost
         self.path_cost_fn = sx.Function("path_cost", [self.state, self.control, self.auxvar], [self.path_cost])
-        self._model = None
+        self._invalidate()
 
     def setFinalCost(self, final_cost):
         if not hasattr(self, "auxvar"):
@@ -76,7 +85,7 @@ class OCSys:
         assert final_cost.numel() == 1, "final_cost must be a scalar function"
         self.final_cost = final_cost
         self.final_cost_fn = sx.Function("final_cost", [self.state, self.auxvar], [self.final_cost])
-        self._model = None
+        self._invalidate()
 
     def _require(self):
         assert hasattr(self, "state"), "Define the state variable first!"
@@ -206,7 +215,7 @@ class OCSys:
         """The device model of the log-barrier sub-problem  min sum_t [c + mu b(x_t, u_t)] + h + mu b(x_T)  s.t. the dynamics:  auxvar = [theta ; mu],
         b = - sum_i log(v_i - lb_i) - sum_i log(ub_i - v_i) over the finitely bounded components of the state and the control (x_0 is fixed: its term
         is a constant).  Built by the symbolic front-end like any other cost: the kernels see one more generated model."""
-        if getattr(self, "_bar_model", None) is None:
+        if self._bar_model is None:
             mu = SX.sym("mu_barrier")
 
             def bar(v, lb, ub):

@@ -39,7 +39,20 @@ CORE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] 
 # the reference's benchmark systems here.  Keyed on the HASH, not on the label: a user's own "quadrotor" with other dynamics, sizes or
 # horizon has another hash and is built with plain -O3 (round-2 advisor finding).  PDP_MFMA_VGPR_FORM=0 builds everything without the option,
 # =1 everything with it (tests/test_gpu_flag_fence.py compares the two builds of the headline models bit for bit).
-TUNED_NAMES = set()
+# The set is read at import from csrc/generated/tuned_names.txt (tracked; written by zoo.register_tuned, held current by tests/test_abi_and_host.py), so that
+# tuned(name) answers the same whatever ran before in the process - a set filled lazily made the flags of a zoo-identical user model depend on call order.
+TUNED_FILE = os.path.join(GEN_DIR, "tuned_names.txt")
+
+
+def _read_tuned():
+    try:
+        with open(TUNED_FILE) as f:
+            return set(ln.strip() for ln in f if ln.strip() and not ln.startswith("#"))
+    except OSError:
+        return set()
+
+
+TUNED_NAMES = _read_tuned()
 # OC models (the fused kernel): loop strength reduction rewrites the running LDS addresses of the step loops as (induction variable + 0)
 # and leaves a `v_add_u32 v, 0, v` in front of every ds_read (39 VALU instructions per time step); the loops already carry their own
 # running addresses.  Measured: fused kernel +5 % without LSR; the SysID / ControlPlanning kernels lose up to 12 % -> OC models only.
@@ -460,9 +473,50 @@ def compile_model(name, force=False, plain_twin=False):
     return _build(out, deps, extra + ["-DPDP_MODEL_HEADER=\"generated/%s.h\"" % name, "-I", CSRC, os.path.join(CSRC, "pdp_model.hip")], force, flags=flags)
 
 
+CORE_LIB_PATH = os.path.join(LIB_DIR, "libpdp_hip.so")
+
+
 def compile_core(force=False):
     deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_lqr_kernels.h", "pdp_lqr_stream_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
     return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force, flags=CORE_FLAGS)
+
+
+def kernel_resources(lib, count_scratch_instructions=False):
+    """Register / scratch usage of every kernel in a built library, read from the gfx950 code object's metadata notes (llvm-objcopy ->
+    clang-offload-bundler -> llvm-readelf --notes): {demangled-ish kernel name: dict(vgpr, agpr, sgpr, spill, scratch, lds)}.  Used by the no-spill
+    test (tests/test_abi_and_host.py) and by bench.py, which prints the dominant kernel's figures into its roofline entry."""
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
+        _run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib])
+        _run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = _run([os.path.join(llvm, "llvm-readelf"), "--notes", co])
+        dis = _run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", co]) if count_scratch_instructions else ""
+    nscr = {}
+    if dis:                                                   # scratch_load / scratch_store instructions per kernel symbol
+        cur = None
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                cur = m.group(1)
+                nscr[cur] = 0
+            elif cur is not None and "scratch_" in ln:
+                nscr[cur] += 1
+    out = {}
+    for ent in notes.split("- .agpr_count:")[1:]:
+        get = lambda k: int(re.search(r"\.%s:\s*(\d+)" % k, ent).group(1))
+        sym = re.search(r"\.name:\s*(\S+)", ent).group(1)
+        m = re.match(r"_ZN3pdp(\d+)", sym)                   # pdp::<name><template args...>
+        name = sym[m.end():m.end() + int(m.group(1))] if m else sym
+        targs = re.findall(r"Li(\d+)E", sym[m.end() + int(m.group(1)):].split("EE")[0] + "E") if m and "I" in sym[m.end() + int(m.group(1)):][:1] else []
+        key = name + ("<%s>" % ",".join(targs) if targs else "")
+        out[key] = dict(vgpr=get("vgpr_count"), agpr=int(ent.split()[0]), sgpr=get("sgpr_count"), spill=get("vgpr_spill_count"),
+                        scratch=get("private_segment_fixed_size"), lds=get("group_segment_fixed_size"), symbol=sym)
+        if dis:
+            out[key]["scratch_instructions"] = nscr.get(sym, 0)
+    return out
 
 
 def build_problem(problem, force=False):

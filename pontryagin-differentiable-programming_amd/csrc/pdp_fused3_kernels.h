@@ -110,12 +110,16 @@ PDP_DEV void move3(Run3& r, int bytes) {
 // batches that fill the chip (>= 1024 trajectories).  TPW = 2 / 1 (a 512-trajectory shard of C4, small batches): a CU then hosts at most two / one
 // trajectory, and the two waves of a trajectory sit on DIFFERENT SIMDs - the evaluator no longer competes with the runner's MFMA chain for issue slots
 // (profiles/r03_fused3_small_batch.txt).
-template <class Mdl, int TPW = 4>
+// RIC (the instantiation behind pdp_oc_pdp_grad_sens_batched): the runner also leaves the Riccati matrices P_{t+1}, W_{t+1} of every stage (PP[t], WW[t] of
+// the reference's lqrSolver, PDP.py:561-580) in `riccati` [B][T][n n + n p + 1] - with dxdp / dudp they give the first-order change of the optimal
+// (x, u, lambda) with theta (pdp_oc_predict_batched).  A template parameter, not a run-time branch: the default kernel keeps its instruction stream.
+template <class Mdl, int TPW = 4, bool RIC = false>
 __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
                                                             const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
                                                             const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                             double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
-                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
+                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain,
+                                                            double* __restrict__ riccati) {
     using F3 = Fused3Layout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>(), GSZ0 = fused_gain0_doubles<Mdl>();
@@ -281,6 +285,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                 return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
             // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
             const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+            // Riccati record of a stage (RIC): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | zero sink
+            constexpr int RSZ = oc_riccati_doubles<Mdl>();
+            [[maybe_unused]] const TileMapBytes mRP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, RSZ - 1), mRW = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
+            [[maybe_unused]] double* rw = RIC ? riccati + (int64_t)b * T * RSZ : nullptr;
             constexpr int RB = 8 * BS;                           // bytes per row
             for (int g = 0; g < nchunk; ++g) {
                 int t0, cnt;
@@ -311,6 +319,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
                     d4 P_old;
+                    if constexpr (RIC) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
                     ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);

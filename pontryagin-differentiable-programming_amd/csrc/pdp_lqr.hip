@@ -193,15 +193,16 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
     if (variant == 2 && nt == 1 && lqs_ok(pr.n, pr.m, pr.p, Lam != nullptr)) {
         const dim3 grid((pr.B + 3) / 4), block(512);
         PDP_CLEAR();
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(kern, grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw);
+        };
+        const bool nl12 = lqs_lines(pr.n, pr.m, pr.p, Lam != nullptr) <= 12;      // lines per ring slot: 12 (C3 sizes and smaller) or 16
         switch (pr.m) {
-            case 1: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    hipLaunchKernelGGL((lqr_solve_stream_kernel<1>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
-            case 2: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    hipLaunchKernelGGL((lqr_solve_stream_kernel<2>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
-            case 3: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    hipLaunchKernelGGL((lqr_solve_stream_kernel<3>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
-            default: (void)hipFuncSetAttribute((const void*)lqr_solve_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    hipLaunchKernelGGL((lqr_solve_stream_kernel<4>), grid, block, 160 * 1024, s, pr, X, U, Lam, status, wg, wpw); break;
+            case 1: if (nl12) go(lqr_solve_stream_kernel<1, 12>); else go(lqr_solve_stream_kernel<1, 16>); break;
+            case 2: if (nl12) go(lqr_solve_stream_kernel<2, 12>); else go(lqr_solve_stream_kernel<2, 16>); break;
+            case 3: if (nl12) go(lqr_solve_stream_kernel<3, 12>); else go(lqr_solve_stream_kernel<3, 16>); break;
+            default: if (nl12) go(lqr_solve_stream_kernel<4, 12>); else go(lqr_solve_stream_kernel<4, 16>); break;
         }
         return launched();
     }

@@ -15,25 +15,35 @@
 
 namespace pdp {
 
-constexpr int LQS_D = 4, LQS_LMAX = 16, LQS_SP = 64 * LQS_LMAX;      // ring depth, 64-double lines per slot, doubles per slot
+constexpr int LQS_D = 4, LQS_LMAX = 16;                              // ring depth, most 64-double lines per slot (kernel template parameter NL <= LQS_LMAX: doubles per slot = 64 NL)
 constexpr int LQS_SLICE = 160 * 1024 / 8 / 4;                        // doubles of LDS per trajectory
 constexpr int LQS_MISC = RICCATI_SCRATCH, LQS_RING = LQS_MISC + 8;
-static_assert(LQS_RING + LQS_D * LQS_SP <= LQS_SLICE, "ring does not fit the trajectory's LDS slice");
+static_assert(LQS_RING + LQS_D * 64 * LQS_LMAX <= LQS_SLICE, "ring does not fit the trajectory's LDS slice");
 
 // segment offsets (doubles) inside a slot: backward sweep F | G | E | Hxx | Hxu | Hxe | Huu | Hue | 0.0, forward sweep F | G | E | K',k | P,W | 0.0
 struct LqsLayout { int F, G, E, Hxx, Hxu, Hxe, Huu, Hue, Z, fF, fG, fE, fK, fPW, fZ; };
+// P_{t+1}, W_{t+1} in the workspace of this kernel: the UPPER TRIANGLE of P (it is symmetrised every step: the two halves are bit-identical), row-major packed,
+// followed by W [n][p] - 91 + 117 doubles per stage at C3 sizes instead of 169 + 117 (64 MB less per launch in each direction)
+__host__ __device__ inline int lqs_ptri(int n, int i, int j) { return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j); }
+__host__ __device__ inline int lqs_pw_doubles(int n, int p) { return n * (n + 1) / 2 + n * p; }
 __host__ __device__ inline LqsLayout lqs_layout(int n, int m, int p, bool costate) {
     LqsLayout L;
     int o = 0;
     L.F = o; o += n * n; L.G = o; o += n * m; L.E = o; o += n * p; L.Hxx = o; o += n * n; L.Hxu = o; o += n * m; L.Hxe = o; o += n * p;
     L.Huu = o; o += m * m; L.Hue = o; o += m * p; L.Z = o;
     o = 0;
-    L.fF = o; o += n * n; L.fG = o; o += n * m; L.fE = o; o += n * p; L.fK = o; o += n * m + m * p; L.fPW = o; o += costate ? n * n + n * p : 0; L.fZ = o;
+    L.fF = o; o += n * n; L.fG = o; o += n * m; L.fE = o; o += n * p; L.fK = o; o += n * m + m * p; L.fPW = o; o += costate ? lqs_pw_doubles(n, p) : 0; L.fZ = o;
     return L;
 }
-__host__ __device__ inline bool lqs_ok(int n, int m, int p, bool costate) {
+// lines per slot a problem needs (the kernel is instantiated for 12 and 16: the streamer issues NL loads and NL LDS stores per step whatever the data volume,
+// and its three register sets are 3 NL doubles - at C3 sizes a backward step is 728 doubles, a forward step 634)
+__host__ __device__ inline int lqs_lines(int n, int m, int p, bool costate) {
     const LqsLayout L = lqs_layout(n, m, p, costate);
-    return n > 4 && n <= 16 && m <= 4 && p <= 16 - m && L.Z < LQS_SP && L.fZ < LQS_SP;
+    const int need = (L.Z > L.fZ ? L.Z : L.fZ) + 1;              // (+ the zero word behind the data)
+    return (need + 63) / 64;
+}
+__host__ __device__ inline bool lqs_ok(int n, int m, int p, bool costate) {
+    return n > 4 && n <= 16 && m <= 4 && p <= 16 - m && lqs_lines(n, m, p, costate) <= LQS_LMAX;
 }
 
 // Two kinds of signal.  lqs_signal_lds orders only the wave's LDS traffic in front of the counter (s_waitcnt lgkmcnt(0)): a RELEASE store would also
@@ -88,7 +98,7 @@ PDP_DEV d4 lqs_read(const LqsGather& g, unsigned slot_addr) {
 
 // (range-checked buffer stores lqs_store / StoreMap / LQS_RSRC: pdp_lqr_kernels.h)
 
-template <int M>
+template <int M, int NL>
 __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo,
                                                                double* __restrict__ Lo, int32_t* __restrict__ status,
                                                                double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
@@ -106,7 +116,8 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
     const int n = pr.n, p = pr.p, T = pr.T;
     const bool costate = Lo != nullptr && ws_pw != nullptr;
     const LqsLayout L = lqs_layout(n, M, p, costate);
-    const int gsz = n * M + M * p, pwsz = n * n + n * p;
+    constexpr int LQS_SP = 64 * NL;                          // doubles per ring slot
+    const int gsz = n * M + M * p, pwsz = lqs_pw_doubles(n, p), ntri = n * (n + 1) / 2;
     const unsigned ring_addr = lqs_lds_addr(ring);
     const d4 z = zero4();
 #ifdef PDP_LQS_TIMING
@@ -122,12 +133,12 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
         const Fam bw[8] = {{pr.F, n * n}, {pr.G, n * M}, {pr.E, n * p}, {pr.Hxx, n * n}, {pr.Hxu, n * M}, {pr.Hxe, n * p}, {pr.Huu, M * M}, {pr.Hue, M * p}};
         const Fam fw[5] = {{pr.F, n * n}, {pr.G, n * M}, {pr.E, n * p}, {gains, gsz}, {pw, costate ? pwsz : 0}};
         int seen_c = 0;                  // lower bound of fl[1] (steps consumed)
-        const double* lp[LQS_LMAX];      // this lane's element of line l at the current step ...
-        int lstep[LQS_LMAX];             // ... and its byte distance to the same element of the next step (0: absent family / padding -> reads the zero word)
+        const double* lp[NL];            // this lane's element of line l at the current step ...
+        int lstep[NL];                   // ... and its byte distance to the same element of the next step (0: absent family / padding -> reads the zero word)
         auto phase = [&](const Fam* fam, int nfam, int zoff, int t_first, int dir, int kbase) {
             (void)zoff;
 #pragma unroll
-            for (int l = 0; l < LQS_LMAX; ++l) {
+            for (int l = 0; l < NL; ++l) {
                 const int e = 64 * l + lane;
                 lp[l] = PDP_ZERO; lstep[l] = 0;
                 int o = 0;
@@ -136,10 +147,11 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
                     o += fam[f].cnt;
                 }
             }
-            double v0[LQS_LMAX], v1[LQS_LMAX], v2[LQS_LMAX];
+            double v0[NL], v1[NL];
+            [[maybe_unused]] double v2[NL > 12 ? 1 : NL];       // slots of more than 12 lines: two register sets (three would not fit 256 registers beside the runner's code)
             auto issue = [&](double* v) {
 #pragma unroll
-                for (int l = 0; l < LQS_LMAX; ++l) { v[l] = *lp[l]; lp[l] = (const double*)((const char*)lp[l] + lstep[l]); }      // no branches in here:
+                for (int l = 0; l < NL; ++l) { v[l] = *lp[l]; lp[l] = (const double*)((const char*)lp[l] + lstep[l]); }      // no branches in here:
                 // control flow between the loads makes the compiler's s_waitcnt placement conservative (vmcnt(0) at every join), which would
                 // serialise the steps in flight; lines past the step's data read the zero word and land in the slot's padding
             };
@@ -148,16 +160,24 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
                 { LQS_TW0(); lqs_wait_cached(fl + 1, k - LQS_D + 1, seen_c); LQS_TW1(); }      // the slot's previous occupant has been consumed
                 double* s = ring + (j % LQS_D) * LQS_SP;              // slot = step index inside the phase, mod D (both phases start on slot 0)
 #pragma unroll
-                for (int l = 0; l < LQS_LMAX; ++l) s[64 * l + lane] = v[l];
+                for (int l = 0; l < NL; ++l) s[64 * l + lane] = v[l];
                 lqs_signal_lds(fl + 0, k + 1);
             };
             issue(v0);
-            if (T > 1) issue(v1);
-            for (int j = 0; j < T; j += 3) {
-                if (j + 2 < T) issue(v2);
-                commit(v0, j);
-                if (j + 1 < T) { if (j + 3 < T) issue(v0); commit(v1, j + 1); }
-                if (j + 2 < T) { if (j + 4 < T) issue(v1); commit(v2, j + 2); }
+            if constexpr (NL > 12) {                         // two steps in flight (2 x 8 KB per trajectory)
+                for (int j = 0; j < T; j += 2) {
+                    if (j + 1 < T) issue(v1);
+                    commit(v0, j);
+                    if (j + 1 < T) { if (j + 2 < T) issue(v0); commit(v1, j + 1); }
+                }
+            } else {                                         // three steps in flight (3 x 6 KB)
+                if (T > 1) issue(v1);
+                for (int j = 0; j < T; j += 3) {
+                    if (j + 2 < T) issue(v2);
+                    commit(v0, j);
+                    if (j + 1 < T) { if (j + 3 < T) issue(v0); commit(v1, j + 1); }
+                    if (j + 2 < T) { if (j + 4 < T) issue(v1); commit(v2, j + 2); }
+                }
             }
         };
         phase(bw, 8, L.Z, T - 1, -1, 0);
@@ -179,6 +199,13 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
                   mMP = make_dense_map<false>(M, p0, p, 0, M, lane), mFT = make_dense_map<true>(n, n, n, 0, 0, lane),
                   mGT = make_dense_map<true>(n, M, M, 0, 0, lane), mNMrep = make_rep4_map(n, M, M, lane);
     const TileMap mNone = {{-1, -1, -1, -1}};
+    TileMap mPst, mPld;                                      // P in the workspace: stored from the upper triangle of the tile, read back symmetrically
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tile_row(lane, r), col = tile_col(lane);
+        mPst.off[r] = (row < n && col < n && row <= col) ? lqs_ptri(n, row, col) : -1;
+        mPld.off[r] = (row < n && col < n) ? lqs_ptri(n, row, col) : -1;
+    }
     // terminal condition: PP[T-1] = hxx, WW[T-1] = hxe (PDP.py:561-562)
     d4 P = load_map(mat_at(pr.hxx, b, 0), mNN);
     d4 W0;
@@ -191,7 +218,7 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
                         gHxx = lqs_gather(L.Hxx, mNN, 0, mNone, L.Z), gHX = lqs_gather(L.Hxu, mNM, L.Hxe, mNP, L.Z),
                         gHU = lqs_gather(L.Huu, mMM, L.Hue, mMP, L.Z), gHux = lqs_gather(L.Hxu, mGT, 0, mNone, L.Z);
         constexpr unsigned SB = 8u * LQS_SP;                 // bytes per slot: the slot of a step is a literal offset in the 4-step trips below
-        const StoreMap sNN = lqs_store_map(mNN), sNP = lqs_store_map(mNP), sNM = lqs_store_map(mNM), sMP = lqs_store_map(mMP);
+        const StoreMap sNN = lqs_store_map(mPst), sNP = lqs_store_map(mNP), sNM = lqs_store_map(mNM), sMP = lqs_store_map(mMP);
         const auto rPW = LQS_RSRC(ws_pw ? ws_pw + (int64_t)b * T * pwsz : ws_gain, ws_pw ? (int64_t)T * pwsz * 8 : 0);
         const auto rG = LQS_RSRC(ws_gain + (int64_t)b * T * gsz, (int64_t)T * gsz * 8);
         lqs_wait_cached(fl + 0, T > 1 ? 2 : 1, seen);
@@ -203,7 +230,7 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
             if (k + 1 < T) { Fn = lqs_read(gF, ring_addr + sn); Yn = lqs_read(gY, ring_addr + sn); }
             const int t = T - 1 - k;
             lqs_store(rPW, sNN, (unsigned)(t * pwsz) * 8u, P);               // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
-            lqs_store(rPW, sNP, (unsigned)(t * pwsz + n * n) * 8u, W0);
+            lqs_store(rPW, sNP, (unsigned)(t * pwsz + ntri) * 8u, W0);
             RiccatiGains g;
             d4 P_old;
             ok = riccati_backward<M, true, false>(P, W0, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, p0, g, P_old) && ok;
@@ -233,7 +260,7 @@ __global__ void __launch_bounds__(512) lqr_solve_stream_kernel(pdp_lqr_problem p
     {
         const LqsGather gFT = lqs_gather(L.fF, mFT, 0, mNone, L.fZ), gGT = lqs_gather(L.fG, mGT, 0, mNone, L.fZ), gKT = lqs_gather(L.fK, mNMrep, 0, mNone, L.fZ),
                         gk = lqs_gather(L.fK + n * M, mMP, 0, mNone, L.fZ), gE = lqs_gather(L.fE, mNP, 0, mNone, L.fZ),
-                        gP = lqs_gather(L.fPW, costate ? mNN : mNone, 0, mNone, L.fZ), gW = lqs_gather(L.fPW + n * n, costate ? mNP : mNone, 0, mNone, L.fZ);
+                        gP = lqs_gather(L.fPW, costate ? mPld : mNone, 0, mNone, L.fZ), gW = lqs_gather(L.fPW + ntri, costate ? mNP : mNone, 0, mNone, L.fZ);
         constexpr unsigned SB = 8u * LQS_SP;
         const StoreMap sNP = lqs_store_map(mNP), sMP = lqs_store_map(mMP);
         const auto rU = LQS_RSRC(Uo + (int64_t)b * T * M * p, (int64_t)T * M * p * 8), rX = LQS_RSRC(Xo + (int64_t)b * (T + 1) * n * p, (int64_t)(T + 1) * n * p * 8),

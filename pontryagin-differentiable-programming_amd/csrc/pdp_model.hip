@@ -104,7 +104,7 @@ int oc_auxsys(int B, int T, const double* x, const double* u, const double* lam,
 }
 template <class Mdl>
 int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const double* th, int tb, const double* dx, const double* du, double* x,
-           double* lam, double* loss, double* grad, double* dxdp, double* dudp, int32_t* status, void* ws, int64_t wsb, void* st) {
+           double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* ric, int32_t* status, void* ws, int64_t wsb, void* st) {
     if constexpr (fused_oc_ok<Mdl>()) {
         if (B <= 0 || T <= 0 || !u || !th || !dx || !du || !x || !lam || !loss || !grad || !ws) return PDP_E_ARG;
         if (!(flags & PDP_OC_GIVEN_TRAJ) && !x0) return PDP_E_ARG;
@@ -126,17 +126,34 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
                 auto go = [&](auto kern, int TPW) {
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TPW * 40 * 1024);
                     hipLaunchKernelGGL(kern, dim3((B + TPW - 1) / TPW), dim3(128 * TPW), TPW * 40 * 1024, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
-                                       dudp, status, (double*)ws);
+                                       dudp, status, (double*)ws, ric);
                     return launched();
                 };
+                if (ric) {          // with the Riccati record (pdp_oc_pdp_grad_sens_batched): the RIC instantiations
+                    if (tpw == 1) return go(oc_pdp_fused3_kernel<Mdl, 1, true>, 1);
+                    if (tpw == 2) return go(oc_pdp_fused3_kernel<Mdl, 2, true>, 2);
+                    return go(oc_pdp_fused3_kernel<Mdl, 4, true>, 4);
+                }
                 if (tpw == 1) return go(oc_pdp_fused3_kernel<Mdl, 1>, 1);
                 if (tpw == 2) return go(oc_pdp_fused3_kernel<Mdl, 2>, 2);
                 return go(oc_pdp_fused3_kernel<Mdl, 4>, 4);
             }
         }
-        (void)hipFuncSetAttribute((const void*)oc_pdp_fused_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((oc_pdp_fused_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
-                           dudp, status, (double*)ws);
+        auto go1 = [&](auto kern) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp, dudp, status, (double*)ws, ric);
+            return launched();
+        };
+        return ric ? go1(oc_pdp_fused_kernel<Mdl, true>) : go1(oc_pdp_fused_kernel<Mdl, false>);
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl>
+int oc_predict(int B, int T, const double* dth, int dtb, const double* dxdp, const double* dudp, const double* ric, double* x, double* u, double* lam, void* st) {
+    if constexpr (fused_oc_ok<Mdl>()) {
+        if (B <= 0 || T <= 0 || !dth || !dxdp || !dudp || !x || !u || (ric && !lam)) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_predict_kernel<Mdl>), dim3((unsigned)((int64_t)B * ((T + 3) / 4))), dim3(64), 0, S(st), B, T, dth, dtb, dxdp, dudp, ric, x, u, lam);
         return launched();
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
@@ -534,7 +551,19 @@ int64_t pdp_oc_pdp_workspace_bytes(int B, int T) {
 int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta, int tb, const double* demo_x,
                             const double* demo_u, double* x, double* lam, double* loss, double* grad, double* dxdp, double* dudp, int32_t* status,
                             void* workspace, int64_t workspace_bytes, void* stream) {
-    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, status, workspace, workspace_bytes, stream);
+    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, nullptr, status, workspace, workspace_bytes, stream);
+}
+int64_t pdp_oc_riccati_doubles(void) {
+    if constexpr (PdpModel::KIND == PDP_KIND_OC) return oc_riccati_doubles<PdpModel>(); else return 0;
+}
+int pdp_oc_pdp_grad_sens_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta, int tb, const double* demo_x,
+                                 const double* demo_u, double* x, double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* riccati,
+                                 int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
+    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, riccati, status, workspace, workspace_bytes, stream);
+}
+int pdp_oc_predict_batched(int B, int T, const double* dtheta, int dtheta_bstride, const double* dxdp, const double* dudp, const double* riccati, double* x,
+                           double* u, double* lam, void* stream) {
+    return oc_predict<PdpModel>(B, T, dtheta, dtheta_bstride, dxdp, dudp, riccati, x, u, lam, stream);
 }
 int pdp_cp_integrate_batched(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* theta, int tb, double* x, double* u,
                              double* cost, void* stream) {

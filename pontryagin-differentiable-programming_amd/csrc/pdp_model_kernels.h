@@ -46,7 +46,7 @@ PDP_DEV void load_theta(const double* __restrict__ theta, int b, int bstride, do
 // OC: rollout / costate (lane per trajectory), aux system (lane per (b,t))
 // ------------------------------------------------------------------------------------------------------
 template <class Mdl>
-__global__ void oc_rollout_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
+__global__ void __launch_bounds__(64) oc_rollout_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
                                   int tb, double* __restrict__ x, double* __restrict__ cost) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,7 +119,7 @@ PDP_DEV double closed_loop_rollout(int T, double a, const double* __restrict__ x
 
 // closed-loop rollout (one lane per trajectory), per-sample step length alpha
 template <class Mdl>
-__global__ void oc_rollout_feedback_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
+__global__ void __launch_bounds__(64) oc_rollout_feedback_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
                                            const double* __restrict__ gains, const double* __restrict__ alpha, const double* __restrict__ theta, int tb,
                                            double* __restrict__ x, double* __restrict__ u, double* __restrict__ cost) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, GSZ = NX * NU + NU;
@@ -134,7 +134,7 @@ __global__ void oc_rollout_feedback_kernel(int B, int T, const double* __restric
 }
 
 template <class Mdl>
-__global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
+__global__ void __launch_bounds__(64) oc_costate_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
                                   int tb, double* __restrict__ lam) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,7 +177,7 @@ __global__ void oc_costate_kernel(int B, int T, const double* __restrict__ x, co
 // One lane per (trajectory, node): size-generic (any n, m the model has), the building block of the kernel-by-kernel multiple-shooting route for problems
 // beyond the solver kernels' tiles (ocsolver.solve_batch_ms_generic); same quantities as the trial pass of oc_solve_ms2_kernel.
 template <class Mdl>
-__global__ void oc_ms_residuals_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ lam,
+__global__ void __launch_bounds__(64) oc_ms_residuals_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ lam,
                                        const double* __restrict__ theta, int tb, double* __restrict__ c, double* __restrict__ rx, double* __restrict__ ru,
                                        double* __restrict__ cost) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64) oc_newton_prepare_kernel(int B, int T, int
 
 // closed-loop line search: one lane per (sample, trial); trial k uses alpha = 2^-k
 template <class Mdl>
-__global__ void oc_linesearch_kernel(int B, int T, int K, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
+__global__ void __launch_bounds__(64) oc_linesearch_kernel(int B, int T, int K, const double* __restrict__ x0, const double* __restrict__ ubar, const double* __restrict__ xbar,
                                      const double* __restrict__ gains, const double* __restrict__ theta, int tb, double* __restrict__ xt,
                                      double* __restrict__ ut, double* __restrict__ Jt) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, GSZ = NX * NU + NU;
@@ -502,6 +502,9 @@ template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { re
 #endif
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain0_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }      // K | k | zero sink
+// Riccati record of a stage (optional output of the fused gradient unit): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | one scratch word (zero sink of the tile stores)
+template <class Mdl>
+__host__ __device__ constexpr int oc_riccati_doubles() { return Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1; }
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain_doubles() {
     return fused_gain0_doubles<Mdl>() + (fused_closed_loop<Mdl>() ? Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1 : 0);              // + Acl | ecl | zero sink
@@ -545,12 +548,13 @@ __host__ __device__ inline size_t fused_lds_bytes(int T) {
     return sizeof(double) * (size_t)(RICCATI_SCRATCH + FusedLayout<Mdl>::NC + fused_pool_doubles<Mdl>(T) + Mdl::NX + Mdl::NP + Mdl::NPC + 8);
 }
 
-template <class Mdl>
+template <class Mdl, bool RIC = false>
 __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
                                                            const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
                                                            const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                            double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
-                                                           double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain) {
+                                                           double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain,
+                                                           double* __restrict__ riccati) {
     using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = L::CH, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K [NU x NX] | k [NU x NP] | zero sink
@@ -716,6 +720,10 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         // closed-loop matrices behind the gains: Acl [NX x NX] | ecl [NX x NP] | zero sink
         const TileMapBytes mAcl = make_tile_map_sink(NX, NX, NX, 0, 0, lane, NX * NX + NX * NP), mEcl = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
+        // Riccati record of a stage (RIC; see oc_pdp_fused3_kernel): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | zero sink
+        constexpr int RSZ = oc_riccati_doubles<Mdl>();
+        [[maybe_unused]] const TileMapBytes mRP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, RSZ - 1), mRW = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
+        [[maybe_unused]] double* rw = RIC ? riccati + (int64_t)b * T * RSZ : nullptr;
         Gather gGTb;                                      // G' (m x n, rows 0..3): left operand of the rank-m products G K and G k
         make_gather(gGTb, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (CLF && r < M && c < NX) ? codeA(1, c * NU + r) : -1; });
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
@@ -832,6 +840,12 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 if constexpr (SMALL) {
                     SmallGains g;
                     double Pr = P[0], Wr = W2[0];
+                    if constexpr (RIC) {                     // (P is in rep form: the first column block is P itself, the replicas must not reach the sink slot)
+                        d4 Pt_ = z, Wt_ = z;
+                        Pt_[0] = (lane & 12) == 0 ? Pr : 0.0; Wt_[0] = Wr;
+                        store_all<1>(rw + t * RSZ, mRP, Pt_);
+                        store_all<1>(rw + t * RSZ + NX * NX, mRW, Wt_);
+                    }
                     ok = riccati_small_backward<M, true>(Pr, Wr, Fu[0], Yu[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux[0], lane, tlane, NP, g) && ok;
                     P[0] = Pr; W2[0] = Wr;
                     d4 Kt = z, IKt = z;
@@ -844,6 +858,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 d4 P_old;
                 [[maybe_unused]] d4 GTb = z;
                 if constexpr (CLF) GTb = gather_run<1>(rGTb, -1);
+                if constexpr (RIC) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
                 ok = riccati_backward<M, false>(P, W2, Fu, Yu, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
@@ -1036,10 +1051,58 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
 }
 
 // ------------------------------------------------------------------------------------------------------
+// First-order prediction of the optimal trajectory at theta + dtheta - what the auxiliary control system is the derivative OF (PDP.py:582-608: X = dx/dtheta,
+// U = du/dtheta, Lambda_t = P_{t+1} X_{t+1} + W_{t+1} = dlambda_{t+1}/dtheta):
+//     x_t += X_t dtheta      u_t += U_t dtheta      lam_t += P_{t+1} (X_{t+1} dtheta) + W_{t+1} dtheta
+// from the outputs of the gradient unit (dxdp, dudp, riccati).  The starting point of the next OC solve of an IRL loop: one Newton iteration fewer than a
+// start from the previous solution (oracle/ipopt_ms.py: predict_start).  16 lanes per stage (lane = row), four stages per wavefront; the rows of a stage are
+// contiguous, so a wave reads whole lines.  riccati / lam may be NULL (states and controls only).
+// ------------------------------------------------------------------------------------------------------
+template <class Mdl>
+__global__ void __launch_bounds__(64) oc_predict_kernel(int B, int T, const double* __restrict__ dtheta, int dtb, const double* __restrict__ dxdp,
+                                                        const double* __restrict__ dudp, const double* __restrict__ riccati, double* __restrict__ x,
+                                                        double* __restrict__ u, double* __restrict__ lam) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, RSZ = oc_riccati_doubles<Mdl>();
+    static_assert(NX <= 16 && NU <= 16, "one 16-lane group per stage");
+    const int nq = (T + 3) / 4;
+    const int b = blockIdx.x / nq, t = (blockIdx.x - b * nq) * 4 + (threadIdx.x >> 4), i = threadIdx.x & 15;
+    if (b >= B) return;
+    const bool live = t < T;
+    const int tc = live ? t : T - 1;                        // (lanes behind the horizon compute stage T - 1 again and store nothing: no divergence around the shuffles)
+    double d[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) d[j] = dtheta[(int64_t)b * dtb + j];
+    double dx = 0.0;
+    if (i < NX) {                                           // node t + 1 (X_0 = 0: x_0 is fixed)
+        const double* X = dxdp + (((int64_t)b * (T + 1) + tc + 1) * NX + i) * NP;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dx = fma(X[j], d[j], dx);
+        if (live) x[((int64_t)b * (T + 1) + tc + 1) * NX + i] += dx;
+    }
+    if (i < NU) {
+        const double* U = dudp + (((int64_t)b * T + tc) * NU + i) * NP;
+        double du = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) du = fma(U[j], d[j], du);
+        if (live) u[((int64_t)b * T + tc) * NU + i] += du;
+    }
+    if (riccati && lam) {
+        const double* R = riccati + ((int64_t)b * T + tc) * RSZ;
+        const int ii = i < NX ? i : 0;
+        double dl = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dl = fma(R[NX * NX + ii * NP + j], d[j], dl);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) dl = fma(R[ii * NX + k], __shfl(dx, (threadIdx.x & 48) + k, 64), dl);
+        if (live && i < NX) lam[((int64_t)b * T + tc) * NX + i] += dl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // ControlPlanning (PDP_KIND_CP)
 // ------------------------------------------------------------------------------------------------------
 template <class Mdl>
-__global__ void cp_integrate_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta, int tb,
+__global__ void __launch_bounds__(64) cp_integrate_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta, int tb,
                                     double* __restrict__ x, double* __restrict__ u, double* __restrict__ cost) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1073,7 +1136,7 @@ PDP_DEV void fill_static_path(double* dst, int mat, int count) {
 }
 
 template <class Mdl>
-__global__ void cp_auxsys_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x, const double* __restrict__ u,
+__global__ void __launch_bounds__(64) cp_auxsys_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x, const double* __restrict__ u,
                                  const double* __restrict__ theta, int tb, double* __restrict__ dynF, double* __restrict__ dynG,
                                  double* __restrict__ dUx, double* __restrict__ dUe, double* __restrict__ dcx, double* __restrict__ dcu,
                                  double* __restrict__ dhx) {
@@ -1520,7 +1583,7 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
 // SysID (PDP_KIND_SYSID)
 // ------------------------------------------------------------------------------------------------------
 template <class Mdl>
-__global__ void sysid_integrate_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
+__global__ void __launch_bounds__(64) sysid_integrate_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
                                        int tb, double* __restrict__ x) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1542,7 +1605,7 @@ __global__ void sysid_integrate_kernel(int B, int T, const double* __restrict__ 
 }
 
 template <class Mdl>
-__global__ void sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
+__global__ void __launch_bounds__(64) sysid_auxsys_kernel(int B, int T, const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ theta,
                                     int tb, double* __restrict__ dynF, double* __restrict__ dynE) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

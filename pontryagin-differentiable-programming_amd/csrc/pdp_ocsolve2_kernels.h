@@ -126,6 +126,10 @@ enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, 
 // runner's control flow
 PDP_DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PDP_DEV double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+// A value the optimiser cannot see through: per-lane maps derived from opaque(lane) INSIDE a sweep are recomputed at every sweep (a few hundred cycles against
+// the sweep's 50 - 100 k) instead of being hoisted out of the iteration loop, where the maps of BOTH sweeps stayed live across each other and pushed the
+// four-trajectories-per-workgroup instantiation (256 registers per wave) into scratch memory (round 3: 21 spilled VGPRs)
+PDP_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 PDP_DEV int ms2_load(int* f) { return uni(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 // wait until *f >= v; false when the partner never gets there (watchdog) or the trajectory has been declared dead
 PDP_DEV bool ms2_wait_ge(int* f, int v, int* ctl) {
@@ -392,49 +396,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         auto wait_done = [&]() { wait_slot(MS2_DONE); };
         auto abort_sweep = [&]() { f3_signal(ctl + MS2_ABORT, seq); wait_done(); };
 
-        // ---- loop-invariant gather / store maps
-        auto codeS = [](int mat, int i) { return Mdl::sol_code(mat, i); };       // 0 F, 1 G, 2 Hxx, 3 Hxu, 4 Huu
-        Gather3 gF, gY, gHxx, gHX, gHU, gGr, gHux;
-        if constexpr (AUG) {
-            // homogeneous form: F~ = [F c; 0 1], G~ = [G; 0], Hxx~ = [Hxx rx; rx' 0], Hux~ = [Hxu' | ru], Huu
-            make_gather3(gF, lane, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(0, r * NX + c) : ((r < NX && c == NX) ? L::C0 + r : ((r == NX && c == NX) ? L::ONEB : -1)); });
-            make_gather3(gY, lane, L::CB0, [&](int r, int c) { return (r < NX && c < M) ? codeS(1, r * NU + c) : -1; });
-            make_gather3(gHxx, lane, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(2, r * NX + c) : ((r < NX && c == NX) ? L::RX + r : ((r == NX && c < NX) ? L::RX + c : -1)); });
-            make_gather3(gHux, lane, L::CB0, [&](int r, int c) { return (r < M && c < NX) ? codeS(3, c * NU + r) : ((r < M && c == NX) ? L::RU + r : -1); });
-            make_gather3(gHU, lane, L::CB0, [&](int r, int c) { return (r < M && c < M) ? codeS(4, r * NU + c) : -1; });
-            make_gather3(gHX, lane, L::CB0, [&](int r, int c) { return -1; });
-        } else {
-        make_gather3(gF, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(0, r * NX + (c & 3)) : -1)
-                                                                        : ((r < NX && c < NX) ? codeS(0, r * NX + c) : -1); });
-        make_gather3(gY, lane, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(1, r * NU + c) : (c == M ? L::C0 + r : -1)); });
-        make_gather3(gHux, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? codeS(3, (c & 3) * NU + r) : -1)
-                                                                          : ((r < M && c < NX) ? codeS(3, c * NU + r) : -1); });
-        make_gather3(gHxx, lane, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(2, r * NX + (c & 3)) : -1)
-                                                                          : ((r < NX && c < NX) ? codeS(2, r * NX + c) : -1); });
-        make_gather3(gHX, lane, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(3, r * NU + c) : (c == M ? L::RX + r : -1)); });
-        make_gather3(gHU, lane, L::CB0, [&](int r, int c) { return r >= M ? -1 : (c < M ? codeS(4, r * NU + c) : (c == M ? L::RU + r : -1)); });
-        }
-        make_gather3(gGr, lane, L::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
         const int col = tile_col(lane);
-        BufMap mK, mIK, mP, mW, mKT, mPld;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = tile_row(lane, r);
-            mK.voff[r] = (row < NU && col < NA) ? 8u * (unsigned)L::gK(row, col) : MS2_OOB;                           // K [NU x NX] (rep form: first column block) / K~ [NU x NA]
-            mIK.voff[r] = (row < NU && col == M) ? 8u * (unsigned)(NX * NU + row) : MS2_OOB;                          // k behind K (not in the homogeneous form)
-            mP.voff[r] = (row < NA && col < NA && (SMALL || row <= col)) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;   // P_{t+1}: full / upper triangle (of P~)
-            mW.voff[r] = (row < NX && col == M) ? 8u * (unsigned)(PSZ + row) : MS2_OOB;
-            mKT.voff[r] = (row < NA && (col & 3) < NU) ? 8u * (unsigned)L::gK(col & 3, row) : MS2_OOB;                // K (K~) read back transposed, replicated in the column blocks
-            mPld.voff[r] = (AUG && row < NA && col < NA) ? 8u * (unsigned)L::pk(row, col) : MS2_OOB;                   // P~ read back as a full tile from its upper triangle
-        }
         const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gw, 0, (int)((int64_t)T * GSZ * 8), 0x00020000);
         const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)pw, 0, (int)((int64_t)T * PWSZ * 8), 0x00020000);
-        // per-lane tile masks: diagonal of the n x n / m x m blocks
-        d4 dgN, dgM0 = z;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dgN[r] = SMALL ? ((r == 0 && (lane >> 4) == (col & 3) && (col & 3) < NX) ? 1.0 : 0.0) : ((tile_row(lane, r) == col && col < NX) ? 1.0 : 0.0);
-        dgM0[0] = ((lane >> 4) == col && col < M) ? 1.0 : 0.0;
-
         // residuals of the current iterate, as the evaluator's last accepted pass left them
         double f_cur = 0.0, th_cur = 0.0, inf_pr = 0.0, inf_du = 0.0, zmax = 0.0, lmax = 0.0, lamc = 0.0;
         bool finite = true;
@@ -449,6 +413,47 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // Backward sweep over the chunks of the current SWEEP command with Hessian scale hs (1; 0 = least-squares multiplier estimate: W = I,
         // no defects) and shift dw.  Returns true when every Quu was positive definite; stops at the first one that is not.
         auto backward = [&](double hs, double dw) -> bool {
+            // gather / store maps of this sweep (from an opaque lane id: see opaque())
+            const int ln = opaque(lane);
+            auto codeS = [](int mat, int i) { return Mdl::sol_code(mat, i); };       // 0 F, 1 G, 2 Hxx, 3 Hxu, 4 Huu
+            Gather3 gF, gY, gHxx, gHX, gHU, gGr, gHux;
+            if constexpr (AUG) {
+                // homogeneous form: F~ = [F c; 0 1], G~ = [G; 0], Hxx~ = [Hxx rx; rx' 0], Hux~ = [Hxu' | ru], Huu
+                make_gather3(gF, ln, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(0, r * NX + c) : ((r < NX && c == NX) ? L::C0 + r : ((r == NX && c == NX) ? L::ONEB : -1)); });
+                make_gather3(gY, ln, L::CB0, [&](int r, int c) { return (r < NX && c < M) ? codeS(1, r * NU + c) : -1; });
+                make_gather3(gHxx, ln, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(2, r * NX + c) : ((r < NX && c == NX) ? L::RX + r : ((r == NX && c < NX) ? L::RX + c : -1)); });
+                make_gather3(gHux, ln, L::CB0, [&](int r, int c) { return (r < M && c < NX) ? codeS(3, c * NU + r) : ((r < M && c == NX) ? L::RU + r : -1); });
+                make_gather3(gHU, ln, L::CB0, [&](int r, int c) { return (r < M && c < M) ? codeS(4, r * NU + c) : -1; });
+                make_gather3(gHX, ln, L::CB0, [&](int r, int c) { return -1; });
+            } else {
+            make_gather3(gF, ln, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(0, r * NX + (c & 3)) : -1)
+                                                                            : ((r < NX && c < NX) ? codeS(0, r * NX + c) : -1); });
+            make_gather3(gY, ln, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(1, r * NU + c) : (c == M ? L::C0 + r : -1)); });
+            make_gather3(gHux, ln, L::CB0, [&](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? codeS(3, (c & 3) * NU + r) : -1)
+                                                                              : ((r < M && c < NX) ? codeS(3, c * NU + r) : -1); });
+            make_gather3(gHxx, ln, L::CB0, [&](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? codeS(2, r * NX + (c & 3)) : -1)
+                                                                              : ((r < NX && c < NX) ? codeS(2, r * NX + c) : -1); });
+            make_gather3(gHX, ln, L::CB0, [&](int r, int c) { return r >= NX ? -1 : (c < M ? codeS(3, r * NU + c) : (c == M ? L::RX + r : -1)); });
+            make_gather3(gHU, ln, L::CB0, [&](int r, int c) { return r >= M ? -1 : (c < M ? codeS(4, r * NU + c) : (c == M ? L::RU + r : -1)); });
+            }
+            make_gather3(gGr, ln, L::CB0, [&](int r, int c) { return (r < NX && (c & 3) < NU) ? codeS(1, r * NU + (c & 3)) : -1; });
+            BufMap mK, mIK, mP, mW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tile_row(ln, r), colb = tile_col(ln);
+                mK.voff[r] = (row < NU && colb < NA) ? 8u * (unsigned)L::gK(row, colb) : MS2_OOB;                           // K [NU x NX] (rep form: first column block) / K~ [NU x NA]
+                mIK.voff[r] = (row < NU && colb == M) ? 8u * (unsigned)(NX * NU + row) : MS2_OOB;                          // k behind K (not in the homogeneous form)
+                mP.voff[r] = (row < NA && colb < NA && (SMALL || row <= colb)) ? 8u * (unsigned)L::pk(row, colb) : MS2_OOB;   // P_{t+1}: full / upper triangle (of P~)
+                mW.voff[r] = (row < NX && colb == M) ? 8u * (unsigned)(PSZ + row) : MS2_OOB;
+            }
+            // per-lane tile masks: diagonal of the n x n / m x m blocks
+            d4 dgN, dgM0 = z;
+            {
+                const int colb = tile_col(ln);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dgN[r] = SMALL ? ((r == 0 && (ln >> 4) == (colb & 3) && (colb & 3) < NX) ? 1.0 : 0.0) : ((tile_row(ln, r) == colb && colb < NX) ? 1.0 : 0.0);
+                dgM0[0] = ((ln >> 4) == colb && colb < M) ? 1.0 : 0.0;
+            }
             const bool scaled = !(hs == 1.0 && dw == 0.0);
             const double sU = col < M ? hs : 1.0, sC = col == M ? hs : 1.0;      // scale of the Hessian columns / of the defect column
             bool pdall = true, ok = true;
@@ -558,15 +563,24 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // Forward pass of the LQ problem over the forward chunks: dx, du (homogeneous form: and dlam) into the workspace; in the other forms the evaluator follows with dlam;
         // returns grad(phi)' d = grad(L)' d + lambda' c  (A d = -c)
         auto forward = [&](double hs) -> double {
+            const int ln = opaque(lane);
+            BufMap mKT, mPld, mIK;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = tile_row(ln, r), colf = tile_col(ln);
+                mIK.voff[r] = (row < NU && colf == M) ? 8u * (unsigned)(NX * NU + row) : MS2_OOB;                           // k behind K (not in the homogeneous form)
+                mKT.voff[r] = (row < NA && (colf & 3) < NU) ? 8u * (unsigned)L::gK(colf & 3, row) : MS2_OOB;                // K (K~) read back transposed, replicated in the column blocks
+                mPld.voff[r] = (AUG && row < NA && colf < NA) ? 8u * (unsigned)L::pk(row, colf) : MS2_OOB;                   // P~ read back as a full tile from its upper triangle
+            }
             Gather3 gFT, gGT, gE, gRX, gRU;
-            make_gather3(gFT, lane, L::CF0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::solf_code(0, (c & 3) * NX + r) : -1)
+            make_gather3(gFT, ln, L::CF0, [](int r, int c) { return SMALL ? ((r < NX && (c & 3) < NX) ? Mdl::solf_code(0, (c & 3) * NX + r) : -1)
                                                                           : ((r < NX && c < NX) ? Mdl::solf_code(0, c * NX + r)
                                                                              : (AUG && r == NX && c < NX ? L::FC0 + c : (AUG && r == NX && c == NX ? L::ONEF : -1))); });      // F~' = [F' 0; c' 1]
-            make_gather3(gGT, lane, L::CF0, [](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? Mdl::solf_code(1, (c & 3) * NU + r) : -1)
+            make_gather3(gGT, ln, L::CF0, [](int r, int c) { return SMALL ? ((r < M && (c & 3) < NX) ? Mdl::solf_code(1, (c & 3) * NU + r) : -1)
                                                                           : ((r < M && c < NX) ? Mdl::solf_code(1, c * NU + r) : -1); });
-            make_gather3(gE, lane, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
-            make_gather3(gRX, lane, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FRX + r : -1; });
-            make_gather3(gRU, lane, L::CF0, [](int r, int c) { return (r < M && c == M) ? L::FRU + r : -1; });
+            make_gather3(gE, ln, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FC0 + r : -1; });
+            make_gather3(gRX, ln, L::CF0, [](int r, int c) { return (r < NX && c == M) ? L::FRX + r : -1; });
+            make_gather3(gRU, ln, L::CF0, [](int r, int c) { return (r < M && c == M) ? L::FRU + r : -1; });
             BufMap mDX, mDU;                                 // dx_{t+1} / du_t: column M of the tile, row i to [i TS + stage]
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

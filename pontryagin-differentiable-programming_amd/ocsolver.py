@@ -77,36 +77,38 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
     torch = runtime.torch_cuda()
-    big = oc.model().n > 16 or oc.model().m > 4          # beyond the multiple-shooting kernel's tiles
-    if big and method != "single" and u_init is None and warm_start is None and oc.model().n <= 32 and oc.model().m <= 8:
-        # the same NLP and iteration, kernel by kernel (solve_batch_ms_generic); what it leaves unconverged goes on to single shooting below
-        ms = solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, print_level=print_level)
-        if bool(ms["converged"].all()) or method == "ms":
-            sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
-                   "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
-            if want_gains:                                   # (the LQR gains of the last Newton step are not kept on this route: single-shooting refinement provides them)
-                sub = solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=ms["control"], tol=tol, max_iter=max_iter, print_level=print_level,
-                                                  neighbor_retries=0, want_gains=True)
-                sol["gains"] = sub["gains"]
-            return sol
-    if method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start):
+    mdl = oc.model()
+    big = mdl.n > 16 or mdl.m > 4                         # beyond the multiple-shooting kernel's tiles
+    generic = big and method != "single" and u_init is None and warm_start is None and mdl.n <= 32 and mdl.m <= 8
+    if not generic and (method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start)):
         return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
                                            neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)
-    mdl = oc.model()
     x0 = runtime.dev(ini_state).reshape(-1, mdl.n)
     B = x0.shape[0]
     th = oc._theta(auxvar_value, B)
-    warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])
-    ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains,
-                         u_init=u_init if warm is None else None)      # method "ms" with starting controls: PDP_MS_FROM_CONTROLS
+    if generic:
+        # the same NLP and iteration, kernel by kernel (solve_batch_ms_generic)
+        ms = solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, print_level=print_level)
+    else:
+        warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])
+        ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains,
+                             u_init=u_init if warm is None else None)      # method "ms" with starting controls: PDP_MS_FROM_CONTROLS
     sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
            "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
     if want_gains:
-        sol["gains"] = ms["gains"]
+        if generic:
+            # (the LQR gains of the last Newton step are not kept on the kernel-by-kernel route: one single-shooting refinement step at the solution provides them)
+            sub = solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=ms["control"], tol=tol, max_iter=max_iter, print_level=print_level,
+                                              neighbor_retries=0, want_gains=True)
+            sol["gains"] = sub["gains"]
+        else:
+            sol["gains"] = ms["gains"]
     bad = ~ms["converged"]
     if print_level > 0:
         print("  multiple-shooting solve: %d/%d converged, max %d iterations" % (int(ms["converged"].sum()), B, sol["iterations"]))
-    if bool(bad.any()):
+    if bool(bad.any()) and not (generic and method == "ms"):
+        # ONLY the rows the multiple-shooting iteration left unconverged (no restoration possible, iteration limit) go on to single shooting; rows
+        # that converged keep IPOPT's optimum (a single-shooting solve from u = 0 may end in another basin - the rocket)
         bi = torch.nonzero(bad).flatten()
         th_np = np.asarray(th, dtype=np.float64).reshape(-1, oc.n_auxvar)
         thb = th_np[bi.cpu().numpy()] if th_np.shape[0] == B and B > 1 else th_np[0]

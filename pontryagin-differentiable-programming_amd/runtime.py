@@ -53,7 +53,8 @@ CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_bat
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_ms_residuals_batched",
                  "pdp_oc_auxsys_batched",
                  "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched", "pdp_oc_solve_ms_workspace_bytes", "pdp_oc_solve_ms_batched",
-                 "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
+                 "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_oc_riccati_doubles", "pdp_oc_pdp_grad_sens_batched", "pdp_oc_predict_batched",
+                 "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
 _core = None
@@ -232,6 +233,9 @@ _MODEL_SIGS = {
     "pdp_oc_solve_ms_batched": (_I, [_I, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcMsOpts), _VP, _I64, _VP]),
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "pdp_oc_riccati_doubles": (_I64, []),
+    "pdp_oc_pdp_grad_sens_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "pdp_oc_predict_batched": (_I, [_I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_cp_auxsys_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pdp_cp_step_workspace_bytes": (_I64, [_I, _I, C.POINTER(PdpPolicy), _I]),
@@ -409,10 +413,12 @@ class ModelLib:
         check(self.lib.pdp_oc_auxsys_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, C.byref(o), current_stream_ptr()), "pdp_oc_auxsys_batched")
         return out
 
-    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None, packed=False):
+    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None, packed=False, want_riccati=False):
         """Fused forward + Riccati + PDP gradient.  Give (x, lam) to use an optimal trajectory (PDP_OC_GIVEN_TRAJ),
-        else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp]).
-        packed: the kernel writes gradient and loss as one [B, p+1] tensor (PDP_OC_PACKED; out["packed"], out["grad"] is a view of it)."""
+        else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp][, riccati]).
+        packed: the kernel writes gradient and loss as one [B, p+1] tensor (PDP_OC_PACKED; out["packed"], out["grad"] is a view of it).
+        want_riccati (with want_sens: everything oc_predict needs): also the Riccati matrices of the auxiliary control system,
+        out["riccati"] [B, T, n n + n p + 1] = P_{t+1} | W_{t+1} | one scratch word per stage (pdp_oc_pdp_grad_sens_batched)."""
         torch = torch_cuda()
         u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
         B, T = u.shape[0], u.shape[1]
@@ -444,10 +450,17 @@ class ModelLib:
         status = buf("status", (B,), torch.int32)
         dxdp = buf("dxdp", (B, T + 1, n, p)) if want_sens else None
         dudp = buf("dudp", (B, T, m, p)) if want_sens else None
+        ric = buf("riccati", (B, T, int(self.lib.pdp_oc_riccati_doubles()))) if want_riccati else None
         nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
         ws = buf("ws", (max(nbytes, 8) // 8,))
-        rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
-                                              ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+        if want_riccati:
+            rc = self.lib.pdp_oc_pdp_grad_sens_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
+                                                       ptr(pk), ptr(dxdp), ptr(dudp), ptr(ric), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+            if rc == -2:
+                raise RuntimeError("pdp_oc_pdp_grad_sens_batched: the Riccati record is an output of the fused kernels (n <= 16, m <= 4, m + p <= 16)")
+        else:
+            rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
+                                                  ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
         if rc == -2 and self.n <= 32 and self.m <= 8:
             # m + p > 16 (beyond the fused kernel's single parameter tile), n > 16 / m > 4 (beyond one tile per matrix: the generic LQR
             # kernel takes over), or a horizon whose staging exceeds the LDS: the reference's own route, kernel by kernel
@@ -466,7 +479,24 @@ class ModelLib:
             out["packed"] = pk
         if want_sens:
             out.update(dxdp=dxdp, dudp=dudp)
+        if want_riccati:
+            out["riccati"] = ric
         return out
+
+    def oc_predict(self, x, u, lam, dtheta, dxdp, dudp, riccati=None):
+        """First-order prediction of the optimal (x, u, lam) at theta + dtheta from the gradient unit's sensitivity outputs (pdp_oc_predict_batched):
+        returns NEW tensors x + X dtheta, u + U dtheta and - with `riccati` - lam_t + P_{t+1} X_{t+1} dtheta + W_{t+1} dtheta (else lam unchanged).
+        dtheta [p] (shared) or [B, p].  What an IRL loop hands to oc_solve_ms(warm=...) at the next parameter."""
+        torch = torch_cuda()
+        x, u, lam = dev(x).clone(), dev(u).clone(), dev(lam).clone()
+        B, T = u.shape[0], u.shape[1]
+        dth, dtb = self._theta(dtheta, B)
+        dxdp, dudp = dev(dxdp), dev(dudp)
+        assert dxdp.shape == (B, T + 1, self.n, self.p) and dudp.shape == (B, T, self.m, self.p)
+        ric = dev(riccati) if riccati is not None else None
+        check(self.lib.pdp_oc_predict_batched(B, T, ptr(dth), dtb, ptr(dxdp), ptr(dudp), ptr(ric), ptr(x), ptr(u), ptr(lam) if ric is not None else None,
+                                              current_stream_ptr()), "pdp_oc_predict_batched")
+        return x, u, lam
 
     def _oc_pdp_grad_materialised(self, u, theta, demo_x, demo_u, x0, x, lam, flags, loss, grad, status, dxdp=None, dudp=None):
         """The PDP gradient unit by the reference's own route (PDP.py:272-314, 557-608 and the chain rule of cartpole_PDP.py:63-74), one

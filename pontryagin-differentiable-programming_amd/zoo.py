@@ -49,12 +49,26 @@ FENCED = ("quadrotor_oc_", "rocket_oc_")
 _registered = False
 
 
-def register_tuned():
-    """Enter the exact generated names of the zoo models into codegen.TUNED_NAMES (see there)."""
+def tuned_names():
+    """the exact generated names (label + kind + content hash) of the zoo models"""
+    return sorted(codegen.generate(make_problem(*key))[1]["name"] for key in SPECS)
+
+
+def register_tuned(write=True):
+    """Bring codegen.TUNED_NAMES (read from csrc/generated/tuned_names.txt at import) up to date with the generator: a no-op on a current tree; after a
+    change of the generator or of a model the file is rewritten (write=True) and the set updated."""
     global _registered
     if not _registered:
-        for key in SPECS:
-            codegen.TUNED_NAMES.add(codegen.generate(make_problem(*key))[1]["name"])
+        names = tuned_names()
+        if set(names) != codegen.TUNED_NAMES:
+            codegen.TUNED_NAMES.clear()
+            codegen.TUNED_NAMES.update(names)
+            if write:
+                import os
+                tmp = "%s.%d.tmp" % (codegen.TUNED_FILE, os.getpid())
+                with open(tmp, "w") as f:
+                    f.write("# generated names of the zoo models (pdp_amd.zoo.register_tuned): the only models built with codegen.HIP_FLAGS\n" + "\n".join(names) + "\n")
+                os.replace(tmp, codegen.TUNED_FILE)
         _registered = True
 
 

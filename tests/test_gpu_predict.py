@@ -1,0 +1,128 @@
+"""GPU: the sensitivity-predicted starting point of an IRL loop's next OC solve (round 4).
+
+The auxiliary control system of PDP IS the derivative of the optimal trajectory with respect to theta (reference PDP/PDP.py:272-314 getAuxSys,
+557-608 lqrSolver: X = dx/dtheta, U = du/dtheta, Lambda_t = P_{t+1} X_{t+1} + W_{t+1}).  The gradient unit keeps it on request
+(pdp_oc_pdp_grad_sens_batched: dxdp, dudp and the Riccati record P_{t+1} | W_{t+1}), pdp_oc_predict_batched applies it to a parameter step, and the
+multiple-shooting solver started there (PDP_MS_WARM) needs one Newton iteration fewer than from the previous solution.  Checked here against the oracle:
+the record against lqr_solver's PP / WW, the predicted point against ipopt_ms.predict_start, the solve from it against ipopt_ms.solve(warm=...) row by row."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(golden_dir, name):
+    from oracle import models, pdp_oracle as po
+    from pdp_amd import zoo
+    d = np.load(os.path.join(golden_dir, "demos_%s.npz" % name))
+    st = models.IRL_SETUP[name]
+    oc = po.make_oc(models.REGISTRY[name](**st["kwargs"]), st["dt"])
+    return d, oc, zoo.get(name, "irl")
+
+
+def solve_at(mdl, x0, th, T):
+    sol = mdl.oc_solve_ms(x0, th, T, tol=1e-11)
+    assert bool(sol["converged"].all())
+    return sol
+
+
+@pytest.mark.parametrize("name", ["pendulum", "cartpole", "robotarm", "quadrotor", "rocket"])
+def test_riccati_record_and_predicted_point_match_the_oracle(golden_dir, margins, name):
+    """at the optimum of the stored demos' problems: the Riccati record the gradient unit leaves is PP[t], WW[t] of the reference's lqrSolver on the aux system
+    of that point, and (x, u, lam) + (X, U, Lambda) dtheta from pdp_oc_predict_batched is the oracle's predict_start - with per-sample and shared dtheta, with and
+    without the multiplier part; the gradient itself is unchanged by asking for the record."""
+    from oracle import ipopt_ms, pdp_oracle as po
+    d, oc, mdl = setup(golden_dir, name)
+    th = d["true_parameter"]
+    B, T = d["state"].shape[0], d["control"].shape[1]
+    sol = solve_at(mdl, d["state"][:, 0], th, T)
+    out = mdl.oc_pdp_grad(sol["control"], th, d["state"], d["control"], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True)
+    ref = mdl.oc_pdp_grad(sol["control"], th, d["state"], d["control"], x=sol["state"], lam=sol["costate"], want_sens=True)
+    assert int(out["status"].sum()) == 0
+    for k in ("loss", "grad", "dxdp", "dudp"):
+        assert bool((out[k] == ref[k]).all()), k                       # same arithmetic: the record is a by-product
+    n, p = oc.n, oc.p
+    ric = out["riccati"].cpu().numpy()
+    assert ric.shape == (B, T, n * n + n * p + 1)
+    rng = np.random.default_rng(3)
+    dth = th[None] * 0.02 * rng.uniform(-1, 1, (B, p))
+    xs, us, ls = (sol[k].cpu().numpy() for k in ("state", "control", "costate"))
+    xp, up, lp = (a.cpu().numpy() for a in mdl.oc_predict(sol["state"], sol["control"], sol["costate"], dth, out["dxdp"], out["dudp"], out["riccati"]))
+    xq, uq, lq = (a.cpu().numpy() for a in mdl.oc_predict(sol["state"], sol["control"], sol["costate"], dth, out["dxdp"], out["dudp"]))
+    assert (lq == ls).all() and (xq == xp).all() and (uq == up).all()     # without the record: multipliers untouched, the rest identical
+    xs1, us1, ls1 = (a.cpu().numpy() for a in mdl.oc_predict(sol["state"], sol["control"], sol["costate"], dth[0], out["dxdp"], out["dudp"], out["riccati"]))
+    sc = lambda a: max(1.0, np.abs(a).max())
+    for i in range(min(B, 3)):
+        aux = oc.getAuxSys(xs[i], us[i], ls[i], th)
+        lqr = po.lqr_from_aux(aux, n, p, T)
+        PP, WW = np.stack(lqr["PP"]), np.stack(lqr["WW"])
+        margins.check("Riccati record of the gradient unit vs lqr_solver PP, %s sample %d (relative to the largest entry)" % (name, i),
+                      np.abs(ric[i, :, :n * n].reshape(T, n, n) - PP).max() / sc(PP), 1e-9)
+        margins.check("Riccati record of the gradient unit vs lqr_solver WW, %s sample %d" % (name, i),
+                      np.abs(ric[i, :, n * n:n * n + n * p].reshape(T, n, p) - WW).max() / sc(WW), 1e-9)
+        ex, eu, el = ipopt_ms.predict_start(oc, xs[i], us[i], ls[i], th, dth[i])
+        margins.check("predicted state vs oracle predict_start, %s sample %d" % (name, i), np.abs(xp[i] - ex).max() / sc(ex), 1e-10)
+        margins.check("predicted control vs oracle predict_start, %s sample %d" % (name, i), np.abs(up[i] - eu).max() / sc(eu), 1e-10)
+        margins.check("predicted costate vs oracle predict_start, %s sample %d" % (name, i), np.abs(lp[i] - el).max() / sc(el), 1e-9)
+    ex, eu, el = ipopt_ms.predict_start(oc, xs[B - 1], us[B - 1], ls[B - 1], th, dth[0])      # shared dtheta (stride 0) reaches the last sample too
+    assert np.abs(xs1[B - 1] - ex).max() <= 1e-10 * sc(ex) and np.abs(ls1[B - 1] - el).max() <= 1e-9 * sc(el) and np.abs(us1[B - 1] - eu).max() <= 1e-10 * sc(eu)
+    assert (xp[:, 0] == xs[:, 0]).all()                                    # x_0 is fixed: X_0 = 0
+
+
+@pytest.mark.parametrize("name,rel", [("cartpole", 0.05), ("quadrotor", 0.02), ("rocket", 0.02)])
+def test_ms_kernel_from_the_predicted_start_follows_the_oracle(golden_dir, name, rel):
+    """an IRL step: solve at theta, predict to theta' = theta (1 +- rel), solve at theta' from the predicted point.  The kernel's iteration log from that
+    start equals the restatement's (ipopt_ms.solve(warm=predict_start(...))) row by row, it ends in the same optimum as a plain warm start - and takes
+    fewer iterations than that."""
+    from oracle import ipopt_ms
+    d, oc, mdl = setup(golden_dir, name)
+    th = d["true_parameter"]
+    T = d["control"].shape[1]
+    x0 = d["state"][:1, 0]
+    sol = solve_at(mdl, x0, th, T)
+    out = mdl.oc_pdp_grad(sol["control"], th, d["state"][:1], d["control"][:1], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True)
+    rng = np.random.default_rng(7)
+    th1 = th * (1 + rel * rng.uniform(-1, 1, th.shape))
+    pred = mdl.oc_predict(sol["state"], sol["control"], sol["costate"], th1 - th, out["dxdp"], out["dudp"], out["riccati"])
+    xs, us, ls = (sol[k][0].cpu().numpy() for k in ("state", "control", "costate"))
+    log = []
+    ref = ipopt_ms.solve(oc, x0[0], T, th1, tol=1e-10, log=log, warm=ipopt_ms.predict_start(oc, xs, us, ls, th, th1 - th))
+    got = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=pred, log_rows=len(log) + 4)
+    plain = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]))
+    assert bool(got["converged"][0]) and int(got["status"][0]) == 0 and bool(plain["converged"][0])
+    assert int(got["iterations"][0]) == ref["iterations"] == len(log)
+    assert int(got["iterations"][0]) < int(plain["iterations"][0])
+    kl = got["log"][0].cpu().numpy()
+    for r, l in zip(kl, log):
+        assert r[5] == l["alpha"] and r[4] == l["dw"], (name, l["it"], r[4], r[5], l["dw"], l["alpha"])
+        assert abs(r[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r[2] - l["inf_pr"]) <= 1e-8 * max(1e-3, l["inf_pr"])
+    sc = lambda a: max(1.0, np.abs(a).max())
+    for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+        assert np.abs(got[k][0].cpu().numpy() - ref[kr]).max() <= 1e-9 * sc(ref[kr])
+        assert float((got[k] - plain[k]).abs().max()) <= 1e-8 * sc(ref[kr])
+
+
+def test_predicted_start_cuts_the_iterations_of_a_batch(golden_dir):
+    """BASELINE config C2's shape: 256 cart-pole problems, per-sample parameters theta* +- 0.05.  From the predicted point the slowest trajectory of the batch
+    (the launch lasts as long as it does) needs fewer iterations than from the solution at theta*, and every sample lands in the same optimum."""
+    _, _, mdl = setup(golden_dir, "cartpole")
+    rng = np.random.default_rng(0)
+    B, T = 256, 50
+    th = np.array([0.5, 0.5, 1, 1, 6, 1, 1.0])
+    x0 = np.zeros((B, 4))
+    x0[:, 1] = rng.uniform(-0.5, 0.5, B)
+    th1 = th[None] + rng.uniform(-0.05, 0.05, (B, 7))
+    sol = solve_at(mdl, x0, th, T)
+    demo = (sol["state"], sol["control"])
+    out = mdl.oc_pdp_grad(sol["control"], th, demo[0], demo[1], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True)
+    pred = mdl.oc_predict(sol["state"], sol["control"], sol["costate"], th1 - th[None], out["dxdp"], out["dudp"], out["riccati"])
+    a = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]))
+    b = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=pred)
+    assert bool(a["converged"].all()) and bool(b["converged"].all())
+    ia, ib = a["iterations"].double(), b["iterations"].double()
+    print("iterations from the previous solution: mean %.2f max %d; from the predicted point: mean %.2f max %d" % (float(ia.mean()), int(ia.max()), float(ib.mean()), int(ib.max())))
+    assert float(ib.mean()) <= float(ia.mean()) - 0.5 and int(ib.max()) < int(ia.max())
+    for k in ("state", "control", "costate"):
+        assert float((a[k] - b[k]).abs().max()) <= 1e-7 * max(1.0, float(a[k].abs().max()))
