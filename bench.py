@@ -205,25 +205,51 @@ def other_configs(torch):
         cold_ms = _event_ms(torch, lambda: mdl.oc_solve_ms(x0d, th_star, T), reps=3, warm=1)
         demo = mdl.oc_solve_ms(x0d, th_star, T)                                    # demonstrations: optimum at theta* (cold, zero guess)
         warm = (demo["state"], demo["control"], demo["costate"])
-        solve_ms = _event_ms(torch, lambda: mdl.oc_solve_ms(x0d, theta1, T, warm=warm), reps=5, warm=1)
-        sol = mdl.oc_solve_ms(x0d, theta1, T, warm=warm)
-        # the same warm solve stopped where the reference's IPOPT stops (its default tol = 1e-8; the figures above use the 1e-10 the parity tests need)
-        solve8_ms = _event_ms(torch, lambda: mdl.oc_solve_ms(x0d, theta1, T, warm=warm, tol=1e-8), reps=5, warm=1)
-        sol8 = mdl.oc_solve_ms(x0d, theta1, T, warm=warm, tol=1e-8)
+        # (a) round 3's iteration: the solve at theta_{k+1} starts from the solution at theta_k
+        plain_ms = _event_ms(torch, lambda: mdl.oc_solve_ms(x0d, theta1, T, warm=warm), reps=5, warm=1)
+        plain = mdl.oc_solve_ms(x0d, theta1, T, warm=warm)
+        # (b) round 4: it starts from the FIRST-ORDER PREDICTION  (x, u, lam)_k + (X, U, Lambda)_k (theta_{k+1} - theta_k)  - the auxiliary control system the
+        # gradient unit solves at theta_k IS that derivative; the unit keeps X, U and the Riccati record (pdp_oc_pdp_grad_sens_batched), pdp_oc_predict_batched
+        # applies them.  An iteration = predict + solve + gradient unit (with the record, for the NEXT iteration's prediction).
+        th_b = torch.as_tensor(th_star, dtype=torch.float64, device="cuda")
+        dth = (theta1 - th_b.view(1, -1)).contiguous()
+        bufs0, bufs = {}, {}
+        sens0 = mdl.oc_pdp_grad(demo["control"], th_star, demo["state"], demo["control"], x=demo["state"], lam=demo["costate"], want_sens=True, want_riccati=True, buffers=bufs0)
+        use_ric = system == "cartpole" or os.environ.get("PDP_BENCH_PREDICT_LAMBDA", "1") != "0"
+        ric0 = sens0["riccati"] if use_ric else None
+
+        def predicted_solve(tol=1e-10):
+            pred = mdl.oc_predict(demo["state"], demo["control"], demo["costate"], dth, sens0["dxdp"], sens0["dudp"], ric0)
+            return mdl.oc_solve_ms(x0d, theta1, T, warm=pred, consume_warm=True, tol=tol)
+        predict_ms = _event_ms(torch, lambda: mdl.oc_predict(demo["state"], demo["control"], demo["costate"], dth, sens0["dxdp"], sens0["dudp"], ric0), reps=5, warm=1)
+        solve_ms = _event_ms(torch, predicted_solve, reps=5, warm=1)            # prediction + solve
+        sol = predicted_solve()
+        # the same stopped where the reference's IPOPT stops (its default tol = 1e-8; the figures above use the 1e-10 the parity tests need)
+        solve8_ms = _event_ms(torch, lambda: predicted_solve(1e-8), reps=5, warm=1)
+        sol8 = predicted_solve(1e-8)
         it8 = sol8["iterations"].double()
-        bufs = {}
         grad_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], buffers=bufs))
-        it, itc = sol["iterations"].double(), demo["iterations"].double()
-        entry(key, B, solve_ms + grad_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
-              note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); OC solve (pdp_oc_solve_ms_batched, warm start from the solution at theta*) + fused "
-                   "aux/Riccati/gradient unit; the flop figure is section 8d's for the gradient unit (it has none for the solve)",
-              extra={"oc_solve_ms": solve_ms, "gradient_ms": grad_ms, "oc_solve_converged": int(sol["converged"].sum()),
+        bufs_s = {}
+        grad_sens_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], want_sens=True,
+                                                                want_riccati=use_ric, buffers=bufs_s))
+        it, itc, itp = sol["iterations"].double(), demo["iterations"].double(), plain["iterations"].double()
+        agree = max(float((sol[k] - plain[k]).abs().max()) / max(1.0, float(plain[k].abs().max())) for k in ("state", "control", "costate"))
+        entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
+              note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); one IRL iteration = first-order prediction of the starting point from the previous iteration's "
+                   "sensitivities (pdp_oc_predict_batched) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / Riccati / gradient unit keeping X, U%s for the next "
+                   "prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit (it has none for the solve)" % (" and the Riccati record" if use_ric else ""),
+              extra={"oc_solve_ms": solve_ms, "of_which_prediction_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
+                     "prediction_includes_multipliers": bool(use_ric), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
+                     "solution_agrees_with_plain_warm_start_rel": agree,
+                     "round3_pipeline_plain_warm_start": {"oc_solve_ms": plain_ms, "gradient_ms": grad_ms, "iteration_ms": plain_ms + grad_ms,
+                                                          "traj_per_s": B / ((plain_ms + grad_ms) * 1e-3), "converged": int(plain["converged"].sum()),
+                                                          "iterations_mean_max": [float(itp.mean()), float(itp.max())]},
                      "oc_solve_cold_ms": cold_ms, "oc_solve_cold_converged": int(demo["converged"].sum()),
                      "oc_solve_cold_iterations_mean_max": [float(itc.mean()), float(itc.max())], "oc_solves_per_s_cold": B / (cold_ms * 1e-3),
                      "oc_solve_at_ipopt_default_tol_1e-8": {"ms": solve8_ms, "converged": int(sol8["converged"].sum()),
                                                             "iterations_mean_max": [float(it8.mean()), float(it8.max())],
-                                                            "irl_iteration_traj_per_s": B / ((solve8_ms + grad_ms) * 1e-3)}})
+                                                            "irl_iteration_traj_per_s": B / ((solve8_ms + grad_sens_ms) * 1e-3)}})
         if system == "cartpole":
             entry("C2_cartpole_gradient_unit_B256", B, grad_ms, flop=flop, T=T, latency_bound=True, note="aux system + Riccati + gradient at a given optimum (quarter-filled GPU)")
     # ---- C4 shard: rocket T=100, B=512: fused OC unit (p=10) and ControlPlanning.step (Lagrange policy p=18)
@@ -326,9 +352,11 @@ def scaling_configs(torch, dist, world, rank, steps):
             og.drain()
         torch.cuda.synchronize()
         kern_ms = _event_ms(torch, lambda: unit(og.buffers[0] if og is not None else None), reps=5, warm=1)
-        exch_us = None
+        exch_us, exch_ar_us = None, None
         if og is not None:
             exch_us = 1e3 * _event_ms(torch, lambda: parallel.gather_packed(og.buffers[0], out=og.gathered[0]), reps=5, warm=1)
+            # the other form of the exchange (what a gradient-descent driver needs: the batch mean only): local sum of the rows + ONE all-reduce of p + 1 doubles
+            exch_ar_us = 1e3 * _event_ms(torch, lambda: parallel.allreduce_mean_packed(og.buffers[0], B_total), reps=5, warm=1)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
@@ -341,9 +369,10 @@ def scaling_configs(torch, dist, world, rank, steps):
         if distributed:
             dist.barrier()
         dt = time.perf_counter() - t0
-        stats = torch.tensor([kern_ms, exch_us if exch_us is not None else 0.0, dt / steps * 1e3, float(b)], dtype=torch.float64, device="cuda")
+        stats = torch.tensor([kern_ms, exch_us if exch_us is not None else 0.0, dt / steps * 1e3, float(b), exch_ar_us if exch_ar_us is not None else 0.0],
+                             dtype=torch.float64, device="cuda")
         if distributed:
-            allr = torch.empty((world, 4), dtype=torch.float64, device="cuda")
+            allr = torch.empty((world, 5), dtype=torch.float64, device="cuda")
             dist.all_gather_into_tensor(allr, stats)
         else:
             allr = stats[None]
@@ -353,6 +382,8 @@ def scaling_configs(torch, dist, world, rank, steps):
         res[name] = {"total_batch": B_total, "shard_per_rank": [int(v) for v in allr[:, 3]], "scaling": "strong", "steps": steps,
                      "kernel_ms_per_rank": [float(v) for v in allr[:, 0]], "exchange_us_per_rank": [float(v) for v in allr[:, 1]] if distributed else None,
                      "exchange_bytes_per_rank": int(b * (p + 1) * 8) if distributed else 0,
+                     "exchange_allreduce_us_per_rank": [float(v) for v in allr[:, 4]] if distributed else None,
+                     "exchange_allreduce_bytes": int((p + 1) * 8) if distributed else 0,
                      "ms_per_step": step_ms, "traj_per_s": B_total / (step_ms * 1e-3),
                      "algorithmic_flop_per_traj": flop, "achieved_tflops_all_gpus": tf, "note": note}
         if latency_bound:       # one serial chain per trajectory: time per time step of a wavefront's chain instead of a roofline fraction (see other_configs)

@@ -1,9 +1,11 @@
 """Multi-GPU data parallelism of the PDP iteration: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over
 xGMI on ROCm, "gloo" on CPU for tests).  Trajectories are independent: the batch is cut into
-contiguous shards, every rank runs the same kernels on its shard with a replicated theta, and ONE all-gather of the
-per-sample gradients and losses `[B/G, p+1]` per iteration gives every rank the full `[B, p+1]`; the batch mean the
-reference takes (PDP/PDP.py:1293-1294, cartpole_PDP.py:77-78) is then a local reduction.  Message size at C3: 1024 x 10 x 8 B
-= 80 KB per rank - latency-bound over xGMI, so it is issued as a single collective, never per parameter."""
+contiguous shards, every rank runs the same kernels on its shard with a replicated theta, and ONE collective per iteration follows.  Two forms of it:
+  * all-gather of the per-sample gradients and losses `[B/G, p+1]` - every rank ends with the full `[B, p+1]` (BASELINE.json's "all-gather of per-sample PDP
+    gradients"); the batch mean the reference takes (PDP/PDP.py:1293-1294, cartpole_PDP.py:77-78) is then a local reduction.  Message size at C3:
+    1024 x 10 x 8 B = 80 KB per rank - latency-bound over xGMI, so it is a single collective, never one per parameter;
+  * all-reduce of the locally summed row `[p+1]` (allreduce_mean_packed, mode="allreduce") - what a driver that only needs the mean should use: 3.4 KB at
+    C5b (p = 420) instead of 27.6 MB received per rank."""
 import torch
 import torch.distributed as dist
 
@@ -47,18 +49,46 @@ def gather_loss_grad(loss, grad, n_total=None):
     return rows[:, p].contiguous(), rows[:, :p].contiguous()
 
 
-def mean_loss_grad(loss, grad, n_total=None):
-    """the reference's batch mean of (loss, gradient) over ALL trajectories of all ranks"""
+def allreduce_mean_packed(packed, n_total=None):
+    """The reference only ever uses the batch MEAN of the per-sample losses and gradients (PDP/PDP.py:1293-1294; Examples/IRL/cartpole/cartpole_PDP.py:77-78), so
+    the exchange of a gradient-descent driver need not move the rows at all: every rank sums its [b, p+1] rows (gradient | loss, the layout PDP_OC_PACKED writes)
+    on the GPU and ONE all-reduce of p + 1 doubles follows - 3.4 KB at C5b (p = 420) where the all-gather hands every rank 8192 x 421 x 8 B = 27.6 MB.
+    Ragged shards need no padding (a sum does not care).  Returns the mean row [p+1] (gradient mean | loss mean) on every rank.
+    n_total: the number of trajectories over all ranks (None: it is all-reduced along, as one more entry of the same message)."""
+    s = packed.sum(dim=0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return s / float(packed.shape[0] if n_total is None else n_total)
+    if n_total is None:
+        s = torch.cat([s, torch.tensor([float(packed.shape[0])], dtype=s.dtype, device=s.device)])
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return s[:-1] / s[-1]
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return s / float(n_total)
+
+
+def mean_loss_grad(loss, grad, n_total=None, mode="allgather"):
+    """the reference's batch mean of (loss, gradient) over ALL trajectories of all ranks.
+    mode "allgather": every rank receives every per-sample row and reduces locally (for callers that also want the rows);
+    mode "allreduce": local sums, one all-reduce of p + 1 doubles (allreduce_mean_packed) - the exchange a driver that only needs the mean should use.
+    The two agree to the rounding of the summation order."""
+    if mode == "allreduce":
+        m = allreduce_mean_packed(torch.cat([grad, loss[:, None]], dim=1), n_total)
+        return m[-1], m[:-1]
+    assert mode == "allgather", mode
     L, G = gather_loss_grad(loss, grad, n_total)
     return L.mean(), G.mean(dim=0)
 
 
-def pdp_iteration(unit, shard_inputs, n_total=None):
+def pdp_iteration(unit, shard_inputs, n_total=None, mode="allgather"):
     """One data-parallel PDP iteration: `unit(**shard_inputs)` must return a dict with per-sample 'loss' [b] and 'grad' [b,p]
-    computed on this rank's shard (e.g. OCSys.pdp_grad_batch, or (loss, grad) from ControlPlanning.step_batch / SysID.step_batch)."""
+    computed on this rank's shard (e.g. OCSys.pdp_grad_batch, or (loss, grad) from ControlPlanning.step_batch / SysID.step_batch);
+    a dict with 'packed' [b, p+1] (PDP_OC_PACKED) is reduced without a packing copy in mode "allreduce"."""
     out = unit(**shard_inputs)
+    if mode == "allreduce" and isinstance(out, dict) and "packed" in out:
+        m = allreduce_mean_packed(out["packed"], n_total)
+        return m[-1], m[:-1]
     loss, grad = (out["loss"], out["grad"]) if isinstance(out, dict) else out
-    return mean_loss_grad(loss, grad, n_total)
+    return mean_loss_grad(loss, grad, n_total, mode)
 
 
 def gather_packed(packed, n_total=None, out=None):

@@ -335,12 +335,13 @@ class ModelLib:
             out["gains"] = gains
         return out
 
-    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None):
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False):
         """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
         (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
         from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
         PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  u_init [B, T, m] (instead of warm): start from these
-        controls, their rollout and the least-squares multiplier estimate (PDP_MS_FROM_CONTROLS).  Returns dict(state, control, costate, cost,
+        controls, their rollout and the least-squares multiplier estimate (PDP_MS_FROM_CONTROLS).  consume_warm: the warm tensors themselves become the outputs
+        (no copies: for callers that built the starting point for this call, e.g. oc_predict).  Returns dict(state, control, costate, cost,
         resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
@@ -349,7 +350,7 @@ class ModelLib:
         f64 = dict(dtype=torch.float64, device="cuda")
         if warm is not None:
             assert u_init is None, "warm and u_init exclude each other"
-            x, u, lam = (dev(a).clone().contiguous() for a in warm)
+            x, u, lam = ((dev(a).contiguous() if consume_warm else dev(a).clone().contiguous()) for a in warm)
             assert x.shape == (B, T + 1, self.n) and u.shape == (B, T, self.m) and lam.shape == (B, T, self.n)
         elif u_init is not None:
             u = dev(u_init).clone().contiguous()

@@ -38,6 +38,16 @@ def _worker(rank, world, port, n_total, q):
     L, G = parallel.gather_loss_grad(out["loss"], out["grad"], n_total)
     Lm, Gm = parallel.pdp_iteration(_fake_unit, dict(x=xs, theta=theta), n_total)
     L2, G2 = parallel.gather_loss_grad(out["loss"], out["grad"])        # sizes exchanged instead of given
+    # the all-reduce form of the exchange (only the batch mean travels: p + 1 doubles), ragged shards included, with and without the total given
+    La, Ga = parallel.pdp_iteration(_fake_unit, dict(x=xs, theta=theta), n_total, mode="allreduce")
+    Lb, Gb = parallel.mean_loss_grad(out["loss"], out["grad"], None, mode="allreduce")
+    assert abs(float(La) - float(Lm)) <= 1e-15 * abs(float(Lm)) and torch.allclose(Ga, Gm, rtol=1e-14, atol=0)
+    assert abs(float(Lb) - float(Lm)) <= 1e-15 * abs(float(Lm)) and torch.allclose(Gb, Gm, rtol=1e-14, atol=0)
+    mrow = parallel.allreduce_mean_packed(torch.cat([out["grad"], out["loss"][:, None]], dim=1), n_total)
+    assert torch.allclose(mrow[:3], Gm, rtol=1e-14, atol=0) and abs(float(mrow[3]) - float(Lm)) <= 1e-15 * abs(float(Lm))
+    Lp, Gp = parallel.pdp_iteration(lambda **kw: {"packed": torch.cat([_fake_unit(**kw)["grad"], _fake_unit(**kw)["loss"][:, None]], dim=1)}, dict(x=xs, theta=theta),
+                                    n_total, mode="allreduce")
+    assert torch.equal(Gp, mrow[:3]) and float(Lp) == float(mrow[3])
     # the packed [b, p+1] rows the fused kernel writes with PDP_OC_PACKED: one collective, no packing copies (ragged: padded route)
     pk = torch.cat([out["grad"], out["loss"][:, None]], dim=1)
     rows = parallel.gather_packed(pk, n_total)
