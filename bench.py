@@ -218,9 +218,11 @@ def other_configs(torch):
         use_ric = system == "cartpole" or os.environ.get("PDP_BENCH_PREDICT_LAMBDA", "1") != "0"
         ric0 = sens0["riccati"] if use_ric else None
 
-        def predicted_solve(tol=1e-10):
-            pred = mdl.oc_predict(demo["state"], demo["control"], demo["costate"], dth, sens0["dxdp"], sens0["dudp"], ric0)
-            return mdl.oc_solve_ms(x0d, theta1, T, warm=pred, consume_warm=True, tol=tol)
+        pred_in = dict(dtheta=dth, dxdp=sens0["dxdp"], dudp=sens0["dudp"], riccati=ric0)
+        copies = [tuple(a.clone() for a in warm) for _ in range(16)]          # an IRL loop solves IN PLACE on the previous solution: every timed call gets its own copy of it
+
+        def predicted_solve(tol=1e-10):       # PDP_MS_PREDICT: the prediction is applied while the solver loads the point (one launch)
+            return mdl.oc_solve_ms(x0d, theta1, T, warm=copies.pop(), consume_warm=True, predict=pred_in, tol=tol)
         predict_ms = _event_ms(torch, lambda: mdl.oc_predict(demo["state"], demo["control"], demo["costate"], dth, sens0["dxdp"], sens0["dudp"], ric0), reps=5, warm=1)
         solve_ms = _event_ms(torch, predicted_solve, reps=5, warm=1)            # prediction + solve
         sol = predicted_solve()
@@ -236,9 +238,9 @@ def other_configs(torch):
         agree = max(float((sol[k] - plain[k]).abs().max()) / max(1.0, float(plain[k].abs().max())) for k in ("state", "control", "costate"))
         entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
               note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); one IRL iteration = first-order prediction of the starting point from the previous iteration's "
-                   "sensitivities (pdp_oc_predict_batched) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / Riccati / gradient unit keeping X, U%s for the next "
+                   "sensitivities (PDP_MS_PREDICT: applied inside the solver launch; the same numbers as pdp_oc_predict_batched) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / Riccati / gradient unit keeping X, U%s for the next "
                    "prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit (it has none for the solve)" % (" and the Riccati record" if use_ric else ""),
-              extra={"oc_solve_ms": solve_ms, "of_which_prediction_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
+              extra={"oc_solve_ms": solve_ms, "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
                      "prediction_includes_multipliers": bool(use_ric), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
                      "solution_agrees_with_plain_warm_start_rel": agree,

@@ -2,8 +2,9 @@
 """Inverse reinforcement learning with PDP on the GPU - the loop of the reference's Examples/IRL/<sys>/<sys>_PDP.py
 (e.g. cartpole_PDP.py:32-94) with the per-demo Python loop replaced by ONE batched launch per stage:
 
-    for k in iterations:   traj  = ocSolver(theta_k)                     (batched Newton/iLQR on the GPU, warm-started)
-                           loss, dp = aux system + Riccati + chain rule  (fused kernel)
+    for k in iterations:   traj  = ocSolver(theta_k)                     (IPOPT's iteration in one GPU launch, started from the first-order PREDICTION
+                                                                          traj_{k-1} + d traj / d theta (theta_k - theta_{k-1}) the previous gradient step provides)
+                           loss, dp = aux system + Riccati + chain rule  (fused kernel; keeps d traj / d theta for the next prediction)
                            theta_{k+1} = theta_k - lr * mean(dp)
 
 Demonstrations: the reference's stored demos (examples/data/demos_<sys>.npz, copies of the extracts under tests/golden), or any `<name>_demos.mat` written by the reference's
@@ -66,16 +67,22 @@ def main():
     rng = np.random.default_rng(a.seed)
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2
     loss_trace, parameter_trace = [], []
-    warm = None
+    warm, predict, theta_prev = None, None, None
+    fused = oc.model().n <= 16 and oc.model().m <= 4 and oc.model().m + oc.model().p <= 16      # the kernels that keep the sensitivities
     t0 = time.time()
     for k in range(a.iters):
-        # first iterate: cold, the reference's all-zero guess (PDP.py:155,166); afterwards the multiple-shooting solver starts from the
-        # previous iterate's (x, u, lambda) - the parameters move by lr * gradient per step - and needs 2-4 Newton iterations
-        sol = ocsolver.solve_batch(oc, demo_x[:, 0], T, theta, warm_start=warm)
+        # first iterate: cold, the reference's all-zero guess (PDP.py:155,166).  Afterwards the multiple-shooting solver starts from the previous solution moved
+        # along its own sensitivities, (x, u, lambda)_{k-1} + (X, U, Lambda)_{k-1} (theta_k - theta_{k-1}) - the auxiliary control system the gradient step has just
+        # solved IS that derivative (PDP.py:582-608) - and needs about one Newton iteration (two from the unmoved previous solution)
+        if predict is not None:
+            predict["dtheta"] = theta - theta_prev
+        sol = ocsolver.solve_batch(oc, demo_x[:, 0], T, theta, warm_start=warm, predict=predict)
         if not bool(sol["converged"].all()):
             print("iter %5d  warning: %d of %d OC solves did not converge" % (k, int((~sol["converged"]).sum()), demo_x.shape[0]))
         warm = {key: sol[key] for key in ("state", "control", "costate")}
-        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"])
+        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"], want_sens=fused, want_riccati=fused)
+        if fused:
+            predict, theta_prev = {"dxdp": out["dxdp"], "dudp": out["dudp"], "riccati": out["riccati"]}, theta.copy()
         if int(out["status"].sum()) != 0:
             print("iter %5d  warning: Riccati sweep reported numerical trouble on %d trajectories" % (k, int((out["status"] != 0).sum())))
         loss = float(out["loss"].mean())

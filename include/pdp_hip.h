@@ -216,11 +216,20 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
 #define PDP_MS_NOGAINS 32
 #define PDP_MS_INTERNAL 64
 #define PDP_MS_RESTORED 128       /* informational: the line search fell below alpha_min at least once and the feasibility restoration below was used */
+#define PDP_MS_PREDICT 16         /* opts.flags, with PDP_MS_WARM: the starting point is the FIRST-ORDER PREDICTION from (x, u, lam) on entry - the solution at the previous
+                                     parameter - for the step opts.dtheta:  x + X dtheta, u + U dtheta, lam_t + P_{t+1} X_{t+1} dtheta + W_{t+1} dtheta  with the outputs
+                                     dxdp, dudp, riccati of pdp_oc_pdp_grad_sens_batched at that solution (what pdp_oc_predict_batched computes, applied while the kernel
+                                     loads the point: no extra launch, no copy).  riccati may be NULL: multipliers as they are */
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;
-    int flags;    /* PDP_MS_WARM */
+    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT */
     int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
+    int dtheta_bstride;        /* PDP_MS_PREDICT: dtheta [B][p] (stride p) or shared [p] (stride 0) ... */
+    const double* dtheta;
+    const double* dxdp;        /* ... [B][T+1][n][p] */
+    const double* dudp;        /* ... [B][T][m][p] */
+    const double* riccati;     /* ... [B][T][pdp_oc_riccati_doubles()] or NULL */
 } pdp_oc_ms_opts;
 int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T, int max_iter);
 /* iter_log (optional, [B][opts->log_rows][8]): one row per accepted step, the columns of IPOPT's iteration output (print_level 5):

@@ -41,24 +41,44 @@ class OCSys:
         self._model = None
         self._bar_model = None
 
+    # ---- models stated with real casadi.SX (as every script of the reference does, PDP.py:23): the symbols are mirrored by this package's own, the
+    # expressions converted through the Function's instruction tape (casadi_adapter.py); from there on CasADi is not used
+    def _own(self, key, var):
+        from . import casadi_adapter as ca
+        if not ca.is_casadi(var):
+            return var
+        if not hasattr(self, "_casadi_vars"):
+            self._casadi_vars = {}
+        self._casadi_vars[key] = var
+        return SX.sym(key, int(var.numel()))
+
+    def _own_expr(self, expr, name, keys=("state", "control", "auxvar")):
+        from . import casadi_adapter as ca
+        if not ca.is_casadi(expr):
+            return expr
+        cv = getattr(self, "_casadi_vars", {})
+        keys = [k for k in keys if k in cv]
+        assert keys, "the expression is a CasADi object but no variable was given as one (setStateVariable / setControlVariable / setAuxvarVariable)"
+        return ca.convert_expression(expr, [cv[k] for k in keys], [getattr(self, k) for k in keys], name)
+
     # ---- set-up (PDP.py:62-119) -------------------------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
         if auxvar is None or auxvar.numel() == 0:
             self.auxvar = SX.sym("auxvar")
         else:
-            self.auxvar = auxvar
+            self.auxvar = self._own("auxvar", auxvar)
         self.n_auxvar = self.auxvar.numel()
         self._invalidate()
 
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
-        self.state = state
+        self.state = self._own("state", state)
         self.n_state = self.state.numel()
         self.state_lb = state_lb if len(state_lb) == self.n_state else self.n_state * [-1e20]
         self.state_ub = state_ub if len(state_ub) == self.n_state else self.n_state * [1e20]
         self._invalidate()
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
-        self.control = control
+        self.control = self._own("control", control)
         self.n_control = self.control.numel()
         self.control_lb = control_lb if len(control_lb) == self.n_control else self.n_control * [-1e20]
         self.control_ub = control_ub if len(control_ub) == self.n_control else self.n_control * [1e20]
@@ -67,7 +87,7 @@ class OCSys:
     def setDyn(self, ode):
         if not hasattr(self, "auxvar"):
             self.setAuxvarVariable()
-        self.dyn = ode
+        self.dyn = self._own_expr(ode, "dynamics")
         self.dyn_fn = sx.Function("dynamics", [self.state, self.control, self.auxvar], [self.dyn])
         self._invalidate()
 
@@ -75,7 +95,7 @@ class OCSys:
         if not hasattr(self, "auxvar"):
             self.setAuxvarVariable()
         assert path_cost.numel() == 1, "path_cost must be a scalar function"
-        self.path_cost = path_cost
+        self.path_cost = self._own_expr(path_cost, "path_cost")
         self.path_cost_fn = sx.Function("path_cost", [self.state, self.control, self.auxvar], [self.path_cost])
         self._invalidate()
 
@@ -83,7 +103,7 @@ class OCSys:
         if not hasattr(self, "auxvar"):
             self.setAuxvarVariable()
         assert final_cost.numel() == 1, "final_cost must be a scalar function"
-        self.final_cost = final_cost
+        self.final_cost = self._own_expr(final_cost, "final_cost", keys=("state", "auxvar"))
         self.final_cost_fn = sx.Function("final_cost", [self.state, self.auxvar], [self.final_cost])
         self._invalidate()
 
@@ -156,12 +176,13 @@ class OCSys:
         return self.model().oc_auxsys(state_traj, u, costate_traj, self._theta(auxvar_value, u.shape[0]))
 
     def pdp_grad_batch(self, control_traj, auxvar_value, demo_state, demo_control, ini_state=None, state_traj=None, costate_traj=None,
-                       want_sens=False, buffers=None):
+                       want_sens=False, buffers=None, want_riccati=False):
         """Fused forward + Riccati + PDP gradient for a batch (the body of the IRL drivers' demo loop,
-        Examples/IRL/cartpole/cartpole_PDP.py:45-74): returns dict(loss [B], grad [B,p], x, lam, status[, dxdp, dudp])."""
+        Examples/IRL/cartpole/cartpole_PDP.py:45-74): returns dict(loss [B], grad [B,p], x, lam, status[, dxdp, dudp][, riccati]).
+        want_sens + want_riccati: everything the next OC solve's predicted start needs (ocsolver.solve_batch(..., predict=...))."""
         u = runtime.dev(control_traj)
         return self.model().oc_pdp_grad(u, self._theta(auxvar_value, u.shape[0]), demo_state, demo_control, x0=ini_state, x=state_traj,
-                                        lam=costate_traj, want_sens=want_sens, buffers=buffers)
+                                        lam=costate_traj, want_sens=want_sens, buffers=buffers, want_riccati=want_riccati)
 
     # ---- PDP.py:272-314 ----------------------------------------------------------------------------------------
     def getAuxSys(self, state_traj_opt, control_traj_opt, costate_traj_opt, auxvar_value=1):

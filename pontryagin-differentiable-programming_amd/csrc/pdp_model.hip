@@ -103,6 +103,16 @@ int oc_auxsys(int B, int T, const double* x, const double* u, const double* lam,
     } else { return PDP_E_MODE; }
 }
 template <class Mdl>
+int oc_predict(int B, int T, const double* dth, int dtb, const double* dxdp, const double* dudp, const double* ric, double* x, double* u, double* lam, void* st) {
+    if constexpr (fused_oc_ok<Mdl>()) {
+        if (B <= 0 || T <= 0 || !dth || !dxdp || !dudp || !x || !u || (ric && !lam)) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_predict_kernel<Mdl>), dim3((unsigned)((int64_t)B * ((T + 3) / 4))), dim3(64), 0, S(st), B, T, dth, dtb, dxdp, dudp, ric, x, u, lam);
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+
+template <class Mdl>
 int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const double* th, int tb, const double* dx, const double* du, double* x,
            double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* ric, int32_t* status, void* ws, int64_t wsb, void* st) {
     if constexpr (fused_oc_ok<Mdl>()) {
@@ -145,16 +155,6 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
             return launched();
         };
         return ric ? go1(oc_pdp_fused_kernel<Mdl, true>) : go1(oc_pdp_fused_kernel<Mdl, false>);
-    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
-}
-
-template <class Mdl>
-int oc_predict(int B, int T, const double* dth, int dtb, const double* dxdp, const double* dudp, const double* ric, double* x, double* u, double* lam, void* st) {
-    if constexpr (fused_oc_ok<Mdl>()) {
-        if (B <= 0 || T <= 0 || !dth || !dxdp || !dudp || !x || !u || (ric && !lam)) return PDP_E_ARG;
-        PDP_CLEAR();
-        hipLaunchKernelGGL((oc_predict_kernel<Mdl>), dim3((unsigned)((int64_t)B * ((T + 3) / 4))), dim3(64), 0, S(st), B, T, dth, dtb, dxdp, dudp, ric, x, u, lam);
-        return launched();
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
 
@@ -286,8 +286,21 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         if (op->max_iter < 0 || wsb < oc_solve_ms_ws_bytes<Mdl>(B, T, op->max_iter)) return PDP_E_ARG;
         const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
         if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
+        const bool predict = (op->flags & PDP_MS_PREDICT) != 0;
+        if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || !op->dxdp || !op->dudp)) return PDP_E_ARG;
+        // PDP_MS_PREDICT is applied by the runner / evaluator kernel while it loads the point (dx parked in its LDS pool); where that kernel does not run, or the
+        // horizon outgrows the pool, the prediction is a launch of its own in front of the solve (pdp_oc_predict_batched, in place on x, u, lam)
+        pdp_oc_ms_opts op1 = *op;
+        auto predict_first = [&]() -> int {
+            if (!predict) return 0;
+            op1.flags &= ~PDP_MS_PREDICT;
+            if constexpr (Mdl::NU + Mdl::NP <= 16) return oc_predict<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->dxdp, op->dudp, op->riccati, x, u, op->riccati ? lam : nullptr, st);
+            else return PDP_E_SIZE;
+        };
         if constexpr (ms2_ok<Mdl>()) {
             if (ms_variant() == 2 || needs_pair) {
+                if (predict && (int64_t)(T + 1) * Mdl::NX > 2 * Ms2Layout<Mdl>::BUF) { const int rc = predict_first(); if (rc != 0) return rc; }
+                op = &op1;
                 // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
                 // batches spread over the CUs with the two waves of a trajectory on different SIMDs
                 const int cus = device_cu_count();
@@ -299,6 +312,8 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         if (needs_pair) return PDP_E_SIZE;
         const size_t lds = ms_lds_bytes<Mdl>();
         if (lds > 160 * 1024) return PDP_E_SIZE;
+        { const int rc = predict_first(); if (rc != 0) return rc; }
+        op = &op1;
         (void)hipFuncSetAttribute((const void*)oc_solve_ms_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
         hipLaunchKernelGGL((oc_solve_ms_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *op, x0, th, tb, x, u, lam, cost, resid, converged, iterations,

@@ -365,11 +365,59 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         }
         // ---- starting point: the caller's (x, u, lambda) [PDP_MS_WARM], or IPOPT's: w0 = 0 (PDP.py:155,166), x_0 = ini_state
         const bool warm = (op.flags & PDP_MS_WARM) != 0;
+        // PDP_MS_PREDICT: the caller's point is the solution at the PREVIOUS parameter; what is loaded is its first-order prediction for the step dtheta,
+        //     x_t + X_t dtheta,   u_t + U_t dtheta,   lam_t + P_{t+1} (X_{t+1} dtheta) + W_{t+1} dtheta
+        // (X, U and the Riccati record of the gradient unit at that solution: pdp_oc_pdp_grad_sens_batched; the same numbers as pdp_oc_predict_batched, applied
+        // here so that an IRL iteration needs neither another launch nor a copy of the trajectory).  dx is parked in the still unused pool for the multiplier part.
+        const bool pred = warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
+        const bool predl = pred && op.riccati != nullptr;
         {
             double* s0 = Pt(0);
-            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0); }
-            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = warm ? ub[q] : 0.0; }
-            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = warm ? lb[q] : 0.0; }
+            constexpr int RSZ = oc_riccati_doubles<Mdl>();
+            double dth[NP > 0 ? NP : 1];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) dth[j] = pred ? op.dtheta[(int64_t)b * op.dtheta_bstride + j] : 0.0;
+            double* dxs = pool;                                  // [t][i], T + 1 nodes
+            for (int q = lane; q < (T + 1) * NX; q += 64) {
+                const int t = q / NX, i = q - t * NX;
+                double v = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0), d = 0.0;
+                if (pred && t > 0) {
+                    const double* X = op.dxdp + ((int64_t)b * (T + 1) * NX + q) * NP;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) d = fma(X[j], dth[j], d);
+                    v += d;
+                }
+                if (predl) dxs[q] = d;
+                s0[i * TS + t] = v;
+            }
+            for (int q = lane; q < T * NU; q += 64) {
+                const int t = q / NU, i = q - t * NU;
+                double v = warm ? ub[q] : 0.0;
+                if (pred) {
+                    const double* Um = op.dudp + ((int64_t)b * T * NU + q) * NP;
+                    double d = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) d = fma(Um[j], dth[j], d);
+                    v += d;
+                }
+                s0[OU + i * TS + t] = v;
+            }
+            if (predl) wave_lds_sync();
+            for (int q = lane; q < T * NX; q += 64) {
+                const int t = q / NX, i = q - t * NX;
+                double v = warm ? lb[q] : 0.0;
+                if (predl) {
+                    const double* R = op.riccati + ((int64_t)b * T + t) * RSZ;
+                    double d = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) d = fma(R[NX * NX + i * NP + j], dth[j], d);
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) d = fma(R[i * NX + k], dxs[(t + 1) * NX + k], d);
+                    v += d;
+                }
+                s0[OL + i * TS + t] = v;
+            }
+            if (predl) wave_lds_sync();                          // (the pool is the evaluator's from the first command on)
             for (int i = lane; i < NX; i += 64) stp[i * TS] = 0.0;       // dx_0 = 0: x_0 is fixed
         }
         bool dead = false;

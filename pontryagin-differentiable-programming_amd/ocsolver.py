@@ -68,12 +68,15 @@ def _solve(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter
 
 
 def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max_iter=300, print_level=0, neighbor_retries=2,
-                warm_start=None, want_gains=False, method="auto"):
+                warm_start=None, want_gains=False, method="auto", predict=None):
     """ocSolver for a batch.  method "auto": the multiple-shooting solver (the reference's formulation, IPOPT's iteration) unless
     starting controls `u_init` are given; "ms" / "single" force one ("ms" with `u_init`: the multiple-shooting iteration started from those controls, their rollout
     and the least-squares multipliers).  warm_start: a previous solution of the same batch (dict with
     state, control, costate[, gains]) - the multiple-shooting solver starts from that point.  Samples the multiple-shooting solver
     returns unconverged (no restoration possible, iteration limit) are re-solved by the single-shooting path.
+    predict (with warm_start = the solution at the PREVIOUS parameter): dict(dtheta, dxdp, dudp[, riccati]) - the parameter step and the sensitivity outputs of
+    OCSys.pdp_grad_batch(..., want_sens=True, want_riccati=True) at that solution; the solver then starts from the first-order prediction
+    (x, u, lam) + (X, U, Lambda) dtheta (PDP_MS_PREDICT) and saves a Newton iteration - the IRL loop of examples/irl_pdp.py.
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""
     torch = runtime.torch_cuda()
@@ -92,7 +95,8 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     else:
         warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])
         ms = mdl.oc_solve_ms(x0, th, horizon, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, warm=warm, want_gains=want_gains,
-                             u_init=u_init if warm is None else None)      # method "ms" with starting controls: PDP_MS_FROM_CONTROLS
+                             u_init=u_init if warm is None else None,      # method "ms" with starting controls: PDP_MS_FROM_CONTROLS
+                             predict=predict if warm is not None else None)
     sol = {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": ms["cost"], "grad_norm": ms["resid"][:, 1].contiguous(),
            "converged": ms["converged"], "iterations": int(ms["iterations"].max()), "method_ms": ms["converged"].clone(), "status": ms["status"]}
     if want_gains:

@@ -41,7 +41,8 @@ class PdpOcSolveOpts(C.Structure):
 
 
 class PdpOcMsOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("flags", C.c_int), ("log_rows", C.c_int)]
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("flags", C.c_int), ("log_rows", C.c_int), ("dtheta_bstride", C.c_int),
+                ("dtheta", C.c_void_p), ("dxdp", C.c_void_p), ("dudp", C.c_void_p), ("riccati", C.c_void_p)]
 
 
 class PdpPolicy(C.Structure):
@@ -335,13 +336,16 @@ class ModelLib:
             out["gains"] = gains
         return out
 
-    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False):
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False, predict=None):
         """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
         (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
         from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
         PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  u_init [B, T, m] (instead of warm): start from these
         controls, their rollout and the least-squares multiplier estimate (PDP_MS_FROM_CONTROLS).  consume_warm: the warm tensors themselves become the outputs
-        (no copies: for callers that built the starting point for this call, e.g. oc_predict).  Returns dict(state, control, costate, cost,
+        (no copies: for callers that built the starting point for this call, e.g. oc_predict).  predict = dict(dtheta [p] or [B, p], dxdp, dudp[, riccati]) with
+        warm = the solution at the previous parameter: the kernel starts from its first-order prediction for the step dtheta (PDP_MS_PREDICT: what oc_predict computes,
+        applied while the point is loaded - no extra launch; with consume_warm the previous solution's tensors are overwritten by the new one, as an IRL loop wants it).
+        Returns dict(state, control, costate, cost,
         resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
@@ -365,6 +369,15 @@ class ModelLib:
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
         opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0), int(log_rows))
+        keep = None
+        if predict is not None:
+            assert warm is not None, "predict needs the previous solution as the warm point"
+            dth, dtb = self._theta(predict["dtheta"], B)
+            keep = (dth, dev(predict["dxdp"]), dev(predict["dudp"]), dev(predict["riccati"]) if predict.get("riccati") is not None else None)
+            assert keep[1].shape == (B, T + 1, self.n, self.p) and keep[2].shape == (B, T, self.m, self.p)
+            opts.flags |= 16
+            opts.dtheta_bstride, opts.dtheta, opts.dxdp, opts.dudp = dtb, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
+            opts.riccati = keep[3].data_ptr() if keep[3] is not None else None
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}

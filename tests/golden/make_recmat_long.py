@@ -4,11 +4,12 @@ imported unmodified from /root/reference) at the horizons its drivers use - Exam
 Examples/OC/quadrotor/uav_PDP_Recmat.py (T = 35), Examples/OC/robotarm/robotarm_PDP_Recmat.py (T = 20) - stored as fixtures (data only).
 
 The recovery matrix is ONE symbolic expression over the whole horizon; the sympy-backed CasADi stand-in of make_ref_outputs.py composes it up to T = 7
-in about a minute and not at all at T = 20.  Here the `casadi` the reference imports is this repository's SX-compatible expression DAG (pdp_amd/sx.py:
-hash-consed nodes, reverse-mode AD - the same kind of object CasADi's SX is), which composes T = 50 in seconds.  That makes the AD engine common to the
-fixture and the product, so the script first CROSS-CHECKS the stand-in: it re-runs the T = 7 rocket / quadrotor cases and the pendulum case that the sympy
-stand-in generated (ref_recmat_*.npz) and requires agreement to 1e-12.  What the fixtures then pin is the reference's ALGORITHM (whole-horizon recovery
-matrix) against the product's (one adjoint sweep on the GPU): different formulas for the same gradient."""
+in about a minute and not at all at T = 20.  Round 3 generated these fixtures with the product's own expression engine (pdp_amd/sx.py) standing in for CasADi, which made
+the AD engine common to fixture and product.  Since round 4 the `casadi` the reference imports here is casadi_numeric_shim.py: lazy matrix-valued graphs evaluated on
+forward-mode dual numbers (values and Jacobians as numpy arrays) - no code, data structure or differentiation method in common with sx.py (scalar hash-consed DAG, reverse
+mode).  The script (i) cross-checks that stand-in against the sympy-generated short fixtures (pendulum; rocket / quadrotor at T = 7), (ii) reports how far the
+round-3 long fixtures (sx.py engine) are from the new numbers - three engines, one answer -, (iii) writes the long fixtures from the numeric stand-in.
+`--engine sx` re-runs step (i) and the long cases with the product's engine instead (writes nothing)."""
 import os
 import sys
 import numpy as np
@@ -19,13 +20,19 @@ REF = os.environ.get("PDP_REFERENCE", "/root/reference")
 if not os.path.isdir(REF):
     sys.exit("reference not present: fixtures can only be regenerated in the build container")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 import matplotlib
 matplotlib.use("Agg")
-from pdp_amd import sx
-sx.numpy = np
-sx.np = np
-sx.casadi = sx
-sys.modules["casadi"] = sx
+ENGINE = "sx" if "--engine" in sys.argv and sys.argv[sys.argv.index("--engine") + 1] == "sx" else "numeric"
+if ENGINE == "sx":
+    from pdp_amd import sx
+    sx.numpy = np
+    sx.np = np
+    sx.casadi = sx
+    sys.modules["casadi"] = sx
+else:
+    import casadi_numeric_shim
+    casadi_numeric_shim.install()
 sys.path.insert(0, REF)
 from PDP import PDP                  # noqa: E402  (reference, unmodified)
 from JinEnv import JinEnv            # noqa: E402  (reference, unmodified)
@@ -74,15 +81,25 @@ def run(name, dt, T, grid, x0, theta=None, seed=0):
 
 
 if __name__ == "__main__":
-    # cross-check of the stand-in against the sympy-generated fixtures
+    print("engine standing in for CasADi:", ENGINE)
+    # (i) cross-check of the stand-in against the sympy-generated fixtures
     for f, name in (("ref_recmat_pendulum_0.npz", "pendulum"), ("ref_recmat_rocket_2.npz", "rocket"), ("ref_recmat_quadrotor_3.npz", "quadrotor")):
         g = np.load(os.path.join(HERE, f))
         grid = None if int(g["grid"]) == -2 else int(g["grid"])
         r = run(name, float(g["dt"]), int(g["T"]), grid, g["x0"], g["theta"])
         el, eg = abs(r["loss"] - float(g["loss"])) / abs(float(g["loss"])), np.abs(r["grad"] - g["grad"]).max() / np.abs(g["grad"]).max()
-        print("cross-check %-28s loss %.1e gradient %.1e (relative)" % (f, el, eg))
-        assert el < 1e-12 and eg < 1e-12, "the sx stand-in disagrees with the sympy stand-in"
+        print("cross-check vs sympy engine  %-28s loss %.1e gradient %.1e (relative)" % (f, el, eg))
+        assert el < 1e-12 and eg < 1e-12, "the stand-in disagrees with the sympy stand-in"
     for k, (name, T) in enumerate((("rocket", 50), ("quadrotor", 35), ("robotarm", 20))):
         r = run(name, 0.1, T, -1, None, seed=100 + k)
-        np.savez_compressed(os.path.join(HERE, "ref_recmat_long_%s.npz" % name), **r)
+        path = os.path.join(HERE, "ref_recmat_long_%s.npz" % name)
+        if os.path.exists(path):                             # (ii) what is stored (round 3: sx.py engine; later: this engine) against this run
+            g = np.load(path)
+            assert np.array_equal(g["theta"], r["theta"]) and np.array_equal(g["x0"], r["x0"])
+            print("stored fixture vs this engine %-10s T %d: loss %.1e gradient %.1e state %.1e (relative)" %
+                  (name, T, abs(r["loss"] - float(g["loss"])) / abs(r["loss"]), np.abs(r["grad"] - g["grad"]).max() / np.abs(r["grad"]).max(),
+                   np.abs(r["state"] - g["state"]).max() / np.abs(r["state"]).max()))
+        if ENGINE == "numeric":
+            r["engine"] = np.array(2)                         # 2 = casadi_numeric_shim (forward-mode duals); the round-3 files (no such field) came from pdp_amd/sx.py
+            np.savez_compressed(path, **r)
         print("recmat", name, "T", T, "p", r["theta"].size, "loss", r["loss"], "|grad|", np.abs(r["grad"]).max())

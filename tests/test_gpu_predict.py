@@ -90,6 +90,11 @@ def test_ms_kernel_from_the_predicted_start_follows_the_oracle(golden_dir, name,
     log = []
     ref = ipopt_ms.solve(oc, x0[0], T, th1, tol=1e-10, log=log, warm=ipopt_ms.predict_start(oc, xs, us, ls, th, th1 - th))
     got = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=pred, log_rows=len(log) + 4)
+    # the same start applied INSIDE the solver launch (PDP_MS_PREDICT) from the previous solution: the same arithmetic in the same order - identical iterates
+    fused = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]), log_rows=len(log) + 4,
+                            predict=dict(dtheta=th1 - th, dxdp=out["dxdp"], dudp=out["dudp"], riccati=out["riccati"]))
+    for k in ("state", "control", "costate", "cost", "iterations", "log"):
+        assert bool((fused[k] == got[k]).all()), k
     plain = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]))
     assert bool(got["converged"][0]) and int(got["status"][0]) == 0 and bool(plain["converged"][0])
     assert int(got["iterations"][0]) == ref["iterations"] == len(log)
@@ -120,9 +125,63 @@ def test_predicted_start_cuts_the_iterations_of_a_batch(golden_dir):
     pred = mdl.oc_predict(sol["state"], sol["control"], sol["costate"], th1 - th[None], out["dxdp"], out["dudp"], out["riccati"])
     a = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]))
     b = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=pred)
+    # the prediction applied inside the solver launch (PDP_MS_PREDICT) from the previous solution: the same arithmetic as the predict kernel - identical results
+    c = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]),
+                        predict=dict(dtheta=th1 - th[None], dxdp=out["dxdp"], dudp=out["dudp"], riccati=out["riccati"]))
+    assert bool((c["iterations"] == b["iterations"]).all()) and bool((c["state"] == b["state"]).all()) and bool((c["costate"] == b["costate"]).all())
+    # states and controls only (no Riccati record): multipliers start where they were
+    pxu = mdl.oc_predict(sol["state"], sol["control"], sol["costate"], th1 - th[None], out["dxdp"], out["dudp"])
+    e = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=pxu)
+    f = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]), predict=dict(dtheta=th1 - th[None], dxdp=out["dxdp"], dudp=out["dudp"]))
+    assert bool(e["converged"].all()) and bool((e["iterations"] == f["iterations"]).all()) and bool((e["state"] == f["state"]).all())
     assert bool(a["converged"].all()) and bool(b["converged"].all())
     ia, ib = a["iterations"].double(), b["iterations"].double()
     print("iterations from the previous solution: mean %.2f max %d; from the predicted point: mean %.2f max %d" % (float(ia.mean()), int(ia.max()), float(ib.mean()), int(ib.max())))
     assert float(ib.mean()) <= float(ia.mean()) - 0.5 and int(ib.max()) < int(ia.max())
     for k in ("state", "control", "costate"):
         assert float((a[k] - b[k]).abs().max()) <= 1e-7 * max(1.0, float(a[k].abs().max()))
+
+
+WORKER = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from pdp_amd import zoo
+out = {}
+for name, B in (("cartpole", 9), ("quadrotor", 2)):
+    d = np.load(%(golden)r + "/demos_" + name + ".npz")
+    mdl = zoo.get(name, "irl")
+    th, T = d["true_parameter"], d["control"].shape[1]
+    x0 = np.repeat(d["state"][:1, 0], B, axis=0)
+    x0[:, 1] += 0.01 * np.arange(B)
+    sol = mdl.oc_solve_ms(x0, th, T, tol=1e-11)
+    o = mdl.oc_pdp_grad(sol["control"], th, sol["state"], sol["control"], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True)
+    th1 = th[None] * (1 + 0.02 * np.random.default_rng(1).uniform(-1, 1, (B, th.size)))
+    r = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]),
+                        predict=dict(dtheta=th1 - th[None], dxdp=o["dxdp"], dudp=o["dudp"], riccati=o["riccati"]))
+    assert bool(r["converged"].all())
+    for k in ("state", "control", "costate", "iterations"):
+        out[name + "_" + k] = r[k].cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_prediction_in_front_of_the_one_wave_kernel(golden_dir, tmp_path):
+    """PDP_MS_VARIANT=1 (the one-wave solver kernel) takes PDP_MS_PREDICT as a launch of pdp_oc_predict_batched in front of it: same iterations, same optimum as the
+    runner / evaluator kernel, which applies the prediction while loading the point."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for variant in ("2", "1"):
+        path = str(tmp_path / ("v%s.npz" % variant))
+        r = subprocess.run([sys.executable, "-c", WORKER % dict(root=root, golden=golden_dir), path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                           env=dict(os.environ, PDP_MS_VARIANT=variant))
+        assert r.returncode == 0, r.stdout[-3000:]
+        res[variant] = np.load(path)
+    for k in res["2"].files:
+        a, b = res["2"][k], res["1"][k]
+        if k.endswith("iterations"):
+            assert np.array_equal(a, b), k
+        else:
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max()), k
