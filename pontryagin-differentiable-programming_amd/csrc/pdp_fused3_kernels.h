@@ -106,13 +106,37 @@ PDP_DEV void move3(Run3& r, int bytes) {
     for (int k = 0; k < NR; ++k) r.cur[k] += (unsigned)bytes;
 }
 
+// tile -> array through range-checked buffer stores: voff[r] = byte offset of element (lane, r) inside one time step's block, or out of range (dropped by the
+// hardware, like every lane of a resource of size 0 = an output that was not asked for): no predicated store blocks in the step loops
+struct F3StoreMap { unsigned voff[4]; };
+PDP_DEV F3StoreMap f3_store_map(int R, int C, int ld, int coff, int lane) {
+    F3StoreMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = tile_row(lane, r), col = tile_col(lane) - coff;
+        m.voff[r] = (row < R && col >= 0 && col < C) ? 8u * (unsigned)(row * ld + col) : 0x80000000u;
+    }
+    return m;
+}
+template <int NR = 4, class RS>
+PDP_DEV void f3_bstore(RS rs, unsigned soff, const F3StoreMap& m, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double x = v[r];          // (through a scalar copy: see DESIGN.md section 8, finding 5)
+        f3_u2 w;
+        w.x = (unsigned)__double2loint(x); w.y = (unsigned)__double2hiint(x);
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs, m.voff[r], soff, 0);
+    }
+}
+
 // TPW trajectories per workgroup of 2 TPW waves (runner = wave j, evaluator = wave j + TPW).  TPW = 4 (512 threads): the pair shares a SIMD - the layout for
 // batches that fill the chip (>= 1024 trajectories).  TPW = 2 / 1 (a 512-trajectory shard of C4, small batches): a CU then hosts at most two / one
 // trajectory, and the two waves of a trajectory sit on DIFFERENT SIMDs - the evaluator no longer competes with the runner's MFMA chain for issue slots
 // (profiles/r03_fused3_small_batch.txt).
-// RIC (the instantiation behind pdp_oc_pdp_grad_sens_batched): the runner also leaves the Riccati matrices P_{t+1}, W_{t+1} of every stage (PP[t], WW[t] of
-// the reference's lqrSolver, PDP.py:561-580) in `riccati` [B][T][n n + n p + 1] - with dxdp / dudp they give the first-order change of the optimal
-// (x, u, lambda) with theta (pdp_oc_predict_batched).  A template parameter, not a run-time branch: the default kernel keeps its instruction stream.
+// RIC (the instantiation that runs when sensitivity outputs are asked for: dxdp, dudp, and - pdp_oc_pdp_grad_sens_batched - the Riccati record): the runner also
+// leaves the Riccati matrices P_{t+1}, W_{t+1} of every stage (PP[t], WW[t] of the reference's lqrSolver, PDP.py:561-580) in `riccati` [B][T][n n + n p + 1] - with
+// dxdp / dudp they give the first-order change of the optimal (x, u, lambda) with theta (pdp_oc_predict_batched) - and all three are written with range-checked
+// buffer stores (an output that is NULL is a resource of size 0).  A template parameter, not a run-time branch: the default kernel keeps its instruction stream.
 template <class Mdl, int TPW = 4, bool RIC = false>
 __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, int flags, const double* __restrict__ x0, const double* __restrict__ u,
                                                             const double* __restrict__ theta, int tb, const double* __restrict__ demo_x,
@@ -287,8 +311,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
             const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
             // Riccati record of a stage (RIC): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | zero sink
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
-            [[maybe_unused]] const TileMapBytes mRP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, RSZ - 1), mRW = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
-            [[maybe_unused]] double* rw = RIC ? riccati + (int64_t)b * T * RSZ : nullptr;
+            [[maybe_unused]] const F3StoreMap mRP = f3_store_map(NX, NX, NX, 0, lane), mRW = f3_store_map(NX, NP, NP, M, lane);
+            [[maybe_unused]] const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && riccati ? riccati + (int64_t)b * T * RSZ : ws_gain), 0,
+                                                                                 RIC && riccati ? (int)((int64_t)T * RSZ * 8) : 0, 0x00020000);
             constexpr int RB = 8 * BS;                           // bytes per row
             for (int g = 0; g < nchunk; ++g) {
                 int t0, cnt;
@@ -319,7 +344,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
                     d4 P_old;
-                    if constexpr (RIC) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
+                    if constexpr (RIC) { f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2); }
                     ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
@@ -366,6 +391,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
             const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
             d4 KTn = -load_all<4>(gw, mKT);
             d4 kn = -load_all<1>(gw + NX * NU, mIK);
+            // sensitivity outputs of the RIC instantiation: buffer stores, an absent output is a resource of size 0
+            [[maybe_unused]] const F3StoreMap mSX = f3_store_map(NX, NP, NP, M, lane), mSU = f3_store_map(NU, NP, NP, M, lane);
+            [[maybe_unused]] const auto rsSX = __builtin_amdgcn_make_buffer_rsrc((void*)(dxdp ? dxdp + (int64_t)b * (T + 1) * NX * NP : ws_gain), 0,
+                                                                                  dxdp ? (int)((int64_t)(T + 1) * NX * NP * 8) : 0, 0x00020000);
+            [[maybe_unused]] const auto rsSU = __builtin_amdgcn_make_buffer_rsrc((void*)(dudp ? dudp + (int64_t)b * T * NU * NP : ws_gain), 0,
+                                                                                  dudp ? (int)((int64_t)T * NU * NP * 8) : 0, 0x00020000);
             constexpr int RF = 8 * FS;
             static_assert((U & 1) == 0, "the register sets of the unrolled loops alternate: U must be even");
             for (int c = 0; c < nchunkF; ++c) {
@@ -388,8 +419,13 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     d4 U2;
                     riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                     acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
-                    if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
-                    if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+                    if constexpr (RIC) {
+                        f3_bstore(rsSX, (unsigned)(t * NX * NP) * 8u, mSX, Xc);
+                        f3_bstore<1>(rsSU, (unsigned)(t * NU * NP) * 8u, mSU, U2);
+                    } else {
+                        if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
+                        if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+                    }
                 };
                 // groups of U steps with literal row offsets, the sensitivity tile and the prefetched gains alternating between two register sets
                 d4 Xb, KTb, kb;

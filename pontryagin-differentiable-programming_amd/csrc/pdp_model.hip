@@ -139,7 +139,7 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
                                        dudp, status, (double*)ws, ric);
                     return launched();
                 };
-                if (ric) {          // with the Riccati record (pdp_oc_pdp_grad_sens_batched): the RIC instantiations
+                if (ric || dxdp || dudp) {          // sensitivity outputs (any of dxdp, dudp, the Riccati record): the instantiation that writes them with buffer stores
                     if (tpw == 1) return go(oc_pdp_fused3_kernel<Mdl, 1, true>, 1);
                     if (tpw == 2) return go(oc_pdp_fused3_kernel<Mdl, 2, true>, 2);
                     return go(oc_pdp_fused3_kernel<Mdl, 4, true>, 4);
@@ -299,7 +299,7 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         };
         if constexpr (ms2_ok<Mdl>()) {
             if (ms_variant() == 2 || needs_pair) {
-                if (predict && (int64_t)(T + 1) * Mdl::NX > 2 * Ms2Layout<Mdl>::BUF) { const int rc = predict_first(); if (rc != 0) return rc; }
+                if (predict && !Ms2Layout<Mdl>::predict_fits(T)) { const int rc = predict_first(); if (rc != 0) return rc; }
                 op = &op1;
                 // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
                 // batches spread over the CUs with the two waves of a trajectory on different SIMDs
@@ -490,7 +490,9 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
     if constexpr (Mdl::KIND == PDP_KIND_SYSID && Mdl::NX <= 16 && Mdl::NP <= 64) {
         if (B <= 0 || T <= 0 || !u || !xobs || !th || !loss || !grad) return PDP_E_ARG;
         constexpr int NT = (Mdl::NP + 15) / 16;
-        const size_t lds = sizeof(double) * (size_t)sysid_slice<Mdl>(T);
+        static const int rows_env = [] { const char* e = std::getenv("PDP_SYSID_ROWS"); return e ? std::atoi(e) : 0; }();
+        const int rows = rows_env > 0 ? (rows_env < Mdl::CHUNK ? rows_env : Mdl::CHUNK) : sysid_rows<Mdl>(B, T, device_cu_count());
+        const size_t lds = sizeof(double) * (size_t)sysid_slice<Mdl>(T, rows);
         if (lds > 150 * 1024) return PDP_E_SIZE;
         // PDP_SYSID_VARIANT: 2 = rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h), the default; 1 = one wavefront per trajectory
         static const int variant = [] { const char* e = std::getenv("PDP_SYSID_VARIANT"); return e ? std::atoi(e) : 2; }();
@@ -511,7 +513,7 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
         }
         (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
-        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad);
+        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows);
         return launched();
     } else { return Mdl::KIND == PDP_KIND_SYSID ? PDP_E_SIZE : PDP_E_MODE; }
 }

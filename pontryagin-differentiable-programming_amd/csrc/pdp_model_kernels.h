@@ -1633,15 +1633,26 @@ __global__ void __launch_bounds__(64) sysid_auxsys_kernel(int B, int T, const do
 // doubles of LDS per trajectory of the fused SysID.step kernels (sysid_step_kernel below, sysid_step2_kernel in pdp_cp_pair_kernels.h):
 // [cpool | pool CH rows | x (T+1) x NX | dlT NX + 1 | u T x NU | dump 64 + NX | hand-over counter, padding]
 template <class Mdl>
-__host__ __device__ inline int sysid_slice(int T) {
-    const int n = 1 + Mdl::PATH_NCONST + Mdl::CHUNK * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (T + 1) * Mdl::NX + Mdl::NX + 1 + T * Mdl::NU + 64 + Mdl::NX + 8;
+__host__ __device__ inline int sysid_slice(int T, int rows = Mdl::CHUNK) {
+    const int n = 1 + Mdl::PATH_NCONST + rows * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (T + 1) * Mdl::NX + Mdl::NX + 1 + T * Mdl::NU + 64 + Mdl::NX + 8;
     return (n + 1) & ~1;
+}
+// Pool rows (stages per lane-parallel Jacobian pass) of sysid_step_kernel.  The generated CHUNK (a 17 KB pool for the quadrotor) makes a workgroup 31 KB: five
+// wavefronts per CU - fine while there is at most one trajectory per SIMD.  A batch with several trajectories per SIMD (C5's total of 8192 on one GPU: eight rounds)
+// is served better by TWO resident waves per SIMD that fill each other's latency gaps (two waves take 1.4x the time of one): the pool is
+// cut to what lets eight workgroups share the CU's 160 KB.
+template <class Mdl>
+__host__ inline int sysid_rows(int B, int T, int cus) {
+    if (B <= 4 * cus) return Mdl::CHUNK;
+    const int stride = (Mdl::PATH_NVAR + Mdl::NX) | 1;
+    const int fit = (160 * 1024 / 8 / 8 - 64 - sysid_slice<Mdl>(T, 0)) / stride;      // (64 doubles of slack for the allocation granularity)
+    return fit >= 4 ? (fit < Mdl::CHUNK ? fit : Mdl::CHUNK) : Mdl::CHUNK;
 }
 // Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
 template <class Mdl, int NT>
 __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const double* __restrict__ u, const double* __restrict__ xobs,
-                                                         const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = Mdl::CHUNK;
+                                                         const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad, int CH) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
     constexpr int NC = 1 + Mdl::PATH_NCONST, DLX = Mdl::PATH_NVAR, STRIDE = (Mdl::PATH_NVAR + NX) | 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* blk = lds;

@@ -99,6 +99,9 @@ struct Ms2Layout {
     //     point set 0 | point set 1 (the iterate is in one, the trial point goes to the other) | step (dx | du | dlam) |
     //     residual set 0 | residual set 1 (grad_x L | grad_u L | defect c)
     // followed by the gains, (P, W) and the filter.  The API arrays are read once (warm start) and written once (the result).
+    // PDP_MS_PREDICT inside the kernel: staging block of the sensitivity rows (64 rows of NP, or 64 / NX stages of the Riccati record) + dx of every node, in the pool
+    static constexpr int PRED_STG = 64 * NP > (64 / NX) * (NX * NX + NX * NP + 1) ? 64 * NP : (64 / NX) * (NX * NX + NX * NP + 1);
+    __host__ __device__ static constexpr bool predict_fits(int T) { return (int64_t)(T + 1) * NX + PRED_STG <= 2 * BUF; }
     __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
         return 5 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
@@ -374,50 +377,88 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         {
             double* s0 = Pt(0);
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
-            double dth[NP > 0 ? NP : 1];
+            if (!pred) {
+                for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0); }
+                for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = warm ? ub[q] : 0.0; }
+                for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = warm ? lb[q] : 0.0; }
+            } else {
+                // The sensitivity arrays are row-major [row][NP] (a row = one element of the trajectory): read lane-per-row they would put every lane in its own
+                // cache line (72-byte rows), and with four trajectories per CU the address unit, not the memory, sets the pace (measured: 29 us of a 255 us
+                // solve).  So blocks of 64 rows are fetched with fully coalesced loads (lane + 64 k), parked in the pool - free until the first command - and each
+                // lane then reads ITS row from LDS.  Same sums in the same order as oc_predict_kernel: the two starts are bit-identical.
+                constexpr int SB = 64 / NX;                          // stages of the Riccati record per block (lane = (stage, row))
+                constexpr int STG = L::PRED_STG;
+                static_assert(STG >= 64 * NP && STG >= SB * RSZ, "staging block");
+                double* stage = pool;
+                double* dxs = pool + STG;                            // dx [t][i], T + 1 nodes
+                double dth[NP > 0 ? NP : 1];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) dth[j] = pred ? op.dtheta[(int64_t)b * op.dtheta_bstride + j] : 0.0;
-            double* dxs = pool;                                  // [t][i], T + 1 nodes
-            for (int q = lane; q < (T + 1) * NX; q += 64) {
-                const int t = q / NX, i = q - t * NX;
-                double v = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0), d = 0.0;
-                if (pred && t > 0) {
-                    const double* X = op.dxdp + ((int64_t)b * (T + 1) * NX + q) * NP;
+                for (int j = 0; j < NP; ++j) dth[j] = op.dtheta[(int64_t)b * op.dtheta_bstride + j];
+                auto rows_dot = [&](const double* __restrict__ src, int nrows, auto sink) {
+                    for (int r0 = 0; r0 < nrows; r0 += 64) {
+                        const int nr = min(64, nrows - r0), nd = nr * NP;
+                        const double* s_ = src + (int64_t)r0 * NP;
+                        double v[NP > 0 ? NP : 1];
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) d = fma(X[j], dth[j], d);
+                        for (int k = 0; k < NP; ++k) { const int idx = lane + 64 * k; v[k] = s_[idx < nd ? idx : 0]; }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) stage[lane + 64 * k] = v[k];
+                        wave_lds_sync();
+                        if (lane < nr) {
+                            double d = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) d = fma(stage[lane * NP + j], dth[j], d);
+                            sink(r0 + lane, d);
+                        }
+                        wave_lds_sync();
+                    }
+                };
+                rows_dot(op.dxdp + (int64_t)b * (T + 1) * NX * NP, (T + 1) * NX, [&](int q, double d) {
+                    const int t = q / NX, i = q - t * NX;
+                    double v = xb[q];
                     v += d;
-                }
-                if (predl) dxs[q] = d;
-                s0[i * TS + t] = v;
-            }
-            for (int q = lane; q < T * NU; q += 64) {
-                const int t = q / NU, i = q - t * NU;
-                double v = warm ? ub[q] : 0.0;
-                if (pred) {
-                    const double* Um = op.dudp + ((int64_t)b * T * NU + q) * NP;
-                    double d = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) d = fma(Um[j], dth[j], d);
+                    s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : v;
+                    dxs[q] = d;
+                });
+                rows_dot(op.dudp + (int64_t)b * T * NU * NP, T * NU, [&](int q, double d) {
+                    const int t = q / NU, i = q - t * NU;
+                    double v = ub[q];
                     v += d;
-                }
-                s0[OU + i * TS + t] = v;
-            }
-            if (predl) wave_lds_sync();
-            for (int q = lane; q < T * NX; q += 64) {
-                const int t = q / NX, i = q - t * NX;
-                double v = warm ? lb[q] : 0.0;
-                if (predl) {
-                    const double* R = op.riccati + ((int64_t)b * T + t) * RSZ;
-                    double d = 0.0;
+                    s0[OU + i * TS + t] = v;
+                });
+                if (!predl) {
+                    for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = lb[q]; }
+                } else {
+                    constexpr int NQR = (SB * RSZ + 63) / 64;
+                    wave_lds_sync();
+                    for (int t0 = 0; t0 < T; t0 += SB) {
+                        const int nst = min(SB, T - t0), nd = nst * RSZ;
+                        const double* s_ = op.riccati + ((int64_t)b * T + t0) * RSZ;
+                        double v[NQR];
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) d = fma(R[NX * NX + i * NP + j], dth[j], d);
+                        for (int k = 0; k < NQR; ++k) { const int idx = lane + 64 * k; v[k] = s_[idx < nd ? idx : 0]; }
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) d = fma(R[i * NX + k], dxs[(t + 1) * NX + k], d);
-                    v += d;
+                        for (int k = 0; k < NQR; ++k) { const int idx = lane + 64 * k; if (idx < SB * RSZ) stage[idx] = v[k]; }
+                        wave_lds_sync();
+                        const int sg = lane / NX, i = lane - sg * NX;
+                        if (lane < nst * NX) {
+                            const int t = t0 + sg;
+                            const double* R = stage + sg * RSZ;
+                            double d = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) d = fma(R[NX * NX + i * NP + j], dth[j], d);
+#pragma unroll
+                            for (int k = 0; k < NX; ++k) d = fma(R[i * NX + k], dxs[(t + 1) * NX + k], d);
+                            double v_ = lb[t * NX + i];
+                            v_ += d;
+                            s0[OL + i * TS + t] = v_;
+                        }
+                        wave_lds_sync();
+                    }
                 }
-                s0[OL + i * TS + t] = v;
             }
-            if (predl) wave_lds_sync();                          // (the pool is the evaluator's from the first command on)
             for (int i = lane; i < NX; i += 64) stp[i * TS] = 0.0;       // dx_0 = 0: x_0 is fixed
         }
         bool dead = false;
@@ -750,9 +791,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         int st = 0, it = 0, nfilt = 0, conv = 0, phase = ph1 ? 1 : 0, cur = 0;
         double hs = ph1 ? 1.0 : 0.0, dw = ph1 ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
         bool gains_ok = false, pending = false;         // pending: the evaluator is already on the sweep of the current iterate (TRIAL_SWEEP)
-        // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays)
-        issue(from_u ? MS2_CMD_RESTORE : MS2_CMD_TRIAL, 0.0, cur, cur);
-        wait_done();
+        // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays).  Unless the point has to be built first
+        // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
+        // the trial half is done and finds chunk 0 of the sweep already under way instead of asking for it then
+        if (from_u) { issue(MS2_CMD_RESTORE, 0.0, cur, cur); wait_done(); }
+        else if constexpr (SPLIT) { issue(MS2_CMD_TRIAL, 0.0, cur, cur); wait_done(); }      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
+        else { issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur); wait_slot(MS2_TDONE); pending = true; }
         read_res();
         for (;;) {
             if (dead) break;
