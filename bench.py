@@ -214,11 +214,13 @@ def other_configs(torch):
         th_b = torch.as_tensor(th_star, dtype=torch.float64, device="cuda")
         dth = (theta1 - th_b.view(1, -1)).contiguous()
         bufs0, bufs = {}, {}
-        sens0 = mdl.oc_pdp_grad(demo["control"], th_star, demo["state"], demo["control"], x=demo["state"], lam=demo["costate"], want_sens=True, want_riccati=True, buffers=bufs0)
-        use_ric = system == "cartpole" or os.environ.get("PDP_BENCH_PREDICT_LAMBDA", "1") != "0"
-        ric0 = sens0["riccati"] if use_ric else None
-
-        pred_in = dict(dtheta=dth, dxdp=sens0["dxdp"], dudp=sens0["dudp"], riccati=ric0)
+        sens0 = mdl.oc_pdp_grad(demo["control"], th_star, demo["state"], demo["control"], x=demo["state"], lam=demo["costate"], want_sens=True, want_riccati=True,
+                                want_predict_record=True, buffers=bufs0)
+        use_ric = True
+        ric0 = sens0["riccati"]
+        # what the loop hands from the gradient unit to the next solve: the packed fp32 prediction record (X, U, P, W in single precision: 2.4 times less traffic
+        # than the fp64 outputs, which at C3 would be read at HBM speed inside the solver - probes/predict_cost.py, profiles/r04_predict_cost.txt)
+        pred_in = dict(dtheta=dth, record=sens0["predict_record"])
         copies = [tuple(a.clone() for a in warm) for _ in range(16)]          # an IRL loop solves IN PLACE on the previous solution: every timed call gets its own copy of it
 
         def predicted_solve(tol=1e-10):       # PDP_MS_PREDICT: the prediction is applied while the solver loads the point (one launch)
@@ -232,16 +234,17 @@ def other_configs(torch):
         it8 = sol8["iterations"].double()
         grad_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], buffers=bufs))
         bufs_s = {}
-        grad_sens_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], want_sens=True,
-                                                                want_riccati=use_ric, buffers=bufs_s))
+        grad_sens_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"],
+                                                                want_predict_record=True, buffers=bufs_s))
         it, itc, itp = sol["iterations"].double(), demo["iterations"].double(), plain["iterations"].double()
         agree = max(float((sol[k] - plain[k]).abs().max()) / max(1.0, float(plain[k].abs().max())) for k in ("state", "control", "costate"))
         entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
               note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); one IRL iteration = first-order prediction of the starting point from the previous iteration's "
-                   "sensitivities (PDP_MS_PREDICT: applied inside the solver launch; the same numbers as pdp_oc_predict_batched) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / Riccati / gradient unit keeping X, U%s for the next "
-                   "prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit (it has none for the solve)" % (" and the Riccati record" if use_ric else ""),
+                   "sensitivities (PDP_MS_PREDICT: applied inside the solver launch from the packed fp32 prediction record) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / "
+                   "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit "
+                   "(it has none for the solve)",
               extra={"oc_solve_ms": solve_ms, "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
-                     "prediction_includes_multipliers": bool(use_ric), "oc_solve_converged": int(sol["converged"].sum()),
+                     "prediction_includes_multipliers": bool(use_ric), "prediction_record_bytes": int(sens0["predict_record"].numel() * 4), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
                      "solution_agrees_with_plain_warm_start_rel": agree,
                      "round3_pipeline_plain_warm_start": {"oc_solve_ms": plain_ms, "gradient_ms": grad_ms, "iteration_ms": plain_ms + grad_ms,

@@ -80,9 +80,9 @@ def main():
         if not bool(sol["converged"].all()):
             print("iter %5d  warning: %d of %d OC solves did not converge" % (k, int((~sol["converged"]).sum()), demo_x.shape[0]))
         warm = {key: sol[key] for key in ("state", "control", "costate")}
-        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"], want_sens=fused, want_riccati=fused)
+        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"], want_predict_record=fused)
         if fused:
-            predict, theta_prev = {"dxdp": out["dxdp"], "dudp": out["dudp"], "riccati": out["riccati"]}, theta.copy()
+            predict, theta_prev = {"record": out["predict_record"]}, theta.copy()
         if int(out["status"].sum()) != 0:
             print("iter %5d  warning: Riccati sweep reported numerical trouble on %d trajectories" % (k, int((out["status"] != 0).sum())))
         loss = float(out["loss"].mean())

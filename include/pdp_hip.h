@@ -230,6 +230,8 @@ typedef struct pdp_oc_ms_opts {
     const double* dxdp;        /* ... [B][T+1][n][p] */
     const double* dudp;        /* ... [B][T][m][p] */
     const double* riccati;     /* ... [B][T][pdp_oc_riccati_doubles()] or NULL */
+    const float* predict_record; /* alternatively (takes precedence; dxdp / dudp / riccati are then ignored): the packed fp32 prediction record
+                                    [B][T][pdp_oc_predict_record_floats()] of pdp_oc_pdp_grad_sens_batched - 74 MB at C3 where the fp64 outputs are 181 MB */
 } pdp_oc_ms_opts;
 int64_t pdp_oc_solve_ms_workspace_bytes(int B, int T, int max_iter);
 /* iter_log (optional, [B][opts->log_rows][8]): one row per accepted step, the columns of IPOPT's iteration output (print_level 5):
@@ -260,9 +262,20 @@ int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const dou
  * (PP[t], WW[t] of PDP.py:561-580; the costate sensitivities are Lambda_t = P_{t+1} X_{t+1} + W_{t+1}, PDP.py:604).  Any of the three may be NULL.
  * pdp_oc_riccati_doubles() = n n + n p + 1 of this model. */
 int64_t pdp_oc_riccati_doubles(void);
+/* Optional outputs of pdp_oc_pdp_grad_sens_batched; any pointer may be NULL.  predict_record [B][T][pdp_oc_predict_record_floats()]: what the prediction of the
+ * next starting point needs, packed and in single precision per stage - X_{t+1} [n][p] | U_t [m][p] | upper triangle of P_{t+1} (row-major packed) | W_{t+1} [n][p]
+ * (a starting point is first-order accurate in dtheta at best: fp32 factors are far below that error, and the record stays in the Infinity Cache where the fp64
+ * outputs are read at HBM speed). */
+typedef struct pdp_oc_sens_out {
+    double* dxdp;
+    double* dudp;
+    double* riccati;
+    float* predict_record;
+} pdp_oc_sens_out;
+int64_t pdp_oc_predict_record_floats(void);
 int pdp_oc_pdp_grad_sens_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta,
                                  int theta_bstride, const double* demo_x, const double* demo_u, double* x, double* lam,
-                                 double* loss, double* grad, double* dxdp, double* dudp, double* riccati, int32_t* status,
+                                 double* loss, double* grad, const pdp_oc_sens_out* sens, int32_t* status,
                                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* First-order prediction of the optimal trajectory at theta + dtheta from those outputs - the derivative the auxiliary control system IS
@@ -272,6 +285,9 @@ int pdp_oc_pdp_grad_sens_batched(int B, int T, int flags, const double* x0, cons
  * dtheta [B][p] (dtheta_bstride = p) or shared [p] (stride 0).  riccati and lam may both be NULL: states and controls only. */
 int pdp_oc_predict_batched(int B, int T, const double* dtheta, int dtheta_bstride, const double* dxdp, const double* dudp,
                            const double* riccati, double* x, double* u, double* lam, void* stream);
+/* the same from the packed fp32 record (lam may be NULL: states and controls only) */
+int pdp_oc_predict_record_batched(int B, int T, const double* dtheta, int dtheta_bstride, const float* predict_record, double* x, double* u,
+                                  double* lam, void* stream);
 
 /* ---- PDP_KIND_CP ------------------------------------------------------------------------------------ */
 

@@ -176,13 +176,14 @@ class OCSys:
         return self.model().oc_auxsys(state_traj, u, costate_traj, self._theta(auxvar_value, u.shape[0]))
 
     def pdp_grad_batch(self, control_traj, auxvar_value, demo_state, demo_control, ini_state=None, state_traj=None, costate_traj=None,
-                       want_sens=False, buffers=None, want_riccati=False):
+                       want_sens=False, buffers=None, want_riccati=False, want_predict_record=False):
         """Fused forward + Riccati + PDP gradient for a batch (the body of the IRL drivers' demo loop,
         Examples/IRL/cartpole/cartpole_PDP.py:45-74): returns dict(loss [B], grad [B,p], x, lam, status[, dxdp, dudp][, riccati]).
-        want_sens + want_riccati: everything the next OC solve's predicted start needs (ocsolver.solve_batch(..., predict=...))."""
+        want_predict_record (or want_sens + want_riccati, the same in fp64): everything the next OC solve's predicted start needs
+        (ocsolver.solve_batch(..., predict=dict(dtheta=..., record=out["predict_record"])))."""
         u = runtime.dev(control_traj)
         return self.model().oc_pdp_grad(u, self._theta(auxvar_value, u.shape[0]), demo_state, demo_control, x0=ini_state, x=state_traj,
-                                        lam=costate_traj, want_sens=want_sens, buffers=buffers, want_riccati=want_riccati)
+                                        lam=costate_traj, want_sens=want_sens, buffers=buffers, want_riccati=want_riccati, want_predict_record=want_predict_record)
 
     # ---- PDP.py:272-314 ----------------------------------------------------------------------------------------
     def getAuxSys(self, state_traj_opt, control_traj_opt, costate_traj_opt, auxvar_value=1):

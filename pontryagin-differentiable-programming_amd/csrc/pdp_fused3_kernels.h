@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                                                             const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                             double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
                                                             double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain,
-                                                            double* __restrict__ riccati) {
+                                                            double* __restrict__ riccati, float* __restrict__ prec) {
     using F3 = Fused3Layout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>(), GSZ0 = fused_gain0_doubles<Mdl>();
@@ -314,6 +314,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
             [[maybe_unused]] const F3StoreMap mRP = f3_store_map(NX, NX, NX, 0, lane), mRW = f3_store_map(NX, NP, NP, M, lane);
             [[maybe_unused]] const auto rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && riccati ? riccati + (int64_t)b * T * RSZ : ws_gain), 0,
                                                                                  RIC && riccati ? (int)((int64_t)T * RSZ * 8) : 0, 0x00020000);
+            // packed fp32 prediction record (PredRec, pdp_model_kernels.h)
+            [[maybe_unused]] const PredMaps<Mdl> pm(lane);
+            [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                                  RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
             constexpr int RB = 8 * BS;                           // bytes per row
             for (int g = 0; g < nchunk; ++g) {
                 int t0, cnt;
@@ -344,7 +348,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
                     d4 P_old;
-                    if constexpr (RIC) { f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2); }
+                    if constexpr (RIC) {
+                        f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2);
+                        pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2);
+                    }
                     ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
@@ -397,6 +404,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                                                                                   dxdp ? (int)((int64_t)(T + 1) * NX * NP * 8) : 0, 0x00020000);
             [[maybe_unused]] const auto rsSU = __builtin_amdgcn_make_buffer_rsrc((void*)(dudp ? dudp + (int64_t)b * T * NU * NP : ws_gain), 0,
                                                                                   dudp ? (int)((int64_t)T * NU * NP * 8) : 0, 0x00020000);
+            [[maybe_unused]] const PredMaps<Mdl> pmf(lane);
+            [[maybe_unused]] const auto rsPRf = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                                   RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
             constexpr int RF = 8 * FS;
             static_assert((U & 1) == 0, "the register sets of the unrolled loops alternate: U must be even");
             for (int c = 0; c < nchunkF; ++c) {
@@ -422,6 +432,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     if constexpr (RIC) {
                         f3_bstore(rsSX, (unsigned)(t * NX * NP) * 8u, mSX, Xc);
                         f3_bstore<1>(rsSU, (unsigned)(t * NU * NP) * 8u, mSU, U2);
+                        pred_store(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.X, Xn);       // X_{t+1}
+                        pred_store<1>(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.U, U2);
                     } else {
                         if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                         if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);

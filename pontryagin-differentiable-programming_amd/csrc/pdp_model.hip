@@ -113,8 +113,17 @@ int oc_predict(int B, int T, const double* dth, int dtb, const double* dxdp, con
 }
 
 template <class Mdl>
+int oc_predict_rec(int B, int T, const double* dth, int dtb, const float* rec, double* x, double* u, double* lam, void* st) {
+    if constexpr (fused_oc_ok<Mdl>()) {
+        if (B <= 0 || T <= 0 || !dth || !rec || !x || !u) return PDP_E_ARG;
+        PDP_CLEAR();
+        hipLaunchKernelGGL((oc_predict_rec_kernel<Mdl>), dim3((unsigned)((int64_t)B * ((T + 3) / 4))), dim3(64), 0, S(st), B, T, dth, dtb, rec, x, u, lam);
+        return launched();
+    } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
+}
+template <class Mdl>
 int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const double* th, int tb, const double* dx, const double* du, double* x,
-           double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* ric, int32_t* status, void* ws, int64_t wsb, void* st) {
+           double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* ric, float* prec, int32_t* status, void* ws, int64_t wsb, void* st) {
     if constexpr (fused_oc_ok<Mdl>()) {
         if (B <= 0 || T <= 0 || !u || !th || !dx || !du || !x || !lam || !loss || !grad || !ws) return PDP_E_ARG;
         if (!(flags & PDP_OC_GIVEN_TRAJ) && !x0) return PDP_E_ARG;
@@ -136,10 +145,10 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
                 auto go = [&](auto kern, int TPW) {
                     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TPW * 40 * 1024);
                     hipLaunchKernelGGL(kern, dim3((B + TPW - 1) / TPW), dim3(128 * TPW), TPW * 40 * 1024, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp,
-                                       dudp, status, (double*)ws, ric);
+                                       dudp, status, (double*)ws, ric, prec);
                     return launched();
                 };
-                if (ric || dxdp || dudp) {          // sensitivity outputs (any of dxdp, dudp, the Riccati record): the instantiation that writes them with buffer stores
+                if (ric || dxdp || dudp || prec) {          // sensitivity outputs (any of dxdp, dudp, the Riccati record): the instantiation that writes them with buffer stores
                     if (tpw == 1) return go(oc_pdp_fused3_kernel<Mdl, 1, true>, 1);
                     if (tpw == 2) return go(oc_pdp_fused3_kernel<Mdl, 2, true>, 2);
                     return go(oc_pdp_fused3_kernel<Mdl, 4, true>, 4);
@@ -151,10 +160,10 @@ int oc_pdp(int B, int T, int flags, const double* x0, const double* u, const dou
         }
         auto go1 = [&](auto kern) {
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp, dudp, status, (double*)ws, ric);
+            hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, S(st), B, T, flags, x0, u, th, tb, dx, du, x, lam, loss, grad, dxdp, dudp, status, (double*)ws, ric, prec);
             return launched();
         };
-        return ric ? go1(oc_pdp_fused_kernel<Mdl, true>) : go1(oc_pdp_fused_kernel<Mdl, false>);
+        return (ric || prec) ? go1(oc_pdp_fused_kernel<Mdl, true>) : go1(oc_pdp_fused_kernel<Mdl, false>);
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
 
@@ -287,19 +296,21 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
         if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
         const bool predict = (op->flags & PDP_MS_PREDICT) != 0;
-        if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || !op->dxdp || !op->dudp)) return PDP_E_ARG;
+        if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || (!op->predict_record && (!op->dxdp || !op->dudp)))) return PDP_E_ARG;
         // PDP_MS_PREDICT is applied by the runner / evaluator kernel while it loads the point (dx parked in its LDS pool); where that kernel does not run, or the
         // horizon outgrows the pool, the prediction is a launch of its own in front of the solve (pdp_oc_predict_batched, in place on x, u, lam)
         pdp_oc_ms_opts op1 = *op;
         auto predict_first = [&]() -> int {
             if (!predict) return 0;
             op1.flags &= ~PDP_MS_PREDICT;
-            if constexpr (Mdl::NU + Mdl::NP <= 16) return oc_predict<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->dxdp, op->dudp, op->riccati, x, u, op->riccati ? lam : nullptr, st);
-            else return PDP_E_SIZE;
+            if constexpr (Mdl::NU + Mdl::NP <= 16) {
+                if (op->predict_record) return oc_predict_rec<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->predict_record, x, u, lam, st);
+                return oc_predict<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->dxdp, op->dudp, op->riccati, x, u, op->riccati ? lam : nullptr, st);
+            } else return PDP_E_SIZE;
         };
         if constexpr (ms2_ok<Mdl>()) {
             if (ms_variant() == 2 || needs_pair) {
-                if (predict && !Ms2Layout<Mdl>::predict_fits(T)) { const int rc = predict_first(); if (rc != 0) return rc; }
+                if (predict && !op->predict_record && !Ms2Layout<Mdl>::predict_fits(T)) { const int rc = predict_first(); if (rc != 0) return rc; }      // (the record is staged block by block: any horizon)
                 op = &op1;
                 // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
                 // batches spread over the CUs with the two waves of a trajectory on different SIMDs
@@ -568,15 +579,25 @@ int64_t pdp_oc_pdp_workspace_bytes(int B, int T) {
 int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta, int tb, const double* demo_x,
                             const double* demo_u, double* x, double* lam, double* loss, double* grad, double* dxdp, double* dudp, int32_t* status,
                             void* workspace, int64_t workspace_bytes, void* stream) {
-    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, nullptr, status, workspace, workspace_bytes, stream);
+    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, nullptr, nullptr, status, workspace, workspace_bytes, stream);
 }
 int64_t pdp_oc_riccati_doubles(void) {
     if constexpr (PdpModel::KIND == PDP_KIND_OC) return oc_riccati_doubles<PdpModel>(); else return 0;
 }
+int64_t pdp_oc_predict_record_floats(void) {
+    if constexpr (PdpModel::KIND == PDP_KIND_OC) return PredRec<PdpModel>::SIZE; else return 0;
+}
 int pdp_oc_pdp_grad_sens_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta, int tb, const double* demo_x,
-                                 const double* demo_u, double* x, double* lam, double* loss, double* grad, double* dxdp, double* dudp, double* riccati,
+                                 const double* demo_u, double* x, double* lam, double* loss, double* grad, const pdp_oc_sens_out* sens,
                                  int32_t* status, void* workspace, int64_t workspace_bytes, void* stream) {
-    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, dxdp, dudp, riccati, status, workspace, workspace_bytes, stream);
+    const pdp_oc_sens_out none = {nullptr, nullptr, nullptr, nullptr};
+    const pdp_oc_sens_out& so = sens ? *sens : none;
+    return oc_pdp<PdpModel>(B, T, flags, x0, u, theta, tb, demo_x, demo_u, x, lam, loss, grad, so.dxdp, so.dudp, so.riccati, so.predict_record, status, workspace,
+                            workspace_bytes, stream);
+}
+int pdp_oc_predict_record_batched(int B, int T, const double* dtheta, int dtheta_bstride, const float* predict_record, double* x, double* u, double* lam,
+                                  void* stream) {
+    return oc_predict_rec<PdpModel>(B, T, dtheta, dtheta_bstride, predict_record, x, u, lam, stream);
 }
 int pdp_oc_predict_batched(int B, int T, const double* dtheta, int dtheta_bstride, const double* dxdp, const double* dudp, const double* riccati, double* x,
                            double* u, double* lam, void* stream) {

@@ -505,6 +505,45 @@ __host__ __device__ constexpr int fused_gain0_doubles() { return Mdl::NX * Mdl::
 // Riccati record of a stage (optional output of the fused gradient unit): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | one scratch word (zero sink of the tile stores)
 template <class Mdl>
 __host__ __device__ constexpr int oc_riccati_doubles() { return Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1; }
+// Prediction record of a stage (optional fp32 output of the fused gradient unit): everything the first-order prediction of the next OC solve's starting point
+// needs, packed and in SINGLE precision - X_{t+1} [NX x NP] | U_t [NU x NP] | upper triangle of P_{t+1} (row-major packed) | W_{t+1} [NX x NP].  A starting
+// point is only ever first-order accurate in dtheta; fp32 factors (6e-8 relative on a correction of size |dtheta|) are far below that error, and the record
+// is 74 MB per launch at C3 where the fp64 outputs (dxdp, dudp, riccati) are 181 MB - the difference between a prediction that is read at HBM speed inside the
+// solver (42 us of a 265 us solve) and one that stays in the Infinity Cache (profiles/r04_predict_cost.txt).
+template <class Mdl>
+struct PredRec {
+    static constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+    static constexpr int X = 0, U = NX * NP, P = U + NU * NP, W = P + NX * (NX + 1) / 2, SIZE = W + NX * NP;
+    __host__ __device__ static constexpr int tri(int i, int j) { return i <= j ? i * NX - i * (i - 1) / 2 + (j - i) : j * NX - j * (j - 1) / 2 + (i - j); }
+};
+struct PredMap { unsigned voff[4]; };        // BYTE offsets of a tile's elements inside one stage's record (fp32), or out of range
+template <class Fn>
+PDP_DEV PredMap pred_map(int lane, Fn idx /* (row, col) -> float index inside the record, or -1 */) {
+    PredMap m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int k = idx(tile_row(lane, r), tile_col(lane)); m.voff[r] = k >= 0 ? 4u * (unsigned)k : 0x80000000u; }
+    return m;
+}
+template <int NR = 4, class RS>
+PDP_DEV void pred_store(RS rs, unsigned soff, const PredMap& m, const d4 v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float x = (float)v[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, m.voff[r], soff, 0);
+    }
+}
+template <class Mdl>
+struct PredMaps {
+    PredMap X, U, P, W;
+    PDP_DEV explicit PredMaps(int lane) {
+        using R = PredRec<Mdl>;
+        constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+        X = pred_map(lane, [](int r, int c) { return (r < NX && c >= NU && c < NU + NP) ? R::X + r * NP + (c - NU) : -1; });
+        U = pred_map(lane, [](int r, int c) { return (r < NU && c >= NU && c < NU + NP) ? R::U + r * NP + (c - NU) : -1; });
+        P = pred_map(lane, [](int r, int c) { return (r <= c && c < NX) ? R::P + R::tri(r, c) : -1; });
+        W = pred_map(lane, [](int r, int c) { return (r < NX && c >= NU && c < NU + NP) ? R::W + r * NP + (c - NU) : -1; });
+    }
+};
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain_doubles() {
     return fused_gain0_doubles<Mdl>() + (fused_closed_loop<Mdl>() ? Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1 : 0);              // + Acl | ecl | zero sink
@@ -554,7 +593,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                                                            const double* __restrict__ demo_u, double* __restrict__ x, double* __restrict__ lam,
                                                            double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ dxdp,
                                                            double* __restrict__ dudp, int32_t* __restrict__ status, double* __restrict__ ws_gain,
-                                                           double* __restrict__ riccati) {
+                                                           double* __restrict__ riccati, float* __restrict__ prec) {
     using L = FusedLayout<Mdl>;
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP, CH = L::CH, M = NU;
     constexpr int GSZ = fused_gain_doubles<Mdl>();         // per step: K [NU x NX] | k [NU x NP] | zero sink
@@ -723,7 +762,11 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         // Riccati record of a stage (RIC; see oc_pdp_fused3_kernel): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | zero sink
         constexpr int RSZ = oc_riccati_doubles<Mdl>();
         [[maybe_unused]] const TileMapBytes mRP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, RSZ - 1), mRW = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
-        [[maybe_unused]] double* rw = RIC ? riccati + (int64_t)b * T * RSZ : nullptr;
+        [[maybe_unused]] double* rw = (RIC && riccati) ? riccati + (int64_t)b * T * RSZ : nullptr;
+        // prediction record (RIC, fp32, see PredRec): range-checked buffer stores, a NULL record is a resource of size 0
+        [[maybe_unused]] const PredMaps<Mdl> pm(lane);
+        [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                              RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
         Gather gGTb;                                      // G' (m x n, rows 0..3): left operand of the rank-m products G K and G k
         make_gather(gGTb, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (CLF && r < M && c < NX) ? codeA(1, c * NU + r) : -1; });
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
@@ -843,8 +886,9 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                     if constexpr (RIC) {                     // (P is in rep form: the first column block is P itself, the replicas must not reach the sink slot)
                         d4 Pt_ = z, Wt_ = z;
                         Pt_[0] = (lane & 12) == 0 ? Pr : 0.0; Wt_[0] = Wr;
-                        store_all<1>(rw + t * RSZ, mRP, Pt_);
-                        store_all<1>(rw + t * RSZ + NX * NX, mRW, Wt_);
+                        if (rw) { store_all<1>(rw + t * RSZ, mRP, Pt_); store_all<1>(rw + t * RSZ + NX * NX, mRW, Wt_); }
+                        pred_store<1>(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, Pt_);
+                        pred_store<1>(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, Wt_);
                     }
                     ok = riccati_small_backward<M, true>(Pr, Wr, Fu[0], Yu[0], Grep[0], Hxx[0], HX2[0], HU2[0], Hux[0], lane, tlane, NP, g) && ok;
                     P[0] = Pr; W2[0] = Wr;
@@ -858,7 +902,11 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 d4 P_old;
                 [[maybe_unused]] d4 GTb = z;
                 if constexpr (CLF) GTb = gather_run<1>(rGTb, -1);
-                if constexpr (RIC) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
+                if constexpr (RIC) {
+                    if (rw) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
+                    pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P);
+                    pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2);
+                }
                 ok = riccati_backward<M, false>(P, W2, Fu, Yu, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, g, P_old) && ok;
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
@@ -969,6 +1017,9 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
         d4 KTn = -load_all<NRT>(gw, mKT);
         d4 kn = -load_all<1>(gw + NX * NU, mIK);
+        [[maybe_unused]] const PredMaps<Mdl> pmf(lane);
+        [[maybe_unused]] const auto rsPRf = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                               RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
         const int nchunk = (T + CH - 1) / CH;
         const int ch = (T + nchunk - 1) / nchunk;      // chunks of equal length
         for (int c = 0; c < nchunk; ++c) {
@@ -1013,6 +1064,10 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
                 if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                 if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
+                if constexpr (RIC) {
+                    pred_store<NRT>(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.X, Xn);      // X_{t+1}
+                    pred_store<1>(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.U, U2);
+                }
                 PDP_FINE(11, t == 20);
                 PDP_FINE(12, t == 21);
             };
@@ -1094,6 +1149,40 @@ __global__ void __launch_bounds__(64) oc_predict_kernel(int B, int T, const doub
         for (int j = 0; j < NP; ++j) dl = fma(R[NX * NX + ii * NP + j], d[j], dl);
 #pragma unroll
         for (int k = 0; k < NX; ++k) dl = fma(R[ii * NX + k], __shfl(dx, (threadIdx.x & 48) + k, 64), dl);
+        if (live && i < NX) lam[((int64_t)b * T + tc) * NX + i] += dl;
+    }
+}
+
+// the same prediction from the packed fp32 record (PredRec) - the launch of its own used where the runner / evaluator solver kernel, which applies the record
+// while loading the point, does not run
+template <class Mdl>
+__global__ void __launch_bounds__(64) oc_predict_rec_kernel(int B, int T, const double* __restrict__ dtheta, int dtb, const float* __restrict__ rec,
+                                                            double* __restrict__ x, double* __restrict__ u, double* __restrict__ lam) {
+    using R = PredRec<Mdl>;
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
+    const int nq = (T + 3) / 4;
+    const int b = blockIdx.x / nq, t = (blockIdx.x - b * nq) * 4 + (threadIdx.x >> 4), i = threadIdx.x & 15;
+    if (b >= B) return;
+    const bool live = t < T;
+    const int tc = live ? t : T - 1;
+    double d[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) d[j] = dtheta[(int64_t)b * dtb + j];
+    const float* r = rec + ((int64_t)b * T + tc) * R::SIZE;
+    const int ii = i < NX ? i : 0, iu = i < NU ? i : 0;
+    double dx = 0.0, du = 0.0, dl = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + ii * NP + j], d[j], dx);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + iu * NP + j], d[j], du);
+    if (i >= NX) dx = 0.0;
+    if (live && i < NX) x[((int64_t)b * (T + 1) + tc + 1) * NX + i] += dx;
+    if (live && i < NU) u[((int64_t)b * T + tc) * NU + i] += du;
+    if (lam) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + ii * NP + j], d[j], dl);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(ii, k)], __shfl(dx, (threadIdx.x & 48) + k, 64), dl);
         if (live && i < NX) lam[((int64_t)b * T + tc) * NX + i] += dl;
     }
 }

@@ -372,12 +372,63 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         //     x_t + X_t dtheta,   u_t + U_t dtheta,   lam_t + P_{t+1} (X_{t+1} dtheta) + W_{t+1} dtheta
         // (X, U and the Riccati record of the gradient unit at that solution: pdp_oc_pdp_grad_sens_batched; the same numbers as pdp_oc_predict_batched, applied
         // here so that an IRL iteration needs neither another launch nor a copy of the trajectory).  dx is parked in the still unused pool for the multiplier part.
-        const bool pred = warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
+        const float* rec = (warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta) ? op.predict_record : nullptr;      // the packed fp32 record (PredRec) takes precedence
+        const bool pred = !rec && warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
         const bool predl = pred && op.riccati != nullptr;
         {
             double* s0 = Pt(0);
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
-            if (!pred) {
+            if (rec) {
+                // one pass over blocks of SB stages: the block's records (SB x PredRec::SIZE floats, contiguous) come in with coalesced loads, lane (stage, row) forms
+                // dx_{t+1}, du_t, parks dx in LDS, and - after the exchange - dlam_t = W_{t+1} dtheta + P_{t+1} dx_{t+1} from the same block
+                using R = PredRec<Mdl>;
+                constexpr int SB = 64 / NX, NQ = (SB * R::SIZE + 63) / 64;
+                static_assert(SB * R::SIZE / 2 + SB * NX + 2 <= L::PRED_STG + 64, "record staging block");
+                float* stage = (float*)pool;
+                double* dxb = pool + (SB * R::SIZE + 1) / 2;          // dx of the block: [stage][row]
+                double dth[NP > 0 ? NP : 1];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) dth[j] = op.dtheta[(int64_t)b * op.dtheta_bstride + j];
+                for (int i = lane; i < NX; i += 64) s0[i * TS] = x0[(int64_t)b * NX + i];
+                const int sg = lane / NX, i = lane - sg * NX;
+                for (int t0 = 0; t0 < T; t0 += SB) {
+                    const int nst = min(SB, T - t0), nd = nst * R::SIZE;
+                    const float* s_ = rec + ((int64_t)b * T + t0) * R::SIZE;
+                    float v[NQ];
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; v[k] = s_[idx < nd ? idx : 0]; }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; if (idx < SB * R::SIZE) stage[idx] = v[k]; }
+                    wave_lds_sync();
+                    const bool live = lane < nst * NX;
+                    const int t = t0 + (live ? sg : 0);
+                    const float* r = stage + (live ? sg : 0) * R::SIZE;
+                    double dx = 0.0;
+                    if (live) {
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
+                        dxb[sg * NX + i] = dx;
+                        s0[i * TS + t + 1] = xb[(t + 1) * NX + i] + dx;
+                        if (i < NU) {
+                            double du = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + i * NP + j], dth[j], du);
+                            s0[OU + i * TS + t] = ub[t * NU + i] + du;
+                        }
+                    }
+                    wave_lds_sync();
+                    if (live) {
+                        double dl = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                        s0[OL + i * TS + t] = lb[t * NX + i] + dl;
+                    }
+                    wave_lds_sync();
+                }
+            } else if (!pred) {
                 for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0); }
                 for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = warm ? ub[q] : 0.0; }
                 for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = warm ? lb[q] : 0.0; }

@@ -74,8 +74,8 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     and the least-squares multipliers).  warm_start: a previous solution of the same batch (dict with
     state, control, costate[, gains]) - the multiple-shooting solver starts from that point.  Samples the multiple-shooting solver
     returns unconverged (no restoration possible, iteration limit) are re-solved by the single-shooting path.
-    predict (with warm_start = the solution at the PREVIOUS parameter): dict(dtheta, dxdp, dudp[, riccati]) - the parameter step and the sensitivity outputs of
-    OCSys.pdp_grad_batch(..., want_sens=True, want_riccati=True) at that solution; the solver then starts from the first-order prediction
+    predict (with warm_start = the solution at the PREVIOUS parameter): dict(dtheta, record) - the parameter step and the packed prediction record of
+    OCSys.pdp_grad_batch(..., want_predict_record=True) at that solution - or dict(dtheta, dxdp, dudp[, riccati]) with its fp64 sensitivity outputs; the solver then starts from the first-order prediction
     (x, u, lam) + (X, U, Lambda) dtheta (PDP_MS_PREDICT) and saves a Newton iteration - the IRL loop of examples/irl_pdp.py.
     Returns dict of CUDA tensors: state [B,T+1,n], control [B,T,m], costate [B,T,n], cost [B], grad_norm [B], converged [B] (bool),
     iterations (int, sequential iterations of the slowest sample), method_ms [B] (bool: solved by the multiple-shooting kernel)."""

@@ -42,7 +42,11 @@ class PdpOcSolveOpts(C.Structure):
 
 class PdpOcMsOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("flags", C.c_int), ("log_rows", C.c_int), ("dtheta_bstride", C.c_int),
-                ("dtheta", C.c_void_p), ("dxdp", C.c_void_p), ("dudp", C.c_void_p), ("riccati", C.c_void_p)]
+                ("dtheta", C.c_void_p), ("dxdp", C.c_void_p), ("dudp", C.c_void_p), ("riccati", C.c_void_p), ("predict_record", C.c_void_p)]
+
+
+class PdpOcSensOut(C.Structure):
+    _fields_ = [("dxdp", C.c_void_p), ("dudp", C.c_void_p), ("riccati", C.c_void_p), ("predict_record", C.c_void_p)]
 
 
 class PdpPolicy(C.Structure):
@@ -54,7 +58,8 @@ CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_bat
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_ms_residuals_batched",
                  "pdp_oc_auxsys_batched",
                  "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched", "pdp_oc_solve_ms_workspace_bytes", "pdp_oc_solve_ms_batched",
-                 "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_oc_riccati_doubles", "pdp_oc_pdp_grad_sens_batched", "pdp_oc_predict_batched",
+                 "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_oc_riccati_doubles", "pdp_oc_predict_record_floats", "pdp_oc_pdp_grad_sens_batched",
+                 "pdp_oc_predict_batched", "pdp_oc_predict_record_batched",
                  "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
                  "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
 
@@ -235,8 +240,10 @@ _MODEL_SIGS = {
     "pdp_oc_pdp_workspace_bytes": (_I64, [_I, _I]),
     "pdp_oc_pdp_grad_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
     "pdp_oc_riccati_doubles": (_I64, []),
-    "pdp_oc_pdp_grad_sens_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "pdp_oc_predict_record_floats": (_I64, []),
+    "pdp_oc_pdp_grad_sens_batched": (_I, [_I, _I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(PdpOcSensOut), _VP, _VP, _I64, _VP]),
     "pdp_oc_predict_batched": (_I, [_I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pdp_oc_predict_record_batched": (_I, [_I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "pdp_cp_integrate_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pdp_cp_auxsys_batched": (_I, [_I, _I, C.POINTER(PdpPolicy), _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pdp_cp_step_workspace_bytes": (_I64, [_I, _I, C.POINTER(PdpPolicy), _I]),
@@ -373,11 +380,17 @@ class ModelLib:
         if predict is not None:
             assert warm is not None, "predict needs the previous solution as the warm point"
             dth, dtb = self._theta(predict["dtheta"], B)
-            keep = (dth, dev(predict["dxdp"]), dev(predict["dudp"]), dev(predict["riccati"]) if predict.get("riccati") is not None else None)
-            assert keep[1].shape == (B, T + 1, self.n, self.p) and keep[2].shape == (B, T, self.m, self.p)
             opts.flags |= 16
-            opts.dtheta_bstride, opts.dtheta, opts.dxdp, opts.dudp = dtb, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr()
-            opts.riccati = keep[3].data_ptr() if keep[3] is not None else None
+            opts.dtheta_bstride, opts.dtheta = dtb, dth.data_ptr()
+            if predict.get("record") is not None:           # the packed fp32 record (oc_pdp_grad(want_predict_record=True))
+                keep = (dth, predict["record"])
+                assert keep[1].dtype == torch.float32 and tuple(keep[1].shape) == (B, T, int(self.lib.pdp_oc_predict_record_floats())) and keep[1].is_contiguous()
+                opts.predict_record = keep[1].data_ptr()
+            else:
+                keep = (dth, dev(predict["dxdp"]), dev(predict["dudp"]), dev(predict["riccati"]) if predict.get("riccati") is not None else None)
+                assert keep[1].shape == (B, T + 1, self.n, self.p) and keep[2].shape == (B, T, self.m, self.p)
+                opts.dxdp, opts.dudp = keep[1].data_ptr(), keep[2].data_ptr()
+                opts.riccati = keep[3].data_ptr() if keep[3] is not None else None
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}
@@ -427,12 +440,15 @@ class ModelLib:
         check(self.lib.pdp_oc_auxsys_batched(B, T, ptr(x), ptr(u), ptr(lam), ptr(th), tb, C.byref(o), current_stream_ptr()), "pdp_oc_auxsys_batched")
         return out
 
-    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None, packed=False, want_riccati=False):
+    def oc_pdp_grad(self, u, theta, demo_x, demo_u, x0=None, x=None, lam=None, want_sens=False, buffers=None, packed=False, want_riccati=False,
+                    want_predict_record=False):
         """Fused forward + Riccati + PDP gradient.  Give (x, lam) to use an optimal trajectory (PDP_OC_GIVEN_TRAJ),
         else x0 and the kernel integrates u and the costates itself.  Returns dict(loss, grad, x, lam, status[, dxdp, dudp][, riccati]).
         packed: the kernel writes gradient and loss as one [B, p+1] tensor (PDP_OC_PACKED; out["packed"], out["grad"] is a view of it).
         want_riccati (with want_sens: everything oc_predict needs): also the Riccati matrices of the auxiliary control system,
-        out["riccati"] [B, T, n n + n p + 1] = P_{t+1} | W_{t+1} | one scratch word per stage (pdp_oc_pdp_grad_sens_batched)."""
+        out["riccati"] [B, T, n n + n p + 1] = P_{t+1} | W_{t+1} | one scratch word per stage (pdp_oc_pdp_grad_sens_batched).
+        want_predict_record: out["predict_record"], float32 [B, T, 2 n p + m p + n (n + 1) / 2] - the same information packed in single precision, what an IRL loop
+        hands to the next oc_solve_ms(predict=dict(dtheta=..., record=...)) (2.4 times less memory traffic than the fp64 outputs)."""
         torch = torch_cuda()
         u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
         B, T = u.shape[0], u.shape[1]
@@ -465,13 +481,16 @@ class ModelLib:
         dxdp = buf("dxdp", (B, T + 1, n, p)) if want_sens else None
         dudp = buf("dudp", (B, T, m, p)) if want_sens else None
         ric = buf("riccati", (B, T, int(self.lib.pdp_oc_riccati_doubles()))) if want_riccati else None
+        prec = buf("predict_record", (B, T, int(self.lib.pdp_oc_predict_record_floats())), torch.float32) if want_predict_record else None
         nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
         ws = buf("ws", (max(nbytes, 8) // 8,))
-        if want_riccati:
+        if want_riccati or want_predict_record:
+            so = PdpOcSensOut(dxdp.data_ptr() if dxdp is not None else None, dudp.data_ptr() if dudp is not None else None,
+                              ric.data_ptr() if ric is not None else None, prec.data_ptr() if prec is not None else None)
             rc = self.lib.pdp_oc_pdp_grad_sens_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
-                                                       ptr(pk), ptr(dxdp), ptr(dudp), ptr(ric), ptr(status), ptr(ws), nbytes, current_stream_ptr())
+                                                       ptr(pk), C.byref(so), ptr(status), ptr(ws), nbytes, current_stream_ptr())
             if rc == -2:
-                raise RuntimeError("pdp_oc_pdp_grad_sens_batched: the Riccati record is an output of the fused kernels (n <= 16, m <= 4, m + p <= 16)")
+                raise RuntimeError("pdp_oc_pdp_grad_sens_batched: the Riccati / prediction records are outputs of the fused kernels (n <= 16, m <= 4, m + p <= 16)")
         else:
             rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
                                                   ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
@@ -495,7 +514,18 @@ class ModelLib:
             out.update(dxdp=dxdp, dudp=dudp)
         if want_riccati:
             out["riccati"] = ric
+        if want_predict_record:
+            out["predict_record"] = prec
         return out
+
+    def oc_predict_from_record(self, x, u, lam, dtheta, record):
+        """oc_predict from the packed fp32 record (pdp_oc_predict_record_batched): new tensors (x, u, lam) + first-order change for the step dtheta"""
+        x, u, lam = dev(x).clone(), dev(u).clone(), dev(lam).clone()
+        B, T = u.shape[0], u.shape[1]
+        dth, dtb = self._theta(dtheta, B)
+        assert record.dtype == torch_cuda().float32 and tuple(record.shape) == (B, T, int(self.lib.pdp_oc_predict_record_floats()))
+        check(self.lib.pdp_oc_predict_record_batched(B, T, ptr(dth), dtb, ptr(record), ptr(x), ptr(u), ptr(lam), current_stream_ptr()), "pdp_oc_predict_record_batched")
+        return x, u, lam
 
     def oc_predict(self, x, u, lam, dtheta, dxdp, dudp, riccati=None):
         """First-order prediction of the optimal (x, u, lam) at theta + dtheta from the gradient unit's sensitivity outputs (pdp_oc_predict_batched):

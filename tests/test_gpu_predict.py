@@ -162,6 +162,11 @@ for name, B in (("cartpole", 9), ("quadrotor", 2)):
     assert bool(r["converged"].all())
     for k in ("state", "control", "costate", "iterations"):
         out[name + "_" + k] = r[k].cpu().numpy()
+    o2 = mdl.oc_pdp_grad(sol["control"], th, sol["state"], sol["control"], x=sol["state"], lam=sol["costate"], want_predict_record=True)
+    r2 = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(sol["state"], sol["control"], sol["costate"]), predict=dict(dtheta=th1 - th[None], record=o2["predict_record"]))
+    assert bool(r2["converged"].all())
+    for k in ("state", "control", "costate", "iterations"):
+        out[name + "_rec_" + k] = r2[k].cpu().numpy()
 np.savez(sys.argv[1], **out)
 """
 
@@ -185,3 +190,50 @@ def test_prediction_in_front_of_the_one_wave_kernel(golden_dir, tmp_path):
             assert np.array_equal(a, b), k
         else:
             assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max()), k
+
+
+@pytest.mark.parametrize("name,B", [("cartpole", 5), ("quadrotor", 2), ("rocket", 2)])
+def test_packed_fp32_prediction_record(golden_dir, margins, name, B):
+    """the single-precision record an IRL loop passes from the gradient unit to the next solve (pdp_oc_sens_out.predict_record: X_{t+1} | U_t | triangle of P_{t+1} |
+    W_{t+1} per stage): its entries are the fp64 outputs rounded to fp32; the point predicted from it agrees with the oracle's to fp32 accuracy OF THE CORRECTION
+    (1e-6 of the step); the solver started from it - inside the launch (PDP_MS_PREDICT with the record) or from pdp_oc_predict_record_batched - takes the iterations
+    the oracle takes from its own (fp64) prediction and lands in the same optimum; asking for the record changes nothing in loss and gradient."""
+    from oracle import ipopt_ms
+    d, oc, mdl = setup(golden_dir, name)
+    th = d["true_parameter"]
+    T = d["control"].shape[1]
+    n, m, p = oc.n, oc.m, oc.p
+    x0 = np.repeat(d["state"][:1, 0], B, axis=0)
+    x0[:, 1] += 0.01 * np.arange(B)
+    sol = solve_at(mdl, x0, th, T)
+    dem = (d["state"][:1].repeat(B, axis=0), d["control"][:1].repeat(B, axis=0))
+    a = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True, want_predict_record=True)
+    b = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"])
+    c = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"], want_predict_record=True)      # the record alone
+    assert bool((a["loss"] == b["loss"]).all()) and bool((a["grad"] == b["grad"]).all()) and bool((c["grad"] == b["grad"]).all())
+    rec = a["predict_record"].cpu().numpy()
+    assert rec.dtype == np.float32 and rec.shape == (B, T, 2 * n * p + m * p + n * (n + 1) // 2) and np.array_equal(rec, c["predict_record"].cpu().numpy())
+    X, U, R = a["dxdp"].cpu().numpy(), a["dudp"].cpu().numpy(), a["riccati"].cpu().numpy()
+    P, W = R[:, :, :n * n].reshape(B, T, n, n), R[:, :, n * n:n * n + n * p].reshape(B, T, n, p)
+    iu = np.triu_indices(n)
+    want = np.concatenate([X[:, 1:].reshape(B, T, -1), U.reshape(B, T, -1), P[:, :, iu[0], iu[1]], W.reshape(B, T, -1)], axis=2).astype(np.float32)
+    assert np.array_equal(rec, want)
+    rng = np.random.default_rng(5)
+    th1 = th[None] * (1 + 0.02 * rng.uniform(-1, 1, (B, p)))
+    dth = th1 - th[None]
+    xs, us, ls = (sol[k].cpu().numpy() for k in ("state", "control", "costate"))
+    xp, up, lp = (t_.cpu().numpy() for t_ in mdl.oc_predict_from_record(sol["state"], sol["control"], sol["costate"], dth, a["predict_record"]))
+    warm = (sol["state"], sol["control"], sol["costate"])
+    inl = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, record=a["predict_record"]))
+    pre = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(xp, up, lp))
+    assert bool(inl["converged"].all()) and bool(pre["converged"].all())
+    for i in range(B):
+        ex, eu, el = ipopt_ms.predict_start(oc, xs[i], us[i], ls[i], th, dth[i])
+        for lab, got, e, base in (("state", xp[i], ex, xs[i]), ("control", up[i], eu, us[i]), ("costate", lp[i], el, ls[i])):
+            margins.check("point predicted from the fp32 record vs oracle, %s sample %d: %s (relative to the size of the correction)" % (name, i, lab),
+                          np.abs(got - e).max() / max(1e-300, np.abs(e - base).max()), 1e-6)
+        ref = ipopt_ms.solve(oc, x0[i], T, th1[i], tol=1e-10, warm=(ex, eu, el))
+        assert int(inl["iterations"][i]) == ref["iterations"] == int(pre["iterations"][i]), (name, i)
+        for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+            sc_ = max(1.0, np.abs(ref[kr]).max())
+            assert np.abs(inl[k][i].cpu().numpy() - ref[kr]).max() <= 1e-9 * sc_ and np.abs(pre[k][i].cpu().numpy() - ref[kr]).max() <= 1e-9 * sc_
