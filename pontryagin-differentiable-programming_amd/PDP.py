@@ -224,9 +224,8 @@ class OCSys:
         With finite bounds: ocsolver.solve_batch_bounded (kwargs: tol, max_iter, print_level)."""
         from . import ocsolver
         self._require()
-        if self.has_bounds():
-            kw = {k: v for k, v in kwargs.items() if k in ("tol", "max_iter", "print_level")}
-            return ocsolver.solve_batch_bounded(self, ini_state, int(horizon), auxvar_value, **kw)
+        if self.has_bounds():         # (kwargs the barrier continuation does not serve - u_init, warm_start, want_gains, method - raise NotImplementedError there)
+            return ocsolver.solve_batch_bounded(self, ini_state, int(horizon), auxvar_value, **kwargs)
         return ocsolver.solve_batch(self, ini_state, int(horizon), auxvar_value, **kwargs)
 
     def has_bounds(self):
@@ -239,6 +238,8 @@ class OCSys:
         is a constant).  Built by the symbolic front-end like any other cost: the kernels see one more generated model."""
         if self._bar_model is None:
             mu = SX.sym("mu_barrier")
+            from . import ocsolver
+            lbx, ubx, lbu, ubu = ocsolver.relaxed_bounds(self)          # IPOPT's bound_relax_factor
 
             def bar(v, lb, ub):
                 b = 0
@@ -248,9 +249,9 @@ class OCSys:
                     if abs(float(ub[i])) < 1e19:
                         b = b - sx.log(float(ub[i]) - v[i])
                 return b
-            bx = bar(self.state, self.state_lb, self.state_ub)
+            bx = bar(self.state, lbx, ubx)
             pb = codegen.Problem(codegen.KIND_OC, self.state, self.control, self.dyn, sx.vertcat(self.auxvar, mu),
-                                 self.path_cost + mu * (bar(self.control, self.control_lb, self.control_ub) + bx), self.final_cost + mu * bx,
+                                 self.path_cost + mu * (bar(self.control, lbu, ubu) + bx), self.final_cost + mu * bx,
                                  label=_label(self.project_name) + "_bar")
             lib, _ = codegen.build_problem(pb)
             self._bar_model = runtime.load_model(lib)

@@ -348,9 +348,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     if (tl > 0) { Fn = read3(rF, imm - RB); Yn = read3(rY, imm - RB); }
                     RiccatiGains gn;
                     d4 P_old;
-                    if constexpr (RIC) {
-                        f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2);
-                        pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2);
+                    if constexpr (RIC) {          // (uniform branches: a store to an absent output would be dropped by its size-0 resource, but still issued - 8 to 13 per step)
+                        if (riccati) { f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2); }
+                        if (prec) { pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2); }
                     }
                     ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
@@ -430,10 +430,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     riccati_forward(KTc, kc, FT, GT, E2, Xc, U2, Xn);
                     acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
                     if constexpr (RIC) {
-                        f3_bstore(rsSX, (unsigned)(t * NX * NP) * 8u, mSX, Xc);
-                        f3_bstore<1>(rsSU, (unsigned)(t * NU * NP) * 8u, mSU, U2);
-                        pred_store(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.X, Xn);       // X_{t+1}
-                        pred_store<1>(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.U, U2);
+                        if (dxdp || dudp) {
+                            f3_bstore(rsSX, (unsigned)(t * NX * NP) * 8u, mSX, Xc);
+                            f3_bstore<1>(rsSU, (unsigned)(t * NU * NP) * 8u, mSU, U2);
+                        }
+                        if (prec) {
+                            pred_store(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.X, Xn);       // X_{t+1}
+                            pred_store<1>(rsPRf, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pmf.U, U2);
+                        }
                     } else {
                         if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
                         if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);

@@ -360,7 +360,20 @@ def solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=Non
     return sol
 
 
-def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter=300, print_level=0, mu0=0.1):
+BOUND_RELAX = 1e-8            # IPOPT's bound_relax_factor: every finite bound is moved outwards by 1e-8 max(1, |bound|) before the barrier is built
+
+
+def relaxed_bounds(oc):
+    """(lbx, ubx, lbu, ubu) as IPOPT sees them: finite bounds relaxed by bound_relax_factor (so that a point ON a bound is strictly inside the barrier's box)"""
+    out = []
+    for nm, sgn in (("state_lb", -1.0), ("state_ub", 1.0), ("control_lb", -1.0), ("control_ub", 1.0)):
+        b = np.asarray(getattr(oc, nm), dtype=float)
+        fin = np.abs(b) < 1e19
+        out.append(np.where(fin, b + sgn * BOUND_RELAX * np.maximum(1.0, np.abs(b)), b))
+    return out
+
+
+def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter=300, print_level=0, mu0=0.1, **unsupported):
     """ocSolver with finite state / control bounds (the reference hands them to IPOPT as lbw / ubw, PDP/PDP.py:141-168).
 
     Log-barrier continuation around the equality-constrained multiple-shooting kernel: for mu = 0.1, then mu <- max(mu_min, min(0.2 mu, mu^1.5))
@@ -368,32 +381,41 @@ def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter
     of the bounds, part of the generated cost (OCSys.barrier_model: the symbolic front-end differentiates it like any cost term) - is solved by
     pdp_oc_solve_ms_batched, warm-started from the previous mu.  The filter line search keeps the iterates strictly inside the bounds by itself: a
     trial point outside makes the objective non-finite and is rejected (the step is halved).  The first sub-problem starts from IPOPT's starting point:
-    the all-zero guess pushed into the interior (bound_push = bound_frac = 1e-2).  This is the classical primal barrier method (Fiacco & McCormick),
-    not IPOPT's primal-dual iteration: the same solution (to O(mu_min) = tol / 10), a different path to it.  Returns the dict of solve_batch
-    (cost = the ORIGINAL objective along the returned trajectory; costate = multipliers of the dynamics = IPOPT's lam_g)."""
+    the reference's initial guess w0 = (lb + ub) / 2 where both bounds are finite (PDP.py:155,167), 0 otherwise, pushed into the interior (bound_push =
+    bound_frac = 1e-2).  The bounds are relaxed as IPOPT relaxes them (bound_relax_factor = 1e-8: relaxed_bounds), so an initial state ON a state bound is
+    inside the box (the reference's NLP does not bound x_0 at all, PDP.py:141-146; its barrier term here is a finite constant).  This is the classical primal
+    barrier method (Fiacco & McCormick), not IPOPT's primal-dual iteration: the same solution (to O(mu_min) = tol / 10), a different path to it.
+    Returns the dict of solve_batch (cost = the ORIGINAL objective along the returned trajectory; costate = multipliers of the dynamics = IPOPT's lam_g) plus
+    "kernel_converged" [B] (the last barrier sub-problem met the kernel's own test) beside "converged" (that, or the documented fp64 floor of the primal barrier)."""
+    if unsupported:
+        raise NotImplementedError("bounded ocSolver: %s not supported with finite bounds (only tol, max_iter, print_level)" % ", ".join(sorted(unsupported)))
     torch = runtime.torch_cuda()
     mdl = oc.model()
     n, m, T = mdl.n, mdl.m, int(horizon)
-    assert n <= 16 and m <= 4, "bounded ocSolver: the multiple-shooting kernel serves n <= 16, m <= 4"
+    if n > 16 or m > 4:
+        raise NotImplementedError("bounded ocSolver: the multiple-shooting kernel serves n <= 16, m <= 4")
     x0 = runtime.dev(ini_state).reshape(-1, n)
     B = x0.shape[0]
     th = np.asarray(oc._theta(auxvar_value, B), dtype=np.float64).reshape(-1, oc.n_auxvar)
-    lbx, ubx = np.asarray(oc.state_lb, float), np.asarray(oc.state_ub, float)
-    lbu, ubu = np.asarray(oc.control_lb, float), np.asarray(oc.control_ub, float)
+    lbx, ubx, lbu, ubu = relaxed_bounds(oc)
     x0n = x0.cpu().numpy()
     if bool(((x0n <= lbx[None]) | (x0n >= ubx[None])).any()):
-        # the reference's NLP does not apply the state bounds to x_0 (PDP.py:144-146), so IPOPT would accept this; a barrier method needs a starting
-        # trajectory strictly inside the bounds, which an x_0 outside them does not give for free
-        raise NotImplementedError("bounded ocSolver: an initial state on or outside the state bounds is not supported")
+        # the reference's NLP does not apply the state bounds to x_0 (PDP.py:144-146), so IPOPT would accept this; in the barrier sub-problems the term of x_0 is a
+        # constant that must be finite: on the bound it is (relaxed bounds), beyond it is not
+        raise NotImplementedError("bounded ocSolver: an initial state outside the state bounds is not supported")
     bar = oc.barrier_model()
 
     def push(z, lb, ub):                    # IPOPT's projection of the starting point into the interior of [lb, ub]
         lo = np.where(np.abs(lb) < 1e19, lb + np.minimum(1e-2 * np.maximum(1.0, np.abs(lb)), 1e-2 * (ub - lb)), -np.inf)
         hi = np.where(np.abs(ub) < 1e19, ub - np.minimum(1e-2 * np.maximum(1.0, np.abs(ub)), 1e-2 * (ub - lb)), np.inf)
         return np.minimum(np.maximum(z, lo), hi)
-    xg = np.tile(push(np.zeros(n), lbx, ubx), (B, T + 1, 1))
+
+    def w0(lb, ub):                         # the reference's initial guess 0.5 (lb + ub) (PDP.py:155,167: 0 for the +-1e20 defaults; for a one-sided bound 0 as well - IPOPT pushes it)
+        both = (np.abs(lb) < 1e19) & (np.abs(ub) < 1e19)
+        return np.where(both, 0.5 * (lb + ub), 0.0)
+    xg = np.tile(push(w0(lbx, ubx), lbx, ubx), (B, T + 1, 1))
     xg[:, 0] = x0n
-    ug = np.tile(push(np.zeros(m), lbu, ubu), (B, T, 1))
+    ug = np.tile(push(w0(lbu, ubu), lbu, ubu), (B, T, 1))
     warm = (runtime.dev(xg), runtime.dev(ug), torch.zeros((B, T, n), dtype=torch.float64, device="cuda"))
     mu_min, mu, iters = max(0.1 * tol, 1e-9), float(mu0), 0
     accepted = None
@@ -420,4 +442,5 @@ def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter
     xr, cost = mdl.oc_rollout(x0, ms["control"], oc._theta(auxvar_value, B))
     feas = (xr - ms["state"]).abs().amax(dim=(1, 2)) <= 1e3 * tol * (1 + ms["state"].abs().amax(dim=(1, 2)))
     return {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": cost, "grad_norm": ms["resid"][:, 1].contiguous(),
-            "converged": accepted & feas, "iterations": iters, "method_ms": ms["converged"].clone(), "status": ms["status"], "barrier_mu": mu}
+            "converged": accepted & feas, "kernel_converged": ms["converged"] & feas, "iterations": iters, "method_ms": ms["converged"].clone(), "status": ms["status"],
+            "barrier_mu": mu}

@@ -296,3 +296,53 @@ def test_oc_solver_with_state_and_control_bounds(golden_dir):
     x0[1, 1] = vmax + 1.0
     with pytest.raises(NotImplementedError, match="outside the state bounds"):
         oc.ocSolver_batch(x0, T, th)
+
+
+def test_control_bounded_cartpole_and_an_initial_state_on_a_state_bound(golden_dir):
+    """(i) cart-pole swing-up of the IRL example (T = 30) with |u| <= 10, eight control bounds active: known answer tests/golden/bounded_oc_cartpole.npz (scipy SLSQP on
+    the single-shooting problem, six starts agreeing to 1e-7 in the cost: make_bounded_oc.py).  (ii) An initial state exactly ON a state bound is accepted - the
+    reference's NLP does not bound x_0 (PDP.py:141-146) and IPOPT relaxes every bound by 1e-8 (bound_relax_factor), as ocsolver.relaxed_bounds does: pendulum started at
+    dq_0 = -6 with -6 <= dq <= 6; the bound is inactive afterwards, so the solution equals that of the same problem with the lower bound moved away.  (iii) keyword
+    arguments the barrier continuation does not serve are refused instead of being dropped."""
+    from pdp_amd import PDP, zoo
+    from pdp_amd.sx import vertcat
+    g = load(golden_dir, "bounded_oc_cartpole.npz")
+    env, dt = zoo.make_env("cartpole", "irl")
+    umax, T = float(g["umax"]), int(g["T"])
+    oc = PDP.OCSys("cartpole bounded")
+    oc.setAuxvarVariable(vertcat(env.dyn_auxvar, env.cost_auxvar))
+    oc.setStateVariable(env.X)
+    oc.setControlVariable(env.U, control_lb=[-umax], control_ub=[umax])
+    oc.setDyn(env.X + dt * env.f)
+    oc.setPathCost(env.path_cost)
+    oc.setFinalCost(env.final_cost)
+    sol = oc.ocSolver_batch(g["x0"][None], T, g["theta"])
+    assert bool(sol["converged"].all()) and "kernel_converged" in sol
+    x, u = sol["state"][0].cpu().numpy(), sol["control"][0].cpu().numpy()
+    assert np.all(np.abs(u) <= umax)
+    assert abs(float(sol["cost"][0]) - float(g["cost"])) <= 1e-6 * float(g["cost"])
+    assert np.abs(u - g["control"]).max() <= 5e-3 * umax and np.abs(x - g["state"]).max() <= 5e-3 * np.abs(g["state"]).max()
+    assert np.array_equal(np.abs(np.abs(u[:, 0]) - umax) < 1e-5, g["active_u"])
+    with pytest.raises(NotImplementedError, match="warm_start"):
+        oc.ocSolver_batch(g["x0"][None], T, g["theta"], warm_start=sol)
+    # (ii)
+    gp = load(golden_dir, "bounded_oc_pendulum.npz")
+    envp, dtp = zoo.make_env("pendulum", "irl")
+
+    def pend(lb):
+        o = PDP.OCSys("pendulum bounded x0")
+        o.setAuxvarVariable(vertcat(envp.dyn_auxvar, envp.cost_auxvar))
+        o.setStateVariable(envp.X, state_lb=[-1e20, lb], state_ub=[1e20, 6.0])
+        o.setControlVariable(envp.U, control_lb=[-12.0], control_ub=[12.0])
+        o.setDyn(envp.X + dtp * envp.f)
+        o.setPathCost(envp.path_cost)
+        o.setFinalCost(envp.final_cost)
+        return o
+    x0 = np.array([[0.0, -6.0]])
+    on = pend(-6.0).ocSolver_batch(x0, 20, gp["theta"])
+    off = pend(-9.0).ocSolver_batch(x0, 20, gp["theta"])
+    assert bool(on["converged"].all()) and bool(off["converged"].all())
+    xs = on["state"][0].cpu().numpy()
+    assert xs[0, 1] == -6.0 and np.all(xs[1:, 1] > -6.0 + 1e-3) and np.all(xs[1:, 1] <= 6.0 + 1e-9)       # on the bound at t = 0, inside afterwards
+    assert float((on["state"] - off["state"]).abs().max()) <= 1e-5 * float(off["state"].abs().max())
+    assert abs(float(on["cost"][0]) - float(off["cost"][0])) <= 1e-7 * float(off["cost"][0])

@@ -231,7 +231,7 @@ def test_packed_fp32_prediction_record(golden_dir, margins, name, B):
         ex, eu, el = ipopt_ms.predict_start(oc, xs[i], us[i], ls[i], th, dth[i])
         for lab, got, e, base in (("state", xp[i], ex, xs[i]), ("control", up[i], eu, us[i]), ("costate", lp[i], el, ls[i])):
             margins.check("point predicted from the fp32 record vs oracle, %s sample %d: %s (relative to the size of the correction)" % (name, i, lab),
-                          np.abs(got - e).max() / max(1e-300, np.abs(e - base).max()), 1e-6)
+                          np.abs(got - e).max() / max(1e-300, np.abs(e - base).max()), 1e-5 if lab == "costate" else 1e-6)      # (P dx and W dtheta cancel in part)
         ref = ipopt_ms.solve(oc, x0[i], T, th1[i], tol=1e-10, warm=(ex, eu, el))
         assert int(inl["iterations"][i]) == ref["iterations"] == int(pre["iterations"][i]), (name, i)
         for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
