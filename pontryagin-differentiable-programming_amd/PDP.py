@@ -232,14 +232,18 @@ class OCSys:
         """any finite state / control bound?  (+-1e20, the reference's defaults, mean "none" - to IPOPT too)"""
         return any(abs(float(b)) < 1e19 for nm in ("state_lb", "state_ub", "control_lb", "control_ub") for b in getattr(self, nm, []))
 
-    def barrier_model(self):
+    def barrier_model(self, bounds=None):
         """The device model of the log-barrier sub-problem  min sum_t [c + mu b(x_t, u_t)] + h + mu b(x_T)  s.t. the dynamics:  auxvar = [theta ; mu],
         b = - sum_i log(v_i - lb_i) - sum_i log(ub_i - v_i) over the finitely bounded components of the state and the control (x_0 is fixed: its term
-        is a constant).  Built by the symbolic front-end like any other cost: the kernels see one more generated model."""
+        is a constant).  Built by the symbolic front-end like any other cost: the kernels see one more generated model.  bounds = (lbx, ubx, lbu, ubu) of the
+        barrier (ocsolver.relaxed_bounds; default: the bounds as set); one model per set of bounds, dropped when the problem changes."""
+        from . import ocsolver
+        lbx, ubx, lbu, ubu = ocsolver.relaxed_bounds(self) if bounds is None else bounds
+        key = tuple(float(v) for a in (lbx, ubx, lbu, ubu) for v in a)
         if self._bar_model is None:
+            self._bar_model = {}
+        if key not in self._bar_model:
             mu = SX.sym("mu_barrier")
-            from . import ocsolver
-            lbx, ubx, lbu, ubu = ocsolver.relaxed_bounds(self)          # IPOPT's bound_relax_factor
 
             def bar(v, lb, ub):
                 b = 0
@@ -254,8 +258,8 @@ class OCSys:
                                  self.path_cost + mu * (bar(self.control, lbu, ubu) + bx), self.final_cost + mu * bx,
                                  label=_label(self.project_name) + "_bar")
             lib, _ = codegen.build_problem(pb)
-            self._bar_model = runtime.load_model(lib)
-        return self._bar_model
+            self._bar_model[key] = runtime.load_model(lib)
+        return self._bar_model[key]
 
 
 def _label(name):

@@ -360,17 +360,23 @@ def solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=Non
     return sol
 
 
-BOUND_RELAX = 1e-8            # IPOPT's bound_relax_factor: every finite bound is moved outwards by 1e-8 max(1, |bound|) before the barrier is built
+BOUND_RELAX = 1e-8            # IPOPT's bound_relax_factor: a finite bound is moved outwards by 1e-8 max(1, |bound|)
 
 
-def relaxed_bounds(oc):
-    """(lbx, ubx, lbu, ubu) as IPOPT sees them: finite bounds relaxed by bound_relax_factor (so that a point ON a bound is strictly inside the barrier's box)"""
-    out = []
-    for nm, sgn in (("state_lb", -1.0), ("state_ub", 1.0), ("control_lb", -1.0), ("control_ub", 1.0)):
-        b = np.asarray(getattr(oc, nm), dtype=float)
-        fin = np.abs(b) < 1e19
-        out.append(np.where(fin, b + sgn * BOUND_RELAX * np.maximum(1.0, np.abs(b)), b))
-    return out
+def relaxed_bounds(oc, x0=None):
+    """(lbx, ubx, lbu, ubu) of the barrier sub-problems.  The caller's bounds, except that a STATE bound some initial state sits on is relaxed the way IPOPT relaxes
+    every bound (bound_relax_factor): the reference's NLP does not bound x_0 at all (PDP.py:141-146), but in the barrier sub-problems the term of x_0 is a constant that
+    must be finite.  (Relaxing all bounds, as IPOPT does, would let the returned controls exceed theirs by 1e-8 - and projecting them back moves the rollout of an
+    unstable system by more than the solver's tolerance; so only where it is needed.)  x0 [B, n] or None (nothing relaxed)."""
+    lbx, ubx = np.asarray(oc.state_lb, dtype=float).copy(), np.asarray(oc.state_ub, dtype=float).copy()
+    lbu, ubu = np.asarray(oc.control_lb, dtype=float), np.asarray(oc.control_ub, dtype=float)
+    if x0 is not None:
+        x0 = np.atleast_2d(np.asarray(x0, dtype=float))
+        sl, su = BOUND_RELAX * np.maximum(1.0, np.abs(lbx)), BOUND_RELAX * np.maximum(1.0, np.abs(ubx))
+        on_l = (np.abs(lbx) < 1e19) & ((x0 >= lbx[None]) & (x0 <= (lbx + sl)[None])).any(axis=0)
+        on_u = (np.abs(ubx) < 1e19) & ((x0 <= ubx[None]) & (x0 >= (ubx - su)[None])).any(axis=0)
+        lbx, ubx = np.where(on_l, lbx - sl, lbx), np.where(on_u, ubx + su, ubx)
+    return lbx, ubx, lbu, ubu
 
 
 def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter=300, print_level=0, mu0=0.1, **unsupported):
@@ -382,8 +388,8 @@ def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter
     pdp_oc_solve_ms_batched, warm-started from the previous mu.  The filter line search keeps the iterates strictly inside the bounds by itself: a
     trial point outside makes the objective non-finite and is rejected (the step is halved).  The first sub-problem starts from IPOPT's starting point:
     the reference's initial guess w0 = (lb + ub) / 2 where both bounds are finite (PDP.py:155,167), 0 otherwise, pushed into the interior (bound_push =
-    bound_frac = 1e-2).  The bounds are relaxed as IPOPT relaxes them (bound_relax_factor = 1e-8: relaxed_bounds), so an initial state ON a state bound is
-    inside the box (the reference's NLP does not bound x_0 at all, PDP.py:141-146; its barrier term here is a finite constant).  This is the classical primal
+    bound_frac = 1e-2).  A state bound an initial state sits on is relaxed as IPOPT relaxes bounds (bound_relax_factor = 1e-8: relaxed_bounds; states in that slack are
+    projected back at the end, IPOPT's honor_original_bounds), so an initial state ON a state bound is inside the box (the reference's NLP does not bound x_0 at all, PDP.py:141-146; its barrier term here is a finite constant).  This is the classical primal
     barrier method (Fiacco & McCormick), not IPOPT's primal-dual iteration: the same solution (to O(mu_min) = tol / 10), a different path to it.
     Returns the dict of solve_batch (cost = the ORIGINAL objective along the returned trajectory; costate = multipliers of the dynamics = IPOPT's lam_g) plus
     "kernel_converged" [B] (the last barrier sub-problem met the kernel's own test) beside "converged" (that, or the documented fp64 floor of the primal barrier)."""
@@ -397,13 +403,13 @@ def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter
     x0 = runtime.dev(ini_state).reshape(-1, n)
     B = x0.shape[0]
     th = np.asarray(oc._theta(auxvar_value, B), dtype=np.float64).reshape(-1, oc.n_auxvar)
-    lbx, ubx, lbu, ubu = relaxed_bounds(oc)
     x0n = x0.cpu().numpy()
+    lbx, ubx, lbu, ubu = relaxed_bounds(oc, x0n)
     if bool(((x0n <= lbx[None]) | (x0n >= ubx[None])).any()):
         # the reference's NLP does not apply the state bounds to x_0 (PDP.py:144-146), so IPOPT would accept this; in the barrier sub-problems the term of x_0 is a
         # constant that must be finite: on the bound it is (relaxed bounds), beyond it is not
         raise NotImplementedError("bounded ocSolver: an initial state outside the state bounds is not supported")
-    bar = oc.barrier_model()
+    bar = oc.barrier_model((lbx, ubx, lbu, ubu))
 
     def push(z, lb, ub):                    # IPOPT's projection of the starting point into the interior of [lb, ub]
         lo = np.where(np.abs(lb) < 1e19, lb + np.minimum(1e-2 * np.maximum(1.0, np.abs(lb)), 1e-2 * (ub - lb)), -np.inf)
@@ -439,6 +445,10 @@ def solve_batch_bounded(oc, ini_state, horizon, auxvar_value, tol=1e-8, max_iter
         if mu <= mu_min:
             break
         mu = max(mu_min, min(0.2 * mu, mu ** 1.5))
+    # (where a state bound was relaxed for an initial state on it, later states may sit in the 1e-8 slack: projected back, IPOPT's honor_original_bounds)
+    f64 = dict(dtype=torch.float64, device="cuda")
+    lo_x, hi_x = torch.as_tensor(np.asarray(oc.state_lb, float), **f64), torch.as_tensor(np.asarray(oc.state_ub, float), **f64)
+    ms["state"][:, 1:] = torch.minimum(torch.maximum(ms["state"][:, 1:], lo_x), hi_x)
     xr, cost = mdl.oc_rollout(x0, ms["control"], oc._theta(auxvar_value, B))
     feas = (xr - ms["state"]).abs().amax(dim=(1, 2)) <= 1e3 * tol * (1 + ms["state"].abs().amax(dim=(1, 2)))
     return {"state": ms["state"], "control": ms["control"], "costate": ms["costate"], "cost": cost, "grad_norm": ms["resid"][:, 1].contiguous(),
