@@ -171,7 +171,9 @@ def other_configs(torch):
         e = {"batch": B, "kernel_ms": ms, "traj_per_s": B / (ms * 1e-3)}
         if flop is not None:
             tf = flop * B / (ms * 1e-3) / 1e12
-            e.update(algorithmic_flop_per_traj=flop, achieved_tflops=tf)
+            e.update(algorithmic_flop_per_traj=flop)
+            if executed_flop is None:          # (where the kernel runs another formulation, a rate priced on flops it does not execute is not a measurement: only executed_* then)
+                e.update(achieved_tflops=tf)
             if not latency_bound:
                 e.update(bound="mfma", frac=tf / FP64_MFMA_PEAK_TFLOPS)
         if executed_flop is not None:
@@ -390,7 +392,9 @@ def scaling_configs(torch, dist, world, rank, steps):
                      "exchange_allreduce_us_per_rank": [float(v) for v in allr[:, 4]] if distributed else None,
                      "exchange_allreduce_bytes": int((p + 1) * 8) if distributed else 0,
                      "ms_per_step": step_ms, "traj_per_s": B_total / (step_ms * 1e-3),
-                     "algorithmic_flop_per_traj": flop, "achieved_tflops_all_gpus": tf, "note": note}
+                     "algorithmic_flop_per_traj": flop, "note": note}
+        if executed_flop is None:
+            res[name]["achieved_tflops_all_gpus"] = tf
         if latency_bound:       # one serial chain per trajectory: time per time step of a wavefront's chain instead of a roofline fraction (see other_configs)
             rounds = max(1, -(-int(allr[:, 3].max()) // 1024))
             res[name].update(bound="latency (one serial chain per trajectory)", ns_per_step=float(allr[:, 0].max()) * 1e6 / T / rounds, horizon=T)
@@ -562,6 +566,16 @@ def main():
             traffic = json.load(open(tf)).get("oc_pdp_fused_kernel_hbm_bytes_per_launch")
         ach_tflops = FLOP_PER_TRAJ * B / (kern_ms * 1e-3) / 1e12
         ach_gbps = BYTES_PER_TRAJ * B / (kern_ms * 1e-3) / 1e9
+        kres = None
+        try:        # registers / spills of the dominant kernel, read from the code object that ran (llvm-readelf --notes of the model library)
+            from pdp_amd import codegen
+            tpw = 1 if B <= 256 else (2 if B <= 512 else 4)
+            kname = "oc_pdp_fused3_kernel<%d,0>" % tpw if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel<0>"
+            r = codegen.kernel_resources(mdl.path).get(kname)
+            if r is not None:
+                kres = {"instantiation": kname, "vgpr_count": r["vgpr"], "agpr_count": r["agpr"], "vgpr_spill_count": r["spill"], "scratch_bytes": r["scratch"]}
+        except Exception as ex:
+            kres = {"error": repr(ex)}
         res = {
             "metric": "trajectories/sec (fwd+Riccati+PDP grad), quadrotor n=13 T=50",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -571,7 +585,7 @@ def main():
                        "batch_per_gpu": B, "horizon": T,
                        "exchange": "all_gather([B,10] gradient|loss rows) over RCCL on a side stream, overlapped with the next step's kernel" if distributed else "none (1 GPU)"},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_resources": kres,
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
                                            "(probes/profile_bench.sh), not collected in this run", "kernel_ms": kern_ms,
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B,

@@ -510,7 +510,7 @@ def kernel_resources(lib, count_scratch_instructions=False):
         sym = re.search(r"\.name:\s*(\S+)", ent).group(1)
         m = re.match(r"_ZN3pdp(\d+)", sym)                   # pdp::<name><template args...>
         name = sym[m.end():m.end() + int(m.group(1))] if m else sym
-        targs = re.findall(r"Li(\d+)E", sym[m.end() + int(m.group(1)):].split("EE")[0] + "E") if m and "I" in sym[m.end() + int(m.group(1)):][:1] else []
+        targs = re.findall(r"L[ib](\d+)E", sym[m.end() + int(m.group(1)):].split("EE")[0] + "E") if m and "I" in sym[m.end() + int(m.group(1)):][:1] else []
         key = name + ("<%s>" % ",".join(targs) if targs else "")
         out[key] = dict(vgpr=get("vgpr_count"), agpr=int(ent.split()[0]), sgpr=get("sgpr_count"), spill=get("vgpr_spill_count"),
                         scratch=get("private_segment_fixed_size"), lds=get("group_segment_fixed_size"), symbol=sym)

@@ -47,6 +47,9 @@
 #ifndef PDP_MS2_DLAM_STAGED
 #define PDP_MS2_DLAM_STAGED 1      // the multiplier step reads its (P, W) records through an LDS copy (dlam_staged) when four trajectories share a CU; 0: straight from the workspace
 #endif
+#ifndef PDP_MS2_SLEEP
+#define PDP_MS2_SLEEP 2             // s_sleep argument of the hand-over polls (64 cycles each)
+#endif
 #ifndef PDP_MS2_TAILF
 #define PDP_MS2_TAILF 0             // stages of a short last forward chunk (0: equal chunks - measured best, profiles/r03_ms2_variants.txt)
 #endif
@@ -138,7 +141,7 @@ PDP_DEV int ms2_load(int* f) { return uni(__hip_atomic_load(f, __ATOMIC_ACQUIRE,
 PDP_DEV bool ms2_wait_ge(int* f, int v, int* ctl) {
     int n = 0;
     while (ms2_load(f) < v) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(PDP_MS2_SLEEP);
         if (++n > (1 << 22) || ms2_load(ctl + MS2_DEAD) != 0) { f3_signal(ctl + MS2_DEAD, 1); return false; }
     }
     return true;
@@ -1212,7 +1215,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if (g >= 2) {
                         bool freed = false;
                         int n = 0;
-                        while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
+                        while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(PDP_MS2_SLEEP); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!freed) break;
                     }
                     MS2_E1(6);
@@ -1251,7 +1254,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if (g >= 2) {
                         bool freed = false;
                         int n = 0;
-                        while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
+                        while (!(freed = ms2_load(ctl + MS2_CONS) >= g - 1) && !stop()) { __builtin_amdgcn_s_sleep(PDP_MS2_SLEEP); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!freed) break;
                     }
                     MS2_E1(6);
@@ -1283,7 +1286,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if (c >= 1) {       // the runner has left chunk c - 1 (it could not start chunk c before the signal above): its dx are in memory
                         bool got = false;
                         int n = 0;
-                        while (!(got = ms2_load(ctl + MS2_CONS) >= g) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
+                        while (!(got = ms2_load(ctl + MS2_CONS) >= g) && !stop()) { __builtin_amdgcn_s_sleep(PDP_MS2_SLEEP); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                         if (!got) break;
                         MS2_E1(6);
                         // (the consumed chunk's buffer is free until chunk c + 1 is evaluated)
@@ -1298,7 +1301,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if (!stop()) {
                     bool got = false;
                     int n = 0;
-                    while (!(got = ms2_load(ctl + MS2_CONS) >= nchunk + nchunkF) && !stop()) { __builtin_amdgcn_s_sleep(2); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
+                    while (!(got = ms2_load(ctl + MS2_CONS) >= nchunk + nchunkF) && !stop()) { __builtin_amdgcn_s_sleep(PDP_MS2_SLEEP); if (++n > (1 << 22)) { f3_signal(ctl + MS2_DEAD, 1); dead = true; } }
                     MS2_E1(6);
                     if (got) {          // the last chunk: both pool buffers are free - its records in ONE block, one trip to memory
                         int tp, cp_;
