@@ -218,35 +218,50 @@ def other_configs(torch):
         bufs0, bufs = {}, {}
         sens0 = mdl.oc_pdp_grad(demo["control"], th_star, demo["state"], demo["control"], x=demo["state"], lam=demo["costate"], want_sens=True, want_riccati=True,
                                 want_predict_record=True, buffers=bufs0)
-        use_ric = True
         ric0 = sens0["riccati"]
         # what the loop hands from the gradient unit to the next solve: the packed fp32 prediction record (X, U, P, W in single precision: 2.4 times less traffic
         # than the fp64 outputs, which at C3 would be read at HBM speed inside the solver - probes/predict_cost.py, profiles/r04_predict_cost.txt)
-        pred_in = dict(dtheta=dth, record=sens0["predict_record"])
-        copies = [tuple(a.clone() for a in warm) for _ in range(16)]          # an IRL loop solves IN PLACE on the previous solution: every timed call gets its own copy of it
+        # Two kinds of record: the full one (states, controls AND multipliers are predicted) and its X | U part alone (PDP_OC_RECORD_PRIMAL / PDP_MS_PREDICT_PRIMAL:
+        # 5 instead of 13 stores per stage in the gradient unit, 0.4 of the bytes in the solver, multipliers start where they were).  Which one makes the faster
+        # iteration depends on the problem (the unstable cart-pole needs the multipliers: 2.2 against 2.7 iterations; the quadrotor at a 2 % step does not: 1.97
+        # against 2.00) - both pipelines are timed, the entry is the faster one, the other stands beside it.
+        pred_full = dict(dtheta=dth, record=sens0["predict_record"])
+        pred_prim = dict(dtheta=dth, record=sens0["predict_record"], primal=True)
+        copies = [tuple(a.clone() for a in warm) for _ in range(40)]          # an IRL loop solves IN PLACE on the previous solution: every timed call gets its own copy of it
 
-        def predicted_solve(tol=1e-10):       # PDP_MS_PREDICT: the prediction is applied while the solver loads the point (one launch)
-            return mdl.oc_solve_ms(x0d, theta1, T, warm=copies.pop(), consume_warm=True, predict=pred_in, tol=tol)
+        def predicted_solve(tol=1e-10, pred=pred_full):       # PDP_MS_PREDICT: the prediction is applied while the solver loads the point (one launch)
+            return mdl.oc_solve_ms(x0d, theta1, T, warm=copies.pop(), consume_warm=True, predict=pred, tol=tol)
         predict_ms = _event_ms(torch, lambda: mdl.oc_predict(demo["state"], demo["control"], demo["costate"], dth, sens0["dxdp"], sens0["dudp"], ric0), reps=5, warm=1)
-        solve_ms = _event_ms(torch, predicted_solve, reps=5, warm=1)            # prediction + solve
-        sol = predicted_solve()
+        kinds = {}
+        for kind, pred, want in (("full", pred_full, True), ("primal", pred_prim, "primal")):
+            s_ms = _event_ms(torch, lambda: predicted_solve(pred=pred), reps=5, warm=1)            # prediction + solve
+            s_ = predicted_solve(pred=pred)
+            bufs_k = {}
+            g_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(s_["control"], theta1, demo["state"], demo["control"], x=s_["state"], lam=s_["costate"],
+                                                            want_predict_record=want, buffers=bufs_k))
+            it_ = s_["iterations"].double()
+            kinds[kind] = {"oc_solve_ms": s_ms, "gradient_ms": g_ms, "iteration_ms": s_ms + g_ms, "traj_per_s": B / ((s_ms + g_ms) * 1e-3), "converged": int(s_["converged"].sum()),
+                           "iterations_mean_max": [float(it_.mean()), float(it_.max())]}
+        record_kind = min(kinds, key=lambda k: kinds[k]["iteration_ms"])
+        pred_in, want_rec = (pred_full, True) if record_kind == "full" else (pred_prim, "primal")
+        solve_ms = kinds[record_kind]["oc_solve_ms"]
+        sol = predicted_solve(pred=pred_in)
         # the same stopped where the reference's IPOPT stops (its default tol = 1e-8; the figures above use the 1e-10 the parity tests need)
-        solve8_ms = _event_ms(torch, lambda: predicted_solve(1e-8), reps=5, warm=1)
-        sol8 = predicted_solve(1e-8)
+        solve8_ms = _event_ms(torch, lambda: predicted_solve(1e-8, pred_in), reps=5, warm=1)
+        sol8 = predicted_solve(1e-8, pred_in)
         it8 = sol8["iterations"].double()
         grad_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], buffers=bufs))
-        bufs_s = {}
-        grad_sens_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"],
-                                                                want_predict_record=True, buffers=bufs_s))
+        grad_sens_ms = kinds[record_kind]["gradient_ms"]
         it, itc, itp = sol["iterations"].double(), demo["iterations"].double(), plain["iterations"].double()
         agree = max(float((sol[k] - plain[k]).abs().max()) / max(1.0, float(plain[k].abs().max())) for k in ("state", "control", "costate"))
         entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
               note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); one IRL iteration = first-order prediction of the starting point from the previous iteration's "
-                   "sensitivities (PDP_MS_PREDICT: applied inside the solver launch from the packed fp32 prediction record) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / "
+                   "sensitivities (PDP_MS_PREDICT: applied inside the solver launch from the packed fp32 prediction record - the kind named in prediction_record_kind) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / "
                    "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit "
                    "(it has none for the solve)",
               extra={"oc_solve_ms": solve_ms, "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
-                     "prediction_includes_multipliers": bool(use_ric), "prediction_record_bytes": int(sens0["predict_record"].numel() * 4), "oc_solve_converged": int(sol["converged"].sum()),
+                     "prediction_record_kind": record_kind, "prediction_includes_multipliers": record_kind == "full", "pipelines_by_record_kind": kinds,
+                     "prediction_record_bytes": int(sens0["predict_record"].numel() * 4) if record_kind == "full" else int(B * T * (mdl.n + mdl.m) * mdl.p * 4), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
                      "solution_agrees_with_plain_warm_start_rel": agree,
                      "round3_pipeline_plain_warm_start": {"oc_solve_ms": plain_ms, "gradient_ms": grad_ms, "iteration_ms": plain_ms + grad_ms,

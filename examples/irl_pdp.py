@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.3, help="initial parameter = true + U(-sigma/2, sigma/2)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--record", default="full", choices=["full", "primal"],
+                    help="what the gradient unit keeps for the next solve's predicted start: states, controls and multipliers (full) or states and controls only "
+                         "(primal: cheaper to write and read; enough where the multipliers move little per step, e.g. the quadrotor)")
     ap.add_argument("--demos", default=None, help="<name>_demos.mat in the reference's schema (default: the stored demos of --system)")
     a = ap.parse_args()
 
@@ -80,9 +83,9 @@ def main():
         if not bool(sol["converged"].all()):
             print("iter %5d  warning: %d of %d OC solves did not converge" % (k, int((~sol["converged"]).sum()), demo_x.shape[0]))
         warm = {key: sol[key] for key in ("state", "control", "costate")}
-        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"], want_predict_record=fused)
+        out = oc.pdp_grad_batch(sol["control"], theta, demo_x, demo_u, state_traj=sol["state"], costate_traj=sol["costate"], want_predict_record=(("primal" if a.record == "primal" else True) if fused else False))
         if fused:
-            predict, theta_prev = {"record": out["predict_record"]}, theta.copy()
+            predict, theta_prev = {"record": out["predict_record"], "primal": a.record == "primal"}, theta.copy()
         if int(out["status"].sum()) != 0:
             print("iter %5d  warning: Riccati sweep reported numerical trouble on %d trajectories" % (k, int((out["status"] != 0).sum())))
         loss = float(out["loss"].mean())

@@ -220,10 +220,12 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                                      parameter - for the step opts.dtheta:  x + X dtheta, u + U dtheta, lam_t + P_{t+1} X_{t+1} dtheta + W_{t+1} dtheta  with the outputs
                                      dxdp, dudp, riccati of pdp_oc_pdp_grad_sens_batched at that solution (what pdp_oc_predict_batched computes, applied while the kernel
                                      loads the point: no extra launch, no copy).  riccati may be NULL: multipliers as they are */
+#define PDP_MS_PREDICT_PRIMAL 32  /* opts.flags, with PDP_MS_PREDICT and opts.predict_record: states and controls only - the multipliers stay as they are and the P | W part
+                                     of the record is not read (it need not have been written: PDP_OC_RECORD_PRIMAL) */
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;
-    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT */
+    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT, PDP_MS_PREDICT_PRIMAL */
     int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
     int dtheta_bstride;        /* PDP_MS_PREDICT: dtheta [B][p] (stride p) or shared [p] (stride 0) ... */
     const double* dtheta;
@@ -251,6 +253,8 @@ int pdp_oc_solve_ms_batched(int B, int T, const double* x0, const double* theta,
  *          status [B].  workspace: pdp_oc_pdp_workspace_bytes(B,T). */
 #define PDP_OC_GIVEN_TRAJ 1
 #define PDP_OC_PACKED 2 /* grad is [B][p + 1]: gradient and, in the last column, the loss (the row the multi-GPU iteration all-gathers) */
+#define PDP_OC_RECORD_PRIMAL 4 /* pdp_oc_pdp_grad_sens_batched: only the X | U part of sens->predict_record is written (same stride; the P | W part is left untouched) -
+                                  the record of a prediction of states and controls only (PDP_MS_PREDICT_PRIMAL), 5 instead of 13 stores per stage */
 int64_t pdp_oc_pdp_workspace_bytes(int B, int T);
 int pdp_oc_pdp_grad_batched(int B, int T, int flags, const double* x0, const double* u, const double* theta,
                             int theta_bstride, const double* demo_x, const double* demo_u, double* x, double* lam,

@@ -21,6 +21,12 @@
 #pragma once
 #include "pdp_model_kernels.h"
 
+#ifndef PDP_F3_GAIN_AHEAD
+#define PDP_F3_GAIN_AHEAD 3         // forward sweep: the feedback gains of step t + PDP_F3_GAIN_AHEAD are requested during step t (1, 2 or 3; profiles/r04_fused3_attempts.txt)
+#endif
+#ifndef PDP_F3_ROLLOUT_LANES
+#define PDP_F3_ROLLOUT_LANES 0      // 1: the rollout parks x_{t+1} in lane t and stores blocks of 64 steps (see the rollout loop)
+#endif
 #ifndef PDP_F3_SYM_EVERY
 #define PDP_F3_SYM_EVERY 1          // P <- (P + P')/2 every k-th backward step of a group of U.  ONLY 1 IS CORRECT: k = 2 / 4 exist to reproduce profiles/r03_fused3_sym_every.txt
                                     // (2 - 4 % faster, gradient wrong in the 5th - 9th digit: one unsymmetrised step already lets the skew rounding error of P through)
@@ -241,6 +247,39 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
             double un[NU];
 #pragma unroll
             for (int i = 0; i < NU; ++i) un[i] = us[i];
+#if PDP_F3_ROLLOUT_LANES
+            // x_{t+1} is parked in LANE (t mod 64) of a register set (2 NX v_cndmask_b32 per step) and blocks of 64 steps go to the API output with NX / 2 stores of
+            // full lanes - against NX / 2 stores PER STEP that carry one live lane each and still occupy the address / data path for ~28 cycles (profiles/r04_fused3_attempts.txt)
+            double xs[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = 0.0;
+            for (int tb_ = 0; tb_ < T; tb_ += 64) {
+                const int nb = min(64, T - tb_);
+                for (int tl_ = 0; tl_ < nb; ++tl_) {
+                    const int t = tb_ + tl_, tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) { uc[i] = un[i]; un[i] = us[tn * NU + i]; }
+                    Mdl::dyn(xc, uc, th, pc, xn);
+                    const bool mine = lane == tl_;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; xs[i] = mine ? xn[i] : xs[i]; }
+                }
+                const unsigned vo = lane < nb ? (unsigned)(lane * NX) * 8u : 0x80000000u;
+                const unsigned so = (unsigned)((tb_ + 1) * NX) * 8u;
+#pragma unroll
+                for (int i = 0; i + 1 < NX; i += 2) {
+                    f3_u4 w;
+                    w.x = (unsigned)__double2loint(xs[i]); w.y = (unsigned)__double2hiint(xs[i]);
+                    w.z = (unsigned)__double2loint(xs[i + 1]); w.w = (unsigned)__double2hiint(xs[i + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rsX, vo + 8u * i, so, 0);
+                }
+                if constexpr (NX & 1) {
+                    f3_u2 w;
+                    w.x = (unsigned)__double2loint(xs[NX - 1]); w.y = (unsigned)__double2hiint(xs[NX - 1]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rsX, vo + 8u * (NX - 1), so, 0);
+                }
+            }
+#else
             for (int t = 0; t < T; ++t) {
                 const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
@@ -265,6 +304,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     }
                 }
             }
+#endif
 #pragma unroll
             for (int i = 0; i < NX; ++i) xTr[i] = xc[i];
         }
@@ -316,8 +356,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                                                                                  RIC && riccati ? (int)((int64_t)T * RSZ * 8) : 0, 0x00020000);
             // packed fp32 prediction record (PredRec, pdp_model_kernels.h)
             [[maybe_unused]] const PredMaps<Mdl> pm(lane);
-            [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
-                                                                                  RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
+            [[maybe_unused]] const bool precPW = RIC && prec && !(flags & PDP_OC_RECORD_PRIMAL);      // the P | W part of the record is wanted
+            [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(precPW ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                                  precPW ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
             constexpr int RB = 8 * BS;                           // bytes per row
             for (int g = 0; g < nchunk; ++g) {
                 int t0, cnt;
@@ -350,7 +391,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     d4 P_old;
                     if constexpr (RIC) {          // (uniform branches: a store to an absent output would be dropped by its size-0 resource, but still issued - 8 to 13 per step)
                         if (riccati) { f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2); }
-                        if (prec) { pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2); }
+                        if (precPW) { pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2); }
                     }
                     ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
@@ -396,8 +437,21 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
             // feedback gains of step t are fetched one step ahead (each lane re-reads exactly what it stored); K is read back transposed and
             // replicated in the four column blocks (operand form of the 4-row product U = -K X - k)
             const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
+#if PDP_F3_GAIN_AHEAD >= 2
+            // gains requested TWO or THREE steps ahead: four register sets, set s = gains of step (group base + s); sets 0 .. AHEAD - 1 are loaded when a group starts
+            d4 KTs[4], ks[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                if (s_ < PDP_F3_GAIN_AHEAD) {
+                    const int ts = s_ < T ? s_ : T - 1;
+                    KTs[s_] = -load_all<4>(gw + ts * GSZ, mKT);
+                    ks[s_] = -load_all<1>(gw + ts * GSZ + NX * NU, mIK);
+                } else { KTs[s_] = z; ks[s_] = z; }
+            }
+#else
             d4 KTn = -load_all<4>(gw, mKT);
             d4 kn = -load_all<1>(gw + NX * NU, mIK);
+#endif
             // sensitivity outputs of the RIC instantiation: buffer stores, an absent output is a resource of size 0
             [[maybe_unused]] const F3StoreMap mSX = f3_store_map(NX, NP, NP, M, lane), mSU = f3_store_map(NU, NP, NP, M, lane);
             [[maybe_unused]] const auto rsSX = __builtin_amdgcn_make_buffer_rsrc((void*)(dxdp ? dxdp + (int64_t)b * (T + 1) * NX * NP : ws_gain), 0,
@@ -418,7 +472,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                 Run3 rFT = run3_at(gFT, pb), rGT = run3_at(gGT, pb), rE = run3_at(gE, pb), rDX = run3_at(gDX, pb), rDU = run3_at(gDU, pb);
                 auto move_all = [&](int bytes) { move3(rFT, bytes); move3<1>(rGT, bytes); move3(rE, bytes); move3(rDX, bytes); move3<1>(rDU, bytes); };
                 auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
-                    const int t = t0 + tl, tnx = (t + 1 < T) ? t + 1 : t;
+#ifdef PDP_F3_EXP_GAINS_STEP0     // timing experiment only (wrong results): every step re-reads the gains of step 0 - always a cache hit: the forward loop without load latency
+                    const int t = t0 + tl, tnx = 0;
+#else
+                    const int t = t0 + tl, tnx = (t + PDP_F3_GAIN_AHEAD < T) ? t + PDP_F3_GAIN_AHEAD : T - 1;
+#endif
                     KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
                     knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
                     d4 FT = read3(rFT, imm);
@@ -444,8 +502,27 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     }
                 };
                 // groups of U steps with literal row offsets, the sensitivity tile and the prefetched gains alternating between two register sets
-                d4 Xb, KTb, kb;
+                d4 Xb;
                 int tl = 0;
+#if PDP_F3_GAIN_AHEAD >= 2
+                static_assert(U == 4 && PDP_F3_GAIN_AHEAD <= 3, "four gain sets rotate through a group of four steps");
+                constexpr int A = PDP_F3_GAIN_AHEAD;
+                for (; tl + U <= cnt; tl += U) {
+                    fstep(tl + 0, (unsigned)(0 * RF), X2, Xb, KTs[0], ks[0], KTs[(0 + A) & 3], ks[(0 + A) & 3]);
+                    fstep(tl + 1, (unsigned)(1 * RF), Xb, X2, KTs[1], ks[1], KTs[(1 + A) & 3], ks[(1 + A) & 3]);
+                    fstep(tl + 2, (unsigned)(2 * RF), X2, Xb, KTs[2], ks[2], KTs[(2 + A) & 3], ks[(2 + A) & 3]);
+                    fstep(tl + 3, (unsigned)(3 * RF), Xb, X2, KTs[3], ks[3], KTs[(3 + A) & 3], ks[(3 + A) & 3]);
+                    move_all(U * RF);
+                }
+                for (; tl < cnt; ++tl) {
+                    fstep(tl, 0u, X2, Xb, KTs[0], ks[0], KTs[A], ks[A]);
+                    X2 = Xb;
+#pragma unroll
+                    for (int s_ = 0; s_ < A; ++s_) { KTs[s_] = KTs[s_ + 1]; ks[s_] = ks[s_ + 1]; }
+                    move_all(RF);
+                }
+#else
+                d4 KTb, kb;
                 for (; tl + U <= cnt; tl += U) {
 #pragma unroll
                     for (int j = 0; j < U; ++j) {
@@ -455,6 +532,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                     move_all(U * RF);
                 }
                 for (; tl < cnt; ++tl) { fstep(tl, 0u, X2, Xb, KTn, kn, KTb, kb); X2 = Xb; KTn = KTb; kn = kb; move_all(RF); }
+#endif
                 f3_signal(fl + 3, g + 1);
             }
         }

@@ -296,6 +296,7 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
         if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
         const bool predict = (op->flags & PDP_MS_PREDICT) != 0;
+        if ((op->flags & PDP_MS_PREDICT_PRIMAL) && (!predict || !op->predict_record)) return PDP_E_ARG;
         if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || (!op->predict_record && (!op->dxdp || !op->dudp)))) return PDP_E_ARG;
         // PDP_MS_PREDICT is applied by the runner / evaluator kernel while it loads the point (dx parked in its LDS pool); where that kernel does not run, or the
         // horizon outgrows the pool, the prediction is a launch of its own in front of the solve (pdp_oc_predict_batched, in place on x, u, lam)
@@ -304,7 +305,8 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
             if (!predict) return 0;
             op1.flags &= ~PDP_MS_PREDICT;
             if constexpr (Mdl::NU + Mdl::NP <= 16) {
-                if (op->predict_record) return oc_predict_rec<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->predict_record, x, u, lam, st);
+                if (op->predict_record)
+                    return oc_predict_rec<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->predict_record, x, u, (op->flags & PDP_MS_PREDICT_PRIMAL) ? nullptr : lam, st);
                 return oc_predict<Mdl>(B, T, op->dtheta, op->dtheta_bstride, op->dxdp, op->dudp, op->riccati, x, u, op->riccati ? lam : nullptr, st);
             } else return PDP_E_SIZE;
         };

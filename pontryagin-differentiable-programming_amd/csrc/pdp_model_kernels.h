@@ -765,8 +765,9 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         [[maybe_unused]] double* rw = (RIC && riccati) ? riccati + (int64_t)b * T * RSZ : nullptr;
         // prediction record (RIC, fp32, see PredRec): range-checked buffer stores, a NULL record is a resource of size 0
         [[maybe_unused]] const PredMaps<Mdl> pm(lane);
-        [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(RIC && prec ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
-                                                                              RIC && prec ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
+        [[maybe_unused]] const bool precPW = RIC && prec && !(flags & PDP_OC_RECORD_PRIMAL);      // (PDP_OC_RECORD_PRIMAL: the P | W stores go to a resource of size 0)
+        [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(precPW ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
+                                                                              precPW ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
         Gather gGTb;                                      // G' (m x n, rows 0..3): left operand of the rank-m products G K and G k
         make_gather(gGTb, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (CLF && r < M && c < NX) ? codeA(1, c * NU + r) : -1; });
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;

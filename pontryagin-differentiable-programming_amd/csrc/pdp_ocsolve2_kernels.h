@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // (X, U and the Riccati record of the gradient unit at that solution: pdp_oc_pdp_grad_sens_batched; the same numbers as pdp_oc_predict_batched, applied
         // here so that an IRL iteration needs neither another launch nor a copy of the trajectory).  dx is parked in the still unused pool for the multiplier part.
         const float* rec = (warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta) ? op.predict_record : nullptr;      // the packed fp32 record (PredRec) takes precedence
+        const bool recp = rec && (op.flags & PDP_MS_PREDICT_PRIMAL) != 0;
         const bool pred = !rec && warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
         const bool predl = pred && op.riccati != nullptr;
         {
@@ -397,12 +398,27 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 for (int t0 = 0; t0 < T; t0 += SB) {
                     const int nst = min(SB, T - t0), nd = nst * R::SIZE;
                     const float* s_ = rec + ((int64_t)b * T + t0) * R::SIZE;
+                    if (recp) {      // PDP_MS_PREDICT_PRIMAL: the X | U part of every stage only (R::P floats of R::SIZE), to the same places of the staging block
+                        constexpr int NQP = (SB * R::P + 63) / 64;
+                        float v[NQP];
+                        int at[NQP];
+#pragma unroll
+                        for (int k = 0; k < NQP; ++k) {
+                            const int idx = lane + 64 * k, s = idx / R::P;
+                            at[k] = s * R::SIZE + (idx - s * R::P);
+                            v[k] = s_[idx < nst * R::P ? at[k] : 0];
+                        }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < NQP; ++k) { if (lane + 64 * k < SB * R::P) stage[at[k]] = v[k]; }
+                    } else {
                     float v[NQ];
 #pragma unroll
                     for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; v[k] = s_[idx < nd ? idx : 0]; }
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; if (idx < SB * R::SIZE) stage[idx] = v[k]; }
+                    }
                     wave_lds_sync();
                     const bool live = lane < nst * NX;
                     const int t = t0 + (live ? sg : 0);
@@ -423,10 +439,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     wave_lds_sync();
                     if (live) {
                         double dl = 0.0;
+                        if (!recp) {
 #pragma unroll
-                        for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
+                            for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                            for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                        }
                         s0[OL + i * TS + t] = lb[t * NX + i] + dl;
                     }
                     wave_lds_sync();

@@ -391,6 +391,8 @@ class ModelLib:
                 assert keep[1].shape == (B, T + 1, self.n, self.p) and keep[2].shape == (B, T, self.m, self.p)
                 opts.dxdp, opts.dudp = keep[1].data_ptr(), keep[2].data_ptr()
                 opts.riccati = keep[3].data_ptr() if keep[3] is not None else None
+            if predict.get("primal"):                       # PDP_MS_PREDICT_PRIMAL: states and controls only (a record written with want_predict_record="primal" holds nothing else)
+                opts.flags |= 32
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}
@@ -448,7 +450,8 @@ class ModelLib:
         want_riccati (with want_sens: everything oc_predict needs): also the Riccati matrices of the auxiliary control system,
         out["riccati"] [B, T, n n + n p + 1] = P_{t+1} | W_{t+1} | one scratch word per stage (pdp_oc_pdp_grad_sens_batched).
         want_predict_record: out["predict_record"], float32 [B, T, 2 n p + m p + n (n + 1) / 2] - the same information packed in single precision, what an IRL loop
-        hands to the next oc_solve_ms(predict=dict(dtheta=..., record=...)) (2.4 times less memory traffic than the fp64 outputs)."""
+        hands to the next oc_solve_ms(predict=dict(dtheta=..., record=...)) (2.4 times less memory traffic than the fp64 outputs).  want_predict_record="primal"
+        (PDP_OC_RECORD_PRIMAL): only the X | U part of the record is written - for oc_solve_ms(predict=dict(..., primal=True)), the prediction of states and controls."""
         torch = torch_cuda()
         u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
         B, T = u.shape[0], u.shape[1]
@@ -482,6 +485,8 @@ class ModelLib:
         dudp = buf("dudp", (B, T, m, p)) if want_sens else None
         ric = buf("riccati", (B, T, int(self.lib.pdp_oc_riccati_doubles()))) if want_riccati else None
         prec = buf("predict_record", (B, T, int(self.lib.pdp_oc_predict_record_floats())), torch.float32) if want_predict_record else None
+        if want_predict_record == "primal":
+            flags |= 4
         nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
         ws = buf("ws", (max(nbytes, 8) // 8,))
         if want_riccati or want_predict_record:
@@ -518,13 +523,15 @@ class ModelLib:
             out["predict_record"] = prec
         return out
 
-    def oc_predict_from_record(self, x, u, lam, dtheta, record):
-        """oc_predict from the packed fp32 record (pdp_oc_predict_record_batched): new tensors (x, u, lam) + first-order change for the step dtheta"""
+    def oc_predict_from_record(self, x, u, lam, dtheta, record, primal=False):
+        """oc_predict from the packed fp32 record (pdp_oc_predict_record_batched): new tensors (x, u, lam) + first-order change for the step dtheta
+        (primal: states and controls only, lam is returned as it came)"""
         x, u, lam = dev(x).clone(), dev(u).clone(), dev(lam).clone()
         B, T = u.shape[0], u.shape[1]
         dth, dtb = self._theta(dtheta, B)
         assert record.dtype == torch_cuda().float32 and tuple(record.shape) == (B, T, int(self.lib.pdp_oc_predict_record_floats()))
-        check(self.lib.pdp_oc_predict_record_batched(B, T, ptr(dth), dtb, ptr(record), ptr(x), ptr(u), ptr(lam), current_stream_ptr()), "pdp_oc_predict_record_batched")
+        check(self.lib.pdp_oc_predict_record_batched(B, T, ptr(dth), dtb, ptr(record), ptr(x), ptr(u), None if primal else ptr(lam), current_stream_ptr()),
+              "pdp_oc_predict_record_batched")
         return x, u, lam
 
     def oc_predict(self, x, u, lam, dtheta, dxdp, dudp, riccati=None):

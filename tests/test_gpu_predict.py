@@ -237,3 +237,49 @@ def test_packed_fp32_prediction_record(golden_dir, margins, name, B):
         for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
             sc_ = max(1.0, np.abs(ref[kr]).max())
             assert np.abs(inl[k][i].cpu().numpy() - ref[kr]).max() <= 1e-9 * sc_ and np.abs(pre[k][i].cpu().numpy() - ref[kr]).max() <= 1e-9 * sc_
+
+
+@pytest.mark.parametrize("name,B", [("cartpole", 5), ("quadrotor", 3)])
+def test_primal_prediction_record(golden_dir, name, B):
+    """PDP_OC_RECORD_PRIMAL / PDP_MS_PREDICT_PRIMAL: the gradient unit writes only the X | U part of the record (bit for bit the full record's, the rest of the
+    buffer is left as it was), the solver started from it inside the launch starts where pdp_oc_predict_record_batched without multipliers puts it (same
+    iterations, same answer as the oracle from that point), and loss and gradient do not depend on the kind of record asked for."""
+    import torch
+    from oracle import ipopt_ms
+    d, oc, mdl = setup(golden_dir, name)
+    th = d["true_parameter"]
+    T = d["control"].shape[1]
+    n, m, p = oc.n, oc.m, oc.p
+    x0 = np.repeat(d["state"][:1, 0], B, axis=0)
+    x0[:, 1] += 0.01 * np.arange(B)
+    sol = solve_at(mdl, x0, th, T)
+    dem = (d["state"][:1].repeat(B, axis=0), d["control"][:1].repeat(B, axis=0))
+    full = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"], want_predict_record=True)
+    nrec = full["predict_record"].shape[2]
+    mark = torch.full((B, T, nrec), -7.0, dtype=torch.float32, device="cuda")
+    prim = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"], want_predict_record="primal", buffers={"predict_record": mark})
+    assert bool((prim["loss"] == full["loss"]).all()) and bool((prim["grad"] == full["grad"]).all())
+    rp, rf = prim["predict_record"].cpu().numpy(), full["predict_record"].cpu().numpy()
+    nxu = (n + m) * p
+    assert np.array_equal(rp[:, :, :nxu], rf[:, :, :nxu]) and (rp[:, :, nxu:] == -7.0).all()
+    rng = np.random.default_rng(11)
+    th1 = th[None] * (1 + 0.02 * rng.uniform(-1, 1, (B, p)))
+    dth = th1 - th[None]
+    xp, up, lp = mdl.oc_predict_from_record(sol["state"], sol["control"], sol["costate"], dth, prim["predict_record"], primal=True)
+    xf, uf, _ = mdl.oc_predict_from_record(sol["state"], sol["control"], sol["costate"], dth, full["predict_record"])
+    assert bool((xp == xf).all()) and bool((up == uf).all()) and bool((lp == sol["costate"]).all())
+    warm = (sol["state"], sol["control"], sol["costate"])
+    inl = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, record=prim["predict_record"], primal=True), log_rows=8)
+    pre = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(xp, up, lp), log_rows=8)
+    assert bool(inl["converged"].all()) and bool((inl["iterations"] == pre["iterations"]).all())
+    for k in ("state", "control", "costate", "cost"):
+        assert bool((inl[k] == pre[k]).all()), k                  # the same starting point, bit for bit: the same iterates
+    for i in range(min(B, 2)):
+        ref = ipopt_ms.solve(oc, x0[i], T, th1[i], tol=1e-10, warm=(xp[i].cpu().numpy(), up[i].cpu().numpy(), lp[i].cpu().numpy()))
+        assert int(inl["iterations"][i]) == ref["iterations"], (name, i)
+        for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+            assert np.abs(inl[k][i].cpu().numpy() - ref[kr]).max() <= 1e-9 * max(1.0, np.abs(ref[kr]).max())
+    # the flag without a record, or without PDP_MS_PREDICT, is an argument error
+    with pytest.raises(RuntimeError):
+        mdl.oc_solve_ms(x0, th1, T, warm=warm, predict=dict(dtheta=dth, dxdp=torch.zeros(B, T + 1, n, p, dtype=torch.float64, device="cuda"),
+                                                           dudp=torch.zeros(B, T, m, p, dtype=torch.float64, device="cuda"), primal=True))
