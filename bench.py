@@ -252,6 +252,34 @@ def other_configs(torch):
         it8 = sol8["iterations"].double()
         grad_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(sol["control"], theta1, demo["state"], demo["control"], x=sol["state"], lam=sol["costate"], buffers=bufs))
         grad_sens_ms = kinds[record_kind]["gradient_ms"]
+        # the LOOP as a user runs it (Examples/IRL/*/..._PDP.py: shared theta, theta <- theta - lr * mean gradient, lr = 1e-4 as in the reference's scripts), wall clock per
+        # iteration: driven from Python (launches, ctypes calls, allocations between the kernels) against one hipGraph replay per iteration (pdp_amd.irl.IRLLoop)
+        from pdp_amd.irl import IRLLoop
+        import time as _time
+        loop_res = None
+        try:
+            th_start = th_star + 0.05 if system == "cartpole" else th_star * (1 + 0.02 * np.cos(np.arange(th_star.size)))
+            loops = {}
+            for mode in ("eager", "graph"):
+                lp = IRLLoop(mdl, demo["state"], demo["control"], th_start, 1e-4, record=record_kind, max_steps=512)
+                lp.start()
+                if mode == "graph":
+                    lp.capture()
+                lp.run(10, graphed=(mode == "graph"))
+                torch.cuda.synchronize()
+                n_it = 100 if mode == "graph" else 40
+                t0_ = _time.perf_counter()
+                lp.run(n_it, graphed=(mode == "graph"))
+                torch.cuda.synchronize()
+                loops[mode] = (1e3 * (_time.perf_counter() - t0_) / n_it, lp.results())
+            rg = loops["graph"][1]
+            loop_res = {"ms_per_iteration_python_driven": loops["eager"][0], "ms_per_iteration_hipgraph_replay": loops["graph"][0],
+                        "traj_per_s_hipgraph_replay": B / (loops["graph"][0] * 1e-3), "learning_rate": 1e-4, "record": record_kind,
+                        "iterations_run": rg["iterations"], "unconverged_solves": rg["unconverged_solves"], "riccati_trouble": rg["riccati_trouble"],
+                        "loss_first_last": [float(rg["loss_trace"][0]), float(rg["loss_trace"][-1])],
+                        "note": "wall clock around n iterations + one synchronisation; shared theta moved by the mean gradient (steps of ~1e-4 relative: one Newton iteration per solve)"}
+        except Exception as e_:          # a side measurement must not cost the headline
+            loop_res = {"error": repr(e_)[:300]}
         it, itc, itp = sol["iterations"].double(), demo["iterations"].double(), plain["iterations"].double()
         agree = max(float((sol[k] - plain[k]).abs().max()) / max(1.0, float(plain[k].abs().max())) for k in ("state", "control", "costate"))
         entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
@@ -260,7 +288,7 @@ def other_configs(torch):
                    "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit "
                    "(it has none for the solve)",
               extra={"oc_solve_ms": solve_ms, "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
-                     "prediction_record_kind": record_kind, "prediction_includes_multipliers": record_kind == "full", "pipelines_by_record_kind": kinds,
+                     "irl_loop_wall_clock": loop_res, "prediction_record_kind": record_kind, "prediction_includes_multipliers": record_kind == "full", "pipelines_by_record_kind": kinds,
                      "prediction_record_bytes": int(sens0["predict_record"].numel() * 4) if record_kind == "full" else int(B * T * (mdl.n + mdl.m) * mdl.p * 4), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
                      "solution_agrees_with_plain_warm_start_rel": agree,

@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--record", default="full", choices=["full", "primal"],
                     help="what the gradient unit keeps for the next solve's predicted start: states, controls and multipliers (full) or states and controls only "
                          "(primal: cheaper to write and read; enough where the multipliers move little per step, e.g. the quadrotor)")
+    ap.add_argument("--graph", action="store_true",
+                    help="keep the loop on the device and replay each iteration as one hipGraph (pdp_amd.irl.IRLLoop): no host work per iteration, traces written by the graph")
     ap.add_argument("--demos", default=None, help="<name>_demos.mat in the reference's schema (default: the stored demos of --system)")
     a = ap.parse_args()
 
@@ -73,6 +75,22 @@ def main():
     warm, predict, theta_prev = None, None, None
     fused = oc.model().n <= 16 and oc.model().m <= 4 and oc.model().m + oc.model().p <= 16      # the kernels that keep the sensitivities
     t0 = time.time()
+    if a.graph:
+        assert fused, "--graph needs the fused kernels (n <= 16, m <= 4, m + p <= 16)"
+        from pdp_amd.irl import IRLLoop
+        loop = IRLLoop(oc.model(), demo_x, demo_u, theta, a.lr, record=a.record, max_steps=a.iters + 8)
+        loop.run(a.iters)
+        r = loop.results()
+        loss_trace, parameter_trace = list(r["loss_trace"][:a.iters]), list(r["parameter_trace"][:a.iters])
+        if r["unconverged_solves"] or r["riccati_trouble"]:
+            print("warning: %d OC solves did not converge, %d trajectories with numerical trouble in the Riccati sweep" % (r["unconverged_solves"], r["riccati_trouble"]))
+        for k in range(0, a.iters, max(1, a.iters // 10)):
+            print("iter %5d  loss %.6e  |theta - theta*| %.4f" % (k, loss_trace[k], np.abs(parameter_trace[k] - true_parameter).max()))
+        save = {"trail_no": 0, "loss_trace": loss_trace, "parameter_trace": parameter_trace, "learning_rate": a.lr, "time_passed": time.time() - t0}
+        if a.out:
+            sio.savemat(a.out, {"results": save})
+        print("done: %d iterations x %d demos in %.2f s, one hipGraph per iteration  (loss %.4e -> %.4e)" % (a.iters, demo_x.shape[0], save["time_passed"], loss_trace[0], loss_trace[-1]))
+        return loss_trace
     for k in range(a.iters):
         # first iterate: cold, the reference's all-zero guess (PDP.py:155,166).  Afterwards the multiple-shooting solver starts from the previous solution moved
         # along its own sensitivities, (x, u, lambda)_{k-1} + (X, U, Lambda)_{k-1} (theta_k - theta_{k-1}) - the auxiliary control system the gradient step has just

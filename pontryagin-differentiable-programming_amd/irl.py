@@ -1,0 +1,115 @@
+"""The reference's IRL loop kept on the device and replayed as ONE hipGraph per iteration.
+
+Reference loop (Examples/IRL/cartpole/cartpole_PDP.py:52-80, Examples/IRL/quadrotor/uav_PDP.py:52-62): at the current parameter solve every demonstration's OC problem
+(`OCSys.ocSolver`), differentiate the solutions (`getAuxSys` + `lqrSolver`), chain rule against the demonstrations, `theta <- theta - lr * mean gradient`.  Here an
+iteration is two kernels - the multiple-shooting solve from the first-order prediction of its solution (pdp_oc_solve_ms_batched with PDP_MS_PREDICT, in place on the previous
+solution) and the fused gradient unit that also leaves the prediction record for the next solve (pdp_oc_pdp_grad_sens_batched) - and four small tensor operations for the
+parameter update.  Driven from Python, the launches, ctypes calls and allocations of one iteration cost more than the 0.17 - 0.31 ms its kernels run; `IRLLoop.capture()`
+records the iteration once (torch.cuda.CUDAGraph = hipGraph on ROCm: every buffer, the parameter vector, the step and the traces live at fixed device addresses) and
+`IRLLoop.run(n)` replays it n times without the host in the loop.  Loss and parameter traces are written by the graph itself into device arrays (a device-side counter
+indexes them).  Nothing in the loop waits for the host; convergence flags of the solves are accumulated on the device and read once at the end.
+"""
+import numpy as np
+
+from . import runtime as rt
+
+
+class IRLLoop:
+    """mdl: runtime.ModelLib of an OC model (PDP.OCSys.model() or zoo.get(system, "irl")); demo_x [B, T+1, n], demo_u [B, T, m]: the demonstrations; theta0 [p]: the initial
+    parameter (shared by all demonstrations, as in the reference); lr: learning rate; record: "full" (states, controls and multipliers are predicted) or "primal"
+    (states and controls only: cheaper, enough where the multipliers move little per step); max_steps: length of the on-device traces."""
+
+    def __init__(self, mdl, demo_x, demo_u, theta0, lr, record="full", tol=1e-10, max_iter=300, max_steps=100000):
+        torch = rt.torch_cuda()
+        assert record in ("full", "primal")
+        self.mdl, self.lr, self.tol, self.max_iter, self.primal = mdl, float(lr), float(tol), int(max_iter), record == "primal"
+        self.demo_x, self.demo_u = rt.dev(demo_x), rt.dev(demo_u)
+        self.B, self.T = int(self.demo_u.shape[0]), int(self.demo_u.shape[1])
+        assert self.demo_x.shape == (self.B, self.T + 1, mdl.n) and self.demo_u.shape == (self.B, self.T, mdl.m)
+        f64 = dict(dtype=torch.float64, device="cuda")
+        self.x0 = self.demo_x[:, 0].contiguous()
+        self.theta = rt.dev(np.asarray(theta0, dtype=float).reshape(-1)).clone()
+        assert self.theta.numel() == mdl.p
+        self.dtheta = torch.zeros(mdl.p, **f64)
+        self.max_steps = int(max_steps)
+        self.loss_trace = torch.zeros(self.max_steps, **f64)
+        self.parameter_trace = torch.zeros(self.max_steps, mdl.p, **f64)
+        self.k = torch.zeros(1, dtype=torch.int64, device="cuda")                  # iterations done (device-side: the graph indexes the traces with it)
+        self.unconverged = torch.zeros(1, dtype=torch.int64, device="cuda")        # OC solves that did not converge, summed over the iterations
+        self.trouble = torch.zeros(1, dtype=torch.int64, device="cuda")            # trajectories on which the Riccati sweep reported numerical trouble
+        self.sol = None                                                            # (x, u, lam) of the current parameter: the solver works in place on them
+        self.bufs = {}                                                             # outputs of the gradient unit (fixed addresses)
+        self.graph = None
+        self.steps_done = 0
+
+    # ---- one iteration, no host synchronisation anywhere
+    def _update(self, out, conv):
+        torch = rt.torch_cuda()
+        k = self.k
+        self.loss_trace.index_copy_(0, k, out["loss"].mean().reshape(1))
+        torch.mul(out["grad"].mean(dim=0), -self.lr, out=self.dtheta)              # theta_{k+1} - theta_k: also the step the next solve's prediction is made for
+        self.theta.add_(self.dtheta)
+        self.parameter_trace.index_copy_(0, k, self.theta.reshape(1, -1))
+        self.unconverged.add_((~conv).sum())
+        self.trouble.add_((out["status"] != 0).sum())
+        k.add_(1)
+
+    def _gradient(self):
+        x, u, lam = self.sol
+        return self.mdl.oc_pdp_grad(u, self.theta, self.demo_x, self.demo_u, x=x, lam=lam, want_predict_record="primal" if self.primal else True, buffers=self.bufs)
+
+    def start(self):
+        """first iteration: cold solve from the reference's all-zero guess (PDP.py:155,166), gradient, update"""
+        s = self.mdl.oc_solve_ms(self.x0, self.theta, self.T, tol=self.tol, max_iter=self.max_iter)
+        self.sol = (s["state"], s["control"], s["costate"])
+        self._update(self._gradient(), s["converged"])
+        self.steps_done = 1
+
+    def step(self):
+        """one warm iteration: solve at the moved parameter from the predicted start (in place), gradient + record, update"""
+        s = self.mdl.oc_solve_ms(self.x0, self.theta, self.T, tol=self.tol, max_iter=self.max_iter, warm=self.sol, consume_warm=True,
+                                 predict=dict(dtheta=self.dtheta, record=self.bufs["predict_record"], primal=self.primal))
+        self._update(self._gradient(), s["converged"])
+
+    def capture(self, warmup=2):
+        """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for)"""
+        torch = rt.torch_cuda()
+        if self.sol is None:
+            self.start()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step()
+                self.steps_done += 1
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step()
+        self.steps_done += 0            # (capturing executes nothing)
+        return self
+
+    def run(self, n, graphed=True):
+        """n more iterations: graph replays (capture() first) or eager steps.  Returns the number of iterations done so far."""
+        if self.sol is None:
+            self.start()
+            n -= 1
+        assert self.steps_done + n <= self.max_steps, "traces are full: raise max_steps"
+        if graphed:
+            if self.graph is None:
+                before = self.steps_done
+                self.capture()
+                n -= self.steps_done - before
+            for _ in range(max(n, 0)):
+                self.graph.replay()
+        else:
+            for _ in range(max(n, 0)):
+                self.step()
+        self.steps_done += max(n, 0)
+        return self.steps_done
+
+    def results(self):
+        """host copies (one synchronisation): the reference's result fields + the health counters"""
+        k = int(self.k.item())
+        return {"loss_trace": self.loss_trace[:k].cpu().numpy(), "parameter_trace": self.parameter_trace[:k].cpu().numpy(), "learning_rate": self.lr,
+                "iterations": k, "unconverged_solves": int(self.unconverged.item()), "riccati_trouble": int(self.trouble.item())}
