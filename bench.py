@@ -276,6 +276,7 @@ def other_configs(torch):
             loop_res = {"ms_per_iteration_python_driven": loops["eager"][0], "ms_per_iteration_hipgraph_replay": loops["graph"][0],
                         "traj_per_s_hipgraph_replay": B / (loops["graph"][0] * 1e-3), "learning_rate": 1e-4, "record": record_kind,
                         "iterations_run": rg["iterations"], "unconverged_solves": rg["unconverged_solves"], "riccati_trouble": rg["riccati_trouble"],
+                        "newton_iterations_per_solve_incl_the_cold_first": rg["newton_iterations_per_solve"],
                         "loss_first_last": [float(rg["loss_trace"][0]), float(rg["loss_trace"][-1])],
                         "note": "wall clock around n iterations + one synchronisation; shared theta moved by the mean gradient (steps of ~1e-4 relative: one Newton iteration per solve)"}
         except Exception as e_:          # a side measurement must not cost the headline

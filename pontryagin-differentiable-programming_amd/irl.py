@@ -37,15 +37,17 @@ class IRLLoop:
         self.k = torch.zeros(1, dtype=torch.int64, device="cuda")                  # iterations done (device-side: the graph indexes the traces with it)
         self.unconverged = torch.zeros(1, dtype=torch.int64, device="cuda")        # OC solves that did not converge, summed over the iterations
         self.trouble = torch.zeros(1, dtype=torch.int64, device="cuda")            # trajectories on which the Riccati sweep reported numerical trouble
+        self.newton = torch.zeros(1, dtype=torch.int64, device="cuda")             # Newton iterations of all OC solves (the cold ones of start() included)
         self.sol = None                                                            # (x, u, lam) of the current parameter: the solver works in place on them
         self.bufs = {}                                                             # outputs of the gradient unit (fixed addresses)
         self.graph = None
         self.steps_done = 0
 
     # ---- one iteration, no host synchronisation anywhere
-    def _update(self, out, conv):
+    def _update(self, out, sol):
         torch = rt.torch_cuda()
-        k = self.k
+        k, conv = self.k, sol["converged"]
+        self.newton.add_(sol["iterations"].sum())
         self.loss_trace.index_copy_(0, k, out["loss"].mean().reshape(1))
         torch.mul(out["grad"].mean(dim=0), -self.lr, out=self.dtheta)              # theta_{k+1} - theta_k: also the step the next solve's prediction is made for
         self.theta.add_(self.dtheta)
@@ -62,14 +64,14 @@ class IRLLoop:
         """first iteration: cold solve from the reference's all-zero guess (PDP.py:155,166), gradient, update"""
         s = self.mdl.oc_solve_ms(self.x0, self.theta, self.T, tol=self.tol, max_iter=self.max_iter)
         self.sol = (s["state"], s["control"], s["costate"])
-        self._update(self._gradient(), s["converged"])
+        self._update(self._gradient(), s)
         self.steps_done = 1
 
     def step(self):
         """one warm iteration: solve at the moved parameter from the predicted start (in place), gradient + record, update"""
         s = self.mdl.oc_solve_ms(self.x0, self.theta, self.T, tol=self.tol, max_iter=self.max_iter, warm=self.sol, consume_warm=True,
                                  predict=dict(dtheta=self.dtheta, record=self.bufs["predict_record"], primal=self.primal))
-        self._update(self._gradient(), s["converged"])
+        self._update(self._gradient(), s)
 
     def capture(self, warmup=2):
         """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for)"""
@@ -112,4 +114,5 @@ class IRLLoop:
         """host copies (one synchronisation): the reference's result fields + the health counters"""
         k = int(self.k.item())
         return {"loss_trace": self.loss_trace[:k].cpu().numpy(), "parameter_trace": self.parameter_trace[:k].cpu().numpy(), "learning_rate": self.lr,
-                "iterations": k, "unconverged_solves": int(self.unconverged.item()), "riccati_trouble": int(self.trouble.item())}
+                "iterations": k, "unconverged_solves": int(self.unconverged.item()), "riccati_trouble": int(self.trouble.item()),
+                "newton_iterations_per_solve": float(self.newton.item()) / max(1, k * self.B)}

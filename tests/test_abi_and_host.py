@@ -298,3 +298,18 @@ def test_warp_and_recovery_matrix_internals_on_the_class_surface(golden_dir):
     ws = np.stack([g["state"][t] for t in cp.time_grid])
     aux = cp.warp_getAuxSys(ws, np.zeros((cp.whorizon, 1)), np.zeros(cp.n_auxvar))
     assert len(aux["wdynF"]) == cp.whorizon and aux["wdynF"][0].shape == (2, 2) and aux["wdUe"][0].shape == (1, cp.n_auxvar) and np.all(aux["wdUx"][0] == 0)
+
+
+def test_product_path_fails_loudly_without_a_gpu(built):
+    """no CPU fallback anywhere on the product path: without a visible GPU the device-resident IRL loop (and every ModelLib call under it) raises instead of computing
+    something somewhere else"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from pdp_amd import zoo
+    from pdp_amd.irl import IRLLoop
+    mdl = zoo.get("cartpole", "irl")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        IRLLoop(mdl, np.zeros((2, 6, 4)), np.zeros((2, 5, 1)), np.ones(7), 1e-4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mdl.oc_solve_ms(np.zeros((2, 4)), np.ones(7), 5)
