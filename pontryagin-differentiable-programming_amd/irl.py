@@ -4,10 +4,11 @@ Reference loop (Examples/IRL/cartpole/cartpole_PDP.py:52-80, Examples/IRL/quadro
 (`OCSys.ocSolver`), differentiate the solutions (`getAuxSys` + `lqrSolver`), chain rule against the demonstrations, `theta <- theta - lr * mean gradient`.  Here an
 iteration is two kernels - the multiple-shooting solve from the first-order prediction of its solution (pdp_oc_solve_ms_batched with PDP_MS_PREDICT, in place on the previous
 solution) and the fused gradient unit that also leaves the prediction record for the next solve (pdp_oc_pdp_grad_sens_batched) - and four small tensor operations for the
-parameter update.  Driven from Python, the launches, ctypes calls and allocations of one iteration cost more than the 0.17 - 0.31 ms its kernels run; `IRLLoop.capture()`
-records the iteration once (torch.cuda.CUDAGraph = hipGraph on ROCm: every buffer, the parameter vector, the step and the traces live at fixed device addresses) and
-`IRLLoop.run(n)` replays it n times without the host in the loop.  Loss and parameter traces are written by the graph itself into device arrays (a device-side counter
-indexes them).  Nothing in the loop waits for the host; convergence flags of the solves are accumulated on the device and read once at the end.
+parameter update.  Nothing in the loop waits for the host: loss and parameter traces are written into device arrays (a device-side counter indexes them), convergence
+flags and iteration counts of the solves are accumulated on the device and read once at the end.  `IRLLoop.capture()` records the iteration once (torch.cuda.CUDAGraph =
+hipGraph on ROCm: every buffer, the parameter vector, the step and the traces live at fixed device addresses) and `IRLLoop.run(n)` replays it n times.  Measured
+(bench.py, `irl_loop_wall_clock`): with no synchronisation in the loop the Python-driven iterations already keep the GPU busy where the kernels are long (C3: 0.27 ms per
+iteration either way); the graph pays where they are short (C2: 0.149 -> 0.123 ms).
 """
 import numpy as np
 
