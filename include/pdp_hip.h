@@ -346,6 +346,12 @@ int pdp_sysid_auxsys_batched(int B, int T, const double* x, const double* u, con
  * reference); the caller averages over the batch (PDP.py:1293-1294). */
 int pdp_sysid_step_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int theta_bstride,
                            double* loss, double* grad, void* stream);
+/* The same with a caller-owned workspace of pdp_sysid_step_workspace_bytes(B, T) bytes (0 for batches that do not use one): batches with more than two trajectories per
+ * SIMD roll their trajectories out beforehand with one LANE per trajectory (the pass behind pdp_sysid_integrate_batched, into the workspace [B][T+1][n]) and run the fused
+ * kernel on them - inside the fused kernel a rollout occupies a whole wavefront per trajectory.  Same results. */
+int64_t pdp_sysid_step_workspace_bytes(int B, int T);
+int pdp_sysid_step_ws_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int theta_bstride,
+                              double* loss, double* grad, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -484,7 +484,7 @@ int sysid_integrate(int B, int T, const double* x0, const double* u, const doubl
     if constexpr (Mdl::KIND == PDP_KIND_SYSID) {
         if (B <= 0 || T <= 0 || !x0 || !u || !th || !x) return PDP_E_ARG;
         PDP_CLEAR();
-        hipLaunchKernelGGL((sysid_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x0, u, th, tb, x);
+        hipLaunchKernelGGL((sysid_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, x0, (int)Mdl::NX, u, th, tb, x);
         return launched();
     } else { return PDP_E_MODE; }
 }
@@ -498,10 +498,29 @@ int sysid_auxsys(int B, int T, const double* x, const double* u, const double* t
         return launched();
     } else { return PDP_E_MODE; }
 }
+// Batches from which SysID.step rolls the trajectories out beforehand, one LANE per trajectory (sysid_integrate_kernel into the caller's workspace), and runs the fused
+// kernel on the given trajectories: more than two trajectories per SIMD (profiles/r04_rollout_prepass.txt).  PDP_SYSID_PREPASS=0 / 1 forces it off / on.
+inline bool sysid_prepass(int B) {
+    static const int env = [] { const char* e = std::getenv("PDP_SYSID_PREPASS"); return e ? std::atoi(e) : -1; }();
+    return env >= 0 ? env != 0 : B > 8 * device_cu_count();
+}
 template <class Mdl>
-int sysid_step(int B, int T, const double* u, const double* xobs, const double* th, int tb, double* loss, double* grad, void* st) {
+int64_t sysid_step_ws_bytes(int B, int T) {
+    if constexpr (Mdl::KIND == PDP_KIND_SYSID) return sysid_prepass(B) ? (int64_t)B * (T + 1) * Mdl::NX * (int64_t)sizeof(double) : 0;
+    else return 0;
+}
+template <class Mdl>
+int sysid_step(int B, int T, const double* u, const double* xobs, const double* th, int tb, double* loss, double* grad, void* ws, int64_t wsb, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_SYSID && Mdl::NX <= 16 && Mdl::NP <= 64) {
         if (B <= 0 || T <= 0 || !u || !xobs || !th || !loss || !grad) return PDP_E_ARG;
+        const double* xgiven = nullptr;
+        if (ws && sysid_prepass(B)) {           // (no workspace: the kernel rolls out itself, whatever the batch)
+            if (wsb < sysid_step_ws_bytes<Mdl>(B, T)) return PDP_E_ARG;
+            PDP_CLEAR();
+            hipLaunchKernelGGL((sysid_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, xobs, (int)((T + 1) * Mdl::NX), u, th, tb, (double*)ws);
+            if (const int rc = launched(); rc != 0) return rc;
+            xgiven = (const double*)ws;
+        }
         constexpr int NT = (Mdl::NP + 15) / 16;
         static const int rows_env = [] { const char* e = std::getenv("PDP_SYSID_ROWS"); return e ? std::atoi(e) : 0; }();
         const int rows = rows_env > 0 ? (rows_env < Mdl::CHUNK ? rows_env : Mdl::CHUNK) : sysid_rows<Mdl>(B, T, device_cu_count());
@@ -511,7 +530,7 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
         static const int variant = [] { const char* e = std::getenv("PDP_SYSID_VARIANT"); return e ? std::atoi(e) : 2; }();
         // the pair pays while SIMDs would idle (B = 256, T = 200: 0.105 -> 0.072 ms); once every SIMD has a trajectory the two waves only share what one had
         // (B = 1024: 0.0667 against 0.0685 ms, profiles/r03_pair_pipeline.txt) - the one-wave kernel stays for those batches
-        if (variant == 2 && B <= 2 * device_cu_count()) {
+        if (variant == 2 && B <= 2 * device_cu_count() && !xgiven) {
             const int cus = device_cu_count(), slice = sysid_slice<Mdl>(T);
             const int tpw = B <= cus ? 1 : 2;
             const int lds2 = slice * tpw * (int)sizeof(double);
@@ -526,7 +545,7 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
         }
         (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
-        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows);
+        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows, xgiven);
         return launched();
     } else { return Mdl::KIND == PDP_KIND_SYSID ? PDP_E_SIZE : PDP_E_MODE; }
 }
@@ -625,7 +644,12 @@ int pdp_sysid_auxsys_batched(int B, int T, const double* x, const double* u, con
     return sysid_auxsys<PdpModel>(B, T, x, u, theta, tb, dynF, dynE, stream);
 }
 int pdp_sysid_step_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int tb, double* loss, double* grad, void* stream) {
-    return sysid_step<PdpModel>(B, T, u, x_obs, theta, tb, loss, grad, stream);
+    return sysid_step<PdpModel>(B, T, u, x_obs, theta, tb, loss, grad, nullptr, 0, stream);
+}
+int64_t pdp_sysid_step_workspace_bytes(int B, int T) { return sysid_step_ws_bytes<PdpModel>(B, T); }
+int pdp_sysid_step_ws_batched(int B, int T, const double* u, const double* x_obs, const double* theta, int tb, double* loss, double* grad, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    return sysid_step<PdpModel>(B, T, u, x_obs, theta, tb, loss, grad, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1673,8 +1673,8 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
 // SysID (PDP_KIND_SYSID)
 // ------------------------------------------------------------------------------------------------------
 template <class Mdl>
-__global__ void __launch_bounds__(64) sysid_integrate_kernel(int B, int T, const double* __restrict__ x0, const double* __restrict__ u, const double* __restrict__ theta,
-                                       int tb, double* __restrict__ x) {
+__global__ void __launch_bounds__(64) sysid_integrate_kernel(int B, int T, const double* __restrict__ x0, int x0_stride, const double* __restrict__ u,
+                                                              const double* __restrict__ theta, int tb, double* __restrict__ x) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -1682,12 +1682,19 @@ __global__ void __launch_bounds__(64) sysid_integrate_kernel(int B, int T, const
     load_theta<Mdl>(theta, b, tb, th);
     double pc[Mdl::NPC];
     Mdl::precompute(th, pc);
-    double xc[NX], xn[NX], uc[NU];
+    // lane = trajectory.  The controls of a lane are requested TWO steps ahead of their use: read inside the step they would put a round trip to memory (every lane in
+    // its own cache line) into the serial chain of each of the T steps.  x0_stride: NX (x0 [B][NX]) or (T + 1) NX (the initial states are the first rows of a
+    // trajectory array: SysID.step's batch_states[i][0], PDP.py:1269)
+    double xc[NX], xn[NX], uc[NU], u1[NU], u2[NU];
+    const double* ub = u + (int64_t)b * T * NU;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * NX + i]; x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)b * x0_stride + i]; x[(int64_t)b * (T + 1) * NX + i] = xc[i]; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { u1[i] = ub[i]; u2[i] = ub[(T > 1 ? 1 : 0) * NU + i]; }
     for (int t = 0; t < T; ++t) {
+        const int tn = t + 2 < T ? t + 2 : T - 1;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) uc[i] = u[((int64_t)b * T + t) * NU + i];
+        for (int i = 0; i < NU; ++i) { uc[i] = u1[i]; u1[i] = u2[i]; u2[i] = ub[tn * NU + i]; }
         Mdl::dyn(xc, uc, th, pc, xn);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { xc[i] = xn[i]; x[((int64_t)b * (T + 1) + t + 1) * NX + i] = xn[i]; }
@@ -1741,7 +1748,11 @@ __host__ inline int sysid_rows(int B, int T, int cus) {
 // Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
 template <class Mdl, int NT>
 __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const double* __restrict__ u, const double* __restrict__ xobs,
-                                                         const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad, int CH) {
+                                                         const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad, int CH,
+                                                         const double* __restrict__ xgiven) {
+    // xgiven [B][T+1][NX] (or NULL): the trajectory, rolled out beforehand by sysid_integrate_kernel with ONE LANE per trajectory - the mode for batches with several
+    // trajectories per SIMD: the rollout below runs one trajectory on all 64 lanes (the same value in every lane), which is the right thing while the SIMD has nothing
+    // else to do and 63/64 wasted once other trajectories wait for it (C5a's 8192 on one GPU: 8 rounds of a 26 us rollout against one 21 us pass for all of them)
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
     constexpr int NC = 1 + Mdl::PATH_NCONST, DLX = Mdl::PATH_NVAR, STRIDE = (Mdl::PATH_NVAR + NX) | 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1762,8 +1773,12 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     if (lane == 0) blk[0] = 0.0;
     for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
     for (int q = lane; q < T * NU; q += 64) us[q] = ub[q];
+    if (xgiven) {
+        const double* xg = xgiven + (int64_t)b * (T + 1) * NX;
+        for (int q = lane; q < (T + 1) * NX; q += 64) xs[q] = xg[q];
+    }
     __syncthreads();
-    {
+    if (!xgiven) {
         // rollout (uniform).  u_t comes from the LDS staging, requested one step ahead (read from global memory inside the loop every step waited for a round
         // trip to memory); x_{t+1} goes to the staging from lane 0 without a conditional block (cp_step_poly_kernel)
         double xc[NX], xn[NX], uc[NU], un[NU];

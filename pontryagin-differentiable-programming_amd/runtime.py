@@ -61,7 +61,8 @@ MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout
                  "pdp_oc_pdp_workspace_bytes", "pdp_oc_pdp_grad_batched", "pdp_oc_riccati_doubles", "pdp_oc_predict_record_floats", "pdp_oc_pdp_grad_sens_batched",
                  "pdp_oc_predict_batched", "pdp_oc_predict_record_batched",
                  "pdp_cp_integrate_batched", "pdp_cp_auxsys_batched",
-                 "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched"]
+                 "pdp_cp_step_workspace_bytes", "pdp_cp_step_batched", "pdp_sysid_integrate_batched", "pdp_sysid_auxsys_batched", "pdp_sysid_step_batched",
+                 "pdp_sysid_step_workspace_bytes", "pdp_sysid_step_ws_batched"]
 
 _core = None
 
@@ -251,6 +252,8 @@ _MODEL_SIGS = {
     "pdp_sysid_integrate_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP]),
     "pdp_sysid_auxsys_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pdp_sysid_step_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "pdp_sysid_step_workspace_bytes": (_I64, [_I, _I]),
+    "pdp_sysid_step_ws_batched": (_I, [_I, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I64, _VP]),
 }
 _models = {}
 
@@ -699,7 +702,11 @@ class ModelLib:
         th, tb = self._theta(theta, B)
         loss = torch.empty((B,), dtype=torch.float64, device="cuda")
         grad = torch.empty((B, self.p), dtype=torch.float64, device="cuda")
-        check(self.lib.pdp_sysid_step_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), current_stream_ptr()), "pdp_sysid_step_batched")
+        nbytes = int(self.lib.pdp_sysid_step_workspace_bytes(B, T))              # > 0: large batch, the trajectories are rolled out beforehand, one lane each
+        ws = getattr(self, "_sysid_ws", None) if nbytes > 0 else None
+        if nbytes > 0 and (ws is None or ws.numel() * 8 < nbytes):
+            ws = self._sysid_ws = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda")      # kept: an SGD loop calls this every step
+        check(self.lib.pdp_sysid_step_ws_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), ptr(ws), nbytes, current_stream_ptr()), "pdp_sysid_step_ws_batched")
         return loss, grad
 
 

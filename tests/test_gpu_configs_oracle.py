@@ -62,12 +62,19 @@ def test_C5a_quadrotor_sysid_T100_against_the_oracle(margins):
     T = 100
     th_star = np.array([1, 1, 1, 1, 0.4])
     theta = th_star + np.array([0.1, -0.05, 0.08, 0.03, -0.02])
-    for B in (1024, 256):
+    for B in (1024, 256, 8192):      # 8192 = C5a's total on ONE GPU: the batch is rolled out beforehand, one lane per trajectory (pdp_sysid_step_ws_batched)
         u = rng.uniform(-1, 1, (B, T, 4)) + 2.5
         x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (B, 1))
+        if B == 8192:
+            x0[:, :3] += rng.standard_normal((B, 3))
+            assert int(mdl.lib.pdp_sysid_step_workspace_bytes(B, T)) == B * (T + 1) * 13 * 8 and int(mdl.lib.pdp_sysid_step_workspace_bytes(1024, T)) == 0
         xobs = npy(mdl.sysid_integrate(x0, u, th_star))
         loss, grad = mdl.sysid_step(u, xobs, theta)
         L, G = npy(loss), npy(grad)
+        if B == 8192:               # the same trajectories in chunks that take the in-kernel rollout: the same numbers, bit for bit
+            for lo in (0, 3072, 7168):
+                l2, g2 = mdl.sysid_step(u[lo:lo + 1024], xobs[lo:lo + 1024], theta)
+                assert np.array_equal(npy(l2), L[lo:lo + 1024]) and np.array_equal(npy(g2), G[lo:lo + 1024])
         for i in (0, B // 2, B - 1):
             l, g = sid.step([u[i]], [xobs[i]], theta)
             margins.check("C5a SysID.step T=100 B=%d sample %d vs oracle: loss (relative)" % (B, i), abs(L[i] - l) / abs(l), 1e-11)
