@@ -366,7 +366,43 @@ int cp_step_launch(int B, int gy, int T, const pdp_policy* pol, int p, const dou
     if (lds > 150 * 1024) return PDP_E_SIZE;
     (void)hipFuncSetAttribute((const void*)cp_step_poly_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PDP_CLEAR();
-    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B, gy), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u);
+    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT>), dim3(B, gy), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, 0, (const double*)nullptr,
+                       (const double*)nullptr, (const double*)nullptr);
+    return launched();
+}
+// Batches from which ControlPlanning.step with the Lagrange policy rolls out beforehand, one LANE per trajectory, and runs the sensitivity kernel on the given trajectories
+// (cp_poly_rollout_lanes_kernel + cp_step_poly_kernel<.., GIVEN>): more than two trajectories per SIMD, like SysID.step.  PDP_CP_PREPASS=0 / 1 forces it off / on.
+inline bool cp_prepass(int B) {
+    static const int env = [] { const char* e = std::getenv("PDP_CP_PREPASS"); return e ? std::atoi(e) : -1; }();
+    return env >= 0 ? env != 0 : B > 8 * device_cu_count();
+}
+// workspace of the pre-pass: x [B][T+1][NX] | u [B][T][NU] | h_x [B][NX]
+template <class Mdl>
+int64_t cp_prepass_ws_bytes(int B, int T) { return (int64_t)B * ((int64_t)(T + 1) * Mdl::NX + (int64_t)T * Mdl::NU + Mdl::NX) * (int64_t)sizeof(double); }
+template <class Mdl, int NT>
+int cp_step_given_launch(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
+                         double* ws, void* st) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, STRIDE = Mdl::PATH_NVAR | 1;
+    const int np = pol->n_pivots;
+    double* xw = x ? x : ws;                                                   // the API outputs double as the hand-over where the caller asked for them
+    double* uw = u ? u : ws + (int64_t)B * (T + 1) * NX;
+    double* hxw = ws + (int64_t)B * ((int64_t)(T + 1) * NX + (int64_t)T * NU);
+    const size_t lds0 = sizeof(double) * ((size_t)T * np + (size_t)p * 64);
+    if (lds0 > 150 * 1024) return PDP_E_SIZE;
+    (void)hipFuncSetAttribute((const void*)cp_poly_rollout_lanes_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    PDP_CLEAR();
+    hipLaunchKernelGGL((cp_poly_rollout_lanes_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), lds0, S(st), B, T, *pol, p, x0, th, tb, loss, xw, uw, hxw);
+    if (const int rc = launched(); rc != 0) return rc;
+    static const int wgs_env = [] { const char* e = std::getenv("PDP_CP_GIVEN_WGS"); return e ? std::atoi(e) : 0; }();
+    const int wgs = wgs_env > 0 ? wgs_env : 12;
+    const int fixed = 1 + Mdl::PATH_NCONST + T * np + NX + 8 + 64 + (NX > NU ? NX : NU);
+    int rows = (160 * 1024 / 8 / wgs - 64 - fixed) / STRIDE;
+    rows = rows > Mdl::CHUNK ? Mdl::CHUNK : (rows < 4 ? (Mdl::CHUNK < 4 ? Mdl::CHUNK : 4) : rows);
+    const size_t lds = sizeof(double) * ((size_t)fixed + (size_t)rows * STRIDE);
+    if (lds > 150 * 1024) return PDP_E_SIZE;
+    (void)hipFuncSetAttribute((const void*)cp_step_poly_kernel<Mdl, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((cp_step_poly_kernel<Mdl, NT, true>), dim3(B, 1), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, rows, (const double*)xw,
+                       (const double*)uw, (const double*)hxw);
     return launched();
 }
 // Lagrange-policy kernel variants (environment PDP_CP_POLY_VARIANT overrides): 2 = rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h) for
@@ -387,6 +423,7 @@ inline int cp_mlp_variant() { static const int v = [] { const char* e = std::get
 template <class Mdl>
 int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
+        if (pol && pol->kind == PDP_POLICY_POLY && p <= 64 && cp_prepass(B)) return cp_prepass_ws_bytes<Mdl>(B, T);
         if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;
         int64_t need = 0;
         if (cp_mlp16_ok<Mdl>(*pol)) need = (int64_t)B * T * 64 * (int64_t)sizeof(double);       // one double per lane and time step
@@ -437,6 +474,14 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
         if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
         const int nt = (p + 15) / 16;
         if (nt > 4) return PDP_E_SIZE;
+        if (ws && cp_prepass(B) && wsb >= cp_prepass_ws_bytes<Mdl>(B, T)) {      // several trajectories per SIMD: rollout beforehand, one lane per trajectory
+            switch (nt) {
+                case 1: return cp_step_given_launch<Mdl, 1>(B, T, pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, st);
+                case 2: return cp_step_given_launch<Mdl, 2>(B, T, pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, st);
+                case 3: return cp_step_given_launch<Mdl, 3>(B, T, pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, st);
+                default: return cp_step_given_launch<Mdl, 4>(B, T, pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, st);
+            }
+        }
         // a batch that leaves SIMDs idle (one wavefront per trajectory, 4 SIMDs per CU) spreads the parameter tiles of a trajectory
         // over several wavefronts: each repeats the rollout and carries nt / gy of the sensitivity tiles
         int gy = (int)((int64_t)4 * device_cu_count() / B);
@@ -523,8 +568,10 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
         }
         constexpr int NT = (Mdl::NP + 15) / 16;
         static const int rows_env = [] { const char* e = std::getenv("PDP_SYSID_ROWS"); return e ? std::atoi(e) : 0; }();
-        const int rows = rows_env > 0 ? (rows_env < Mdl::CHUNK ? rows_env : Mdl::CHUNK) : sysid_rows<Mdl>(B, T, device_cu_count());
-        const size_t lds = sizeof(double) * (size_t)sysid_slice<Mdl>(T, rows);
+        static const int wgs_env = [] { const char* e = std::getenv("PDP_SYSID_GIVEN_WGS"); return e ? std::atoi(e) : 0; }();
+        const int rows = rows_env > 0 ? (rows_env < Mdl::CHUNK ? rows_env : Mdl::CHUNK)
+                         : (xgiven ? sysid_rows_given<Mdl>(T, wgs_env > 0 ? wgs_env : 12) : sysid_rows<Mdl>(B, T, device_cu_count()));
+        const size_t lds = sizeof(double) * (size_t)sysid_slice<Mdl>(T, rows, xgiven != nullptr);
         if (lds > 150 * 1024) return PDP_E_SIZE;
         // PDP_SYSID_VARIANT: 2 = rollout wave + sensitivity wave per trajectory (pdp_cp_pair_kernels.h), the default; 1 = one wavefront per trajectory
         static const int variant = [] { const char* e = std::getenv("PDP_SYSID_VARIANT"); return e ? std::atoi(e) : 2; }();
@@ -543,9 +590,14 @@ int sysid_step(int B, int T, const double* u, const double* xobs, const double* 
                 return launched();
             }
         }
-        (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         PDP_CLEAR();
-        hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows, xgiven);
+        if (xgiven) {
+            (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT, true>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows, xgiven);
+        } else {
+            (void)hipFuncSetAttribute((const void*)sysid_step_kernel<Mdl, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((sysid_step_kernel<Mdl, NT, false>), dim3(B), dim3(64), lds, S(st), B, T, u, xobs, th, tb, loss, grad, rows, xgiven);
+        }
         return launched();
     } else { return Mdl::KIND == PDP_KIND_SYSID ? PDP_E_SIZE : PDP_E_MODE; }
 }

@@ -1260,23 +1260,30 @@ __global__ void __launch_bounds__(64) cp_auxsys_kernel(int B, int T, pdp_policy 
 
 // Fused ControlPlanning.step for the Lagrange-polynomial policy: rollout (uniform), then forward sensitivities
 // X_{t+1} = F X_t + G Ue_t on MFMA tiles with the per-step matrices staged in LDS; NT tiles of 16 parameters.
-template <class Mdl, int NT>
+// GIVEN (batches with several trajectories per SIMD): trajectory, controls, loss and h_x(x_T) come from cp_poly_rollout_lanes_kernel (one LANE per trajectory, below);
+// the kernel keeps only the Jacobian pool and the basis in LDS (rows_given pool rows: sized by the host so that twelve workgroups share a CU) and evaluates its stages
+// from global memory - xg [B][T+1][NX], ug [B][T][NU], hxg [B][NX].
+template <class Mdl, int NT, bool GIVEN = false>
 __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0,
                                                            const double* __restrict__ theta, int tb, double* __restrict__ loss,
-                                                           double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo) {
-    constexpr int NX = Mdl::NX, NU = Mdl::NU, CH = Mdl::CHUNK, M = NU;
+                                                           double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo,
+                                                           int rows_given, const double* __restrict__ xg_, const double* __restrict__ ug_, const double* __restrict__ hxg_) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU, M = NU;
+    const int CH = GIVEN ? rows_given : Mdl::CHUNK;
     constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* blk = lds;                       // [cpool | pool]
     double* pool = blk + NC;
-    double* xs = pool + CH * STRIDE;         // (T+1) x NX
-    double* us = xs + (T + 1) * NX;          // T x NU
-    double* basis = us + T * NU;             // T x n_pivots
+    double* xs = pool + CH * STRIDE;         // (T+1) x NX     (not GIVEN)
+    double* us = xs + (GIVEN ? 0 : (T + 1) * NX);          // T x NU   (not GIVEN)
+    double* basis = us + (GIVEN ? 0 : T * NU);             // T x n_pivots
     double* hx = basis + T * pol.n_pivots;   // NX
-    double* dump = hx + NX + 8;              // 64 + max(NX, NU) words nobody reads (see the rollout)
+    [[maybe_unused]] double* dump = hx + NX + 8;              // 64 + max(NX, NU) words nobody reads (see the rollout)
     const int b = blockIdx.x, lane = threadIdx.x, np = pol.n_pivots;
     const int tile0 = blockIdx.y * NT;         // a batch smaller than the machine spreads its parameter tiles over grid.y (rollout repeated)
-    const double* th = theta + (int64_t)b * tb;
+    [[maybe_unused]] const double* th = theta + (int64_t)b * tb;
+    [[maybe_unused]] const double* xg = GIVEN ? xg_ + (int64_t)b * (T + 1) * NX : nullptr;
+    [[maybe_unused]] const double* ug = GIVEN ? ug_ + (int64_t)b * T * NU : nullptr;
     double pc[Mdl::NPC];
     Mdl::precompute(nullptr, pc);
     const d4 z = zero4();
@@ -1284,7 +1291,10 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
         for (int i = 0; i < np; ++i) basis[t * np + i] = lagrange_basis(pol, i, (double)t);
     if (lane == 0) blk[0] = 0.0;
     for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
+    if constexpr (GIVEN) { if (lane < NX) hx[lane] = hxg_[(int64_t)b * NX + lane]; }
     __syncthreads();
+    double J = 0.0;
+    if constexpr (!GIVEN) {
     // ---- the controls: the Lagrange policy is OPEN-LOOP, u_t = sum_i b_i(t) theta_i depends on t alone - all of them at once, lane = time step, before the rollout.
     // (Evaluated inside the rollout, the np x m parameter loads from global memory sat in the serial chain: ~2.8 k cycles per step, 80 % of this kernel's time.)
     for (int t = lane; t < T; t += 64) {
@@ -1301,7 +1311,6 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     }
     __syncthreads();
     // ---- rollout (uniform); u_{t+1} is requested from the staging one step ahead
-    double J = 0.0;
     {
         double xc[NX], xn[NX], uc[NU], un[NU];
 #pragma unroll
@@ -1339,6 +1348,7 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
     __syncthreads();
     if (xo && blockIdx.y == 0) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
     if (uo && blockIdx.y == 0) for (int i = lane; i < T * NU; i += 64) uo[(int64_t)b * T * NU + i] = us[i];
+    }      // !GIVEN
     // ---- forward sensitivities
     Gather gFT, gGT, gCX, gCU;
     make_gather(gFT, lane, NC, STRIDE, [](int r, int c) { return (r < NX && c < NX) ? Mdl::path_code(0, c * NX + r) : -1; });
@@ -1363,9 +1373,9 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
             const int t = t0 + lane;
             double xc[NX], uc[NU];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xs[t * NX + i];
+            for (int i = 0; i < NX; ++i) xc[i] = GIVEN ? xg[t * NX + i] : xs[t * NX + i];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
+            for (int i = 0; i < NU; ++i) uc[i] = GIVEN ? ug[t * NU + i] : us[t * NU + i];
             PackedSink s{pool + lane * STRIDE};
             Mdl::eval_path(xc, uc, nullptr, nullptr, pc, s);
         }
@@ -1405,7 +1415,60 @@ __global__ void __launch_bounds__(64) cp_step_poly_kernel(int B, int T, pdp_poli
         double a = sum_over_rowgroups(acc[j]);
         if (lane < 16 && 16 * (tile0 + j) + lane < p) grad[(int64_t)b * p + 16 * (tile0 + j) + lane] = a;
     }
-    if (lane == 0 && blockIdx.y == 0) loss[b] = J;
+    if constexpr (!GIVEN) { if (lane == 0 && blockIdx.y == 0) loss[b] = J; }
+}
+
+// Rollout of ControlPlanning.step with the Lagrange policy, ONE LANE per trajectory (the pre-pass of the GIVEN mode above): u_t = sum_i b_i(t) theta_i, x_{t+1} = f(x_t, u_t),
+// J = sum c(x_t, u_t) + h(x_T), h_x(x_T) - the same expressions in the same order as the uniform rollouts of cp_step_poly_kernel / cp_step_poly2_kernel.  The basis is
+// shared by the workgroup's 64 trajectories (LDS, [T][np]); each lane's parameters sit in LDS lane-minor ([p][64]: conflict-free) so that no global load is in the serial chain.
+template <class Mdl>
+__global__ void __launch_bounds__(64) cp_poly_rollout_lanes_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta, int tb,
+                                                                    double* __restrict__ loss, double* __restrict__ xw, double* __restrict__ uw, double* __restrict__ hxw) {
+    constexpr int NX = Mdl::NX, NU = Mdl::NU;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x, np = pol.n_pivots;
+    double* basis = lds;                     // T x np
+    double* thl = basis + T * np;            // p x 64
+    const int b = blockIdx.x * 64 + lane, bb = b < B ? b : B - 1;
+    for (int t = lane; t < T; t += 64)
+        for (int i = 0; i < np; ++i) basis[t * np + i] = lagrange_basis(pol, i, (double)t);
+    for (int k = 0; k < p; ++k) thl[k * 64 + lane] = theta[(int64_t)bb * tb + k];
+    __syncthreads();
+    double pc[Mdl::NPC];
+    Mdl::precompute(nullptr, pc);
+    double xc[NX], xn[NX], uc[NU], J = 0.0;
+    double* xb = xw + (int64_t)bb * (T + 1) * NX;
+    double* ub = uw + (int64_t)bb * T * NU;
+    const bool mine = b < B;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { xc[i] = x0[(int64_t)bb * NX + i]; if (mine) xb[i] = xc[i]; }
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) uc[j] = 0.0;
+        for (int i = 0; i < np; ++i) {
+            const double bi = basis[t * np + i];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uc[j] += bi * thl[(i * NU + j) * 64 + lane];
+        }
+        Mdl::dyn(xc, uc, nullptr, pc, xn);
+        J += Mdl::path_cost(xc, uc, nullptr, pc);
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) ub[t * NU + j] = uc[j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xb[(t + 1) * NX + i] = xn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = xn[i];
+    }
+    J += Mdl::final_cost(xc, nullptr, pc);
+    double h[NX];
+    Mdl::dhx(xc, nullptr, pc, h);
+    if (mine) {
+        loss[b] = J;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hxw[(int64_t)b * NX + i] = h[i];
+    }
 }
 
 // Fused ControlPlanning.step for ANY policy (tanh MLP up to 8 layers x 32 units, or Lagrange), p <= 512, by the adjoint
@@ -1730,9 +1793,17 @@ __global__ void __launch_bounds__(64) sysid_auxsys_kernel(int B, int T, const do
 // doubles of LDS per trajectory of the fused SysID.step kernels (sysid_step_kernel below, sysid_step2_kernel in pdp_cp_pair_kernels.h):
 // [cpool | pool CH rows | x (T+1) x NX | dlT NX + 1 | u T x NU | dump 64 + NX | hand-over counter, padding]
 template <class Mdl>
-__host__ __device__ inline int sysid_slice(int T, int rows = Mdl::CHUNK) {
-    const int n = 1 + Mdl::PATH_NCONST + rows * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (T + 1) * Mdl::NX + Mdl::NX + 1 + T * Mdl::NU + 64 + Mdl::NX + 8;
+__host__ __device__ inline int sysid_slice(int T, int rows = Mdl::CHUNK, bool given = false) {      // given: the trajectory and the controls stay in global memory (no staging)
+    const int n = 1 + Mdl::PATH_NCONST + rows * ((Mdl::PATH_NVAR + Mdl::NX) | 1) + (given ? 0 : (T + 1) * Mdl::NX) + Mdl::NX + 1 + (given ? 0 : T * Mdl::NU) + 64 + Mdl::NX + 8;
     return (n + 1) & ~1;
+}
+// pool rows of the given-trajectory mode: what lets `wgs` workgroups (wavefronts) share a CU's 160 KB.  12 = three wavefronts per SIMD, what the 162 VGPRs of that
+// instantiation allow (forced to 128 registers for four waves it spills 28); measured 8 / 12 / 16: 0.316 / 0.293 / 0.298 ms at B = 8192 (profiles/r04_rollout_prepass.txt)
+template <class Mdl>
+__host__ inline int sysid_rows_given(int T, int wgs) {
+    const int stride = (Mdl::PATH_NVAR + Mdl::NX) | 1;
+    const int fit = (160 * 1024 / 8 / wgs - 64 - sysid_slice<Mdl>(T, 0, true)) / stride;
+    return fit >= 4 ? (fit < Mdl::CHUNK ? fit : Mdl::CHUNK) : (Mdl::CHUNK < 4 ? Mdl::CHUNK : 4);
 }
 // Pool rows (stages per lane-parallel Jacobian pass) of sysid_step_kernel.  The generated CHUNK (a 17 KB pool for the quadrotor) makes a workgroup 31 KB: five
 // wavefronts per CU - fine while there is at most one trajectory per SIMD.  A batch with several trajectories per SIMD (C5's total of 8192 on one GPU: eight rounds)
@@ -1746,11 +1817,12 @@ __host__ inline int sysid_rows(int B, int T, int cus) {
     return fit >= 4 ? (fit < Mdl::CHUNK ? fit : Mdl::CHUNK) : Mdl::CHUNK;
 }
 // Fused SysID.step per trajectory: rollout (uniform, x kept in LDS) then X_{t+1} = F X_t + E on MFMA tiles.
-template <class Mdl, int NT>
+template <class Mdl, int NT, bool GIVEN = false>
 __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const double* __restrict__ u, const double* __restrict__ xobs,
                                                          const double* __restrict__ theta, int tb, double* __restrict__ loss, double* __restrict__ grad, int CH,
-                                                         const double* __restrict__ xgiven) {
-    // xgiven [B][T+1][NX] (or NULL): the trajectory, rolled out beforehand by sysid_integrate_kernel with ONE LANE per trajectory - the mode for batches with several
+                                                         const double* __restrict__ xgiven_) {
+    const double* __restrict__ xgiven = GIVEN ? xgiven_ : nullptr;      // (a template parameter: each instantiation keeps its own register allocation)
+    // xgiven [B][T+1][NX] (GIVEN): the trajectory, rolled out beforehand by sysid_integrate_kernel with ONE LANE per trajectory - the mode for batches with several
     // trajectories per SIMD: the rollout below runs one trajectory on all 64 lanes (the same value in every lane), which is the right thing while the SIMD has nothing
     // else to do and 63/64 wasted once other trajectories wait for it (C5a's 8192 on one GPU: 8 rounds of a 26 us rollout against one 21 us pass for all of them)
     constexpr int NX = Mdl::NX, NU = Mdl::NU, NP = Mdl::NP;
@@ -1758,10 +1830,10 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* blk = lds;
     double* pool = blk + NC;
-    double* xs = pool + CH * STRIDE;         // (T+1) x NX
-    double* dlT = xs + (T + 1) * NX;         // NX
-    double* us = dlT + NX + 1;               // T x NU: the given controls, staged once with coalesced loads
-    double* dump = us + T * NU;              // 64 + NX words nobody reads (see the rollout)
+    double* xs = pool + CH * STRIDE;         // (T+1) x NX   (not in the given-trajectory mode: stages are evaluated from global memory there)
+    double* dlT = xs + (xgiven ? 0 : (T + 1) * NX);         // NX
+    double* us = dlT + NX + 1;               // T x NU: the given controls, staged once with coalesced loads (rollout mode only)
+    double* dump = us + (xgiven ? 0 : T * NU);              // 64 + NX words nobody reads (see the rollout)
     const int b = blockIdx.x, lane = threadIdx.x;
     const d4 z = zero4();
     double th[NP];
@@ -1772,13 +1844,10 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
     const double* ob = xobs + (int64_t)b * (T + 1) * NX;
     if (lane == 0) blk[0] = 0.0;
     for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
-    for (int q = lane; q < T * NU; q += 64) us[q] = ub[q];
-    if (xgiven) {
-        const double* xg = xgiven + (int64_t)b * (T + 1) * NX;
-        for (int q = lane; q < (T + 1) * NX; q += 64) xs[q] = xg[q];
-    }
+    const double* xg = xgiven ? xgiven + (int64_t)b * (T + 1) * NX : nullptr;
+    if (!xgiven) for (int q = lane; q < T * NU; q += 64) us[q] = ub[q];
     __syncthreads();
-    if (!xgiven) {
+    if constexpr (!GIVEN) {
         // rollout (uniform).  u_t comes from the LDS staging, requested one step ahead (read from global memory inside the loop every step waited for a round
         // trip to memory); x_{t+1} goes to the staging from lane 0 without a conditional block (cp_step_poly_kernel)
         double xc[NX], xn[NX], uc[NU], un[NU];
@@ -1823,9 +1892,9 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
             double xc[NX], uc[NU];
             double* row = pool + lane * STRIDE;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { xc[i] = xs[t * NX + i]; double d = xc[i] - ob[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
+            for (int i = 0; i < NX; ++i) { xc[i] = xg ? xg[t * NX + i] : xs[t * NX + i]; double d = xc[i] - ob[t * NX + i]; row[DLX + i] = d; lsum += d * d; }
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uc[i] = us[t * NU + i];
+            for (int i = 0; i < NU; ++i) uc[i] = xg ? ub[t * NU + i] : us[t * NU + i];
             PackedSink s{row};
             Mdl::eval_path(xc, uc, nullptr, th, pc, s);
         }
@@ -1842,7 +1911,7 @@ __global__ void __launch_bounds__(64) sysid_step_kernel(int B, int T, const doub
         }
     }
     __syncthreads();
-    if (lane < NX) { double d = xs[T * NX + lane] - ob[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
+    if (lane < NX) { double d = (xg ? xg[T * NX + lane] : xs[T * NX + lane]) - ob[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
