@@ -260,21 +260,36 @@ def other_configs(torch):
         try:
             th_start = th_star + 0.05 if system == "cartpole" else th_star * (1 + 0.02 * np.cos(np.arange(th_star.size)))
             loops = {}
-            for mode in ("eager", "graph"):
-                lp = IRLLoop(mdl, demo["state"], demo["control"], th_start, 1e-4, record=record_kind, max_steps=512)
-                lp.start()
-                if mode == "graph":
+            # graph_tol8: the solves stop where the reference's IPOPT stops (its default tol = 1e-8, PDP.py:178-182); graph_one: at most ONE Newton iteration per parameter step
+            # (the "real-time iteration" of NMPC: the next step's Newton iteration corrects what this one left - an option, not the default: solves may end unconverged)
+            for mode in ("eager", "graph", "graph_tol8", "graph_one"):
+                lp = IRLLoop(mdl, demo["state"], demo["control"], th_start, 1e-4, record=record_kind, max_steps=512, tol=1e-10 if mode in ("eager", "graph") else 1e-8,
+                             max_iter=300)
+                lp.start()                           # (the cold first solve runs to convergence in every mode)
+                if mode == "graph_one":
+                    lp.max_iter = 1
+                if mode != "eager":
                     lp.capture()
-                lp.run(10, graphed=(mode == "graph"))
+                lp.run(10, graphed=(mode != "eager"))
                 torch.cuda.synchronize()
-                n_it = 100 if mode == "graph" else 40
+                n_it = 40 if mode == "eager" else 100
                 t0_ = _time.perf_counter()
-                lp.run(n_it, graphed=(mode == "graph"))
+                lp.run(n_it, graphed=(mode != "eager"))
                 torch.cuda.synchronize()
                 loops[mode] = (1e3 * (_time.perf_counter() - t0_) / n_it, lp.results())
-            rg = loops["graph"][1]
+            rg, r8, r1 = loops["graph"][1], loops["graph_tol8"][1], loops["graph_one"][1]
             loop_res = {"ms_per_iteration_python_driven": loops["eager"][0], "ms_per_iteration_hipgraph_replay": loops["graph"][0],
                         "traj_per_s_hipgraph_replay": B / (loops["graph"][0] * 1e-3), "learning_rate": 1e-4, "record": record_kind,
+                        "one_newton_iteration_per_step_tol_1e-8": {"ms_per_iteration_hipgraph_replay": loops["graph_one"][0], "traj_per_s": B / (loops["graph_one"][0] * 1e-3),
+                                                                   "solves_stopped_at_the_cap_unconverged": r1["unconverged_solves"], "of": r1["iterations"] * B,
+                                                                   "loss_last": float(r1["loss_trace"][-1]),
+                                                                   "parameter_trace_agrees_with_tol_1e-10_rel": float(np.abs(r1["parameter_trace"] - rg["parameter_trace"]).max()
+                                                                                                                     / np.abs(rg["parameter_trace"]).max())},
+                        "at_ipopt_default_tol_1e-8": {"ms_per_iteration_hipgraph_replay": loops["graph_tol8"][0], "traj_per_s": B / (loops["graph_tol8"][0] * 1e-3),
+                                                      "newton_iterations_per_solve_incl_the_cold_first": r8["newton_iterations_per_solve"],
+                                                      "unconverged_solves": r8["unconverged_solves"], "loss_last": float(r8["loss_trace"][-1]),
+                                                      "parameter_trace_agrees_with_tol_1e-10_rel": float(np.abs(r8["parameter_trace"] - rg["parameter_trace"]).max()
+                                                                                                        / np.abs(rg["parameter_trace"]).max())},
                         "iterations_run": rg["iterations"], "unconverged_solves": rg["unconverged_solves"], "riccati_trouble": rg["riccati_trouble"],
                         "newton_iterations_per_solve_incl_the_cold_first": rg["newton_iterations_per_solve"],
                         "loss_first_last": [float(rg["loss_trace"][0]), float(rg["loss_trace"][-1])],

@@ -94,6 +94,16 @@ int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double
 int pdp_cp_grad_contract_batched(int B, int T, int n, int m, int p, const double* dcx, const double* dcu, const double* dhx,
                                  const double* X, const double* U, double* grad, void* stream);
 
+/* The parameter update of the reference's gradient-descent loops as ONE launch (Examples/IRL/cartpole/cartpole_PDP.py:76-80: loss and dp accumulated over the
+ * demonstrations, current_parameter -= lr * dp; PDP.py:1293-1294: batch means): mean of loss [B] and of grad [B][grad_bstride >= p] over the batch in a fixed summation order,
+ *     dtheta = -lr * mean gradient,  theta += dtheta,  loss_trace[k] = mean loss,  parameter_trace[k][:] = theta      (k = counters[0]; traces may be NULL, rows >= trace_len are dropped)
+ * and the counters of a loop that never synchronises with the host: counters[0] += 1 (iterations done), counters[1] += #(converged[b] == 0), counters[2] += #(status[b] != 0),
+ * counters[3] += sum iterations[b]   (status / converged / iterations: the int32 outputs of the gradient unit and of pdp_oc_solve_ms_batched, each may be NULL).
+ * p <= 1023.  A loop iteration then is three launches - solve, gradient unit, this - and is what pdp_amd.irl.IRLLoop records as a hipGraph. */
+int pdp_gd_update_batched(int B, int p, const double* loss, const double* grad, int grad_bstride, const int32_t* status, const int32_t* converged,
+                          const int32_t* iterations, double lr, double* theta, double* dtheta, double* loss_trace, double* parameter_trace,
+                          int64_t trace_len, int64_t* counters, void* stream);
+
 /* Batched SysID.integrateAuxSys (PDP/PDP.py:1241-1259): X_{t+1} = F_t X_t + E_t.
  * F [B][T][n][n], E [B][T][n][p], X0 [B][n][p] (NULL = 0) -> X [B][T+1][n][p]. */
 int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0,

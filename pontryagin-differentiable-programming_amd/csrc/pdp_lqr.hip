@@ -123,6 +123,50 @@ __global__ void cp_grad_contract_kernel(int B, int T, int n, int m, int p, const
     grad[(int64_t)b * p + j] = acc;
 }
 
+// The parameter update of a data-parallel gradient-descent loop as ONE launch (pdp_gd_update_batched): column sums of [loss | grad] over the batch in a fixed order
+// (thread (r, j) sums the rows b = r, r + R, .. of column j; the R partial sums are added in ascending r), theta <- theta - lr * mean gradient, the traces at the
+// device-side iteration counter, and the health counters.  One workgroup: the iteration counter is read by every thread before thread 0 advances it.
+__global__ void __launch_bounds__(1024) gd_update_kernel(int B, int p, const double* __restrict__ loss, const double* __restrict__ grad, int gs, const int32_t* __restrict__ status,
+                                                         const int32_t* __restrict__ converged, const int32_t* __restrict__ iterations, double lr, double* __restrict__ theta,
+                                                         double* __restrict__ dtheta, double* __restrict__ loss_trace, double* __restrict__ par_trace, long long trace_len,
+                                                         long long* __restrict__ counters) {
+    __shared__ double part[1024];
+    __shared__ unsigned long long cnt[3];
+    const int tid = threadIdx.x;
+    int W = 1;
+    while (W < p + 1) W <<= 1;
+    const int R = 1024 / W, j = tid % W, r = tid / W;
+    if (tid < 3) cnt[tid] = 0;
+    double acc = 0.0;
+    if (j < p) { for (int b = r; b < B; b += R) acc += grad[(int64_t)b * gs + j]; }
+    else if (j == p) { for (int b = r; b < B; b += R) acc += loss[b]; }
+    part[tid] = acc;
+    unsigned long long unc = 0, trb = 0, nwt = 0;
+    for (int b = tid; b < B; b += 1024) {
+        if (converged) unc += converged[b] == 0;
+        if (status) trb += status[b] != 0;
+        if (iterations) nwt += (unsigned long long)iterations[b];
+    }
+    __syncthreads();
+    if (unc) atomicAdd(&cnt[0], unc);
+    if (trb) atomicAdd(&cnt[1], trb);
+    if (nwt) atomicAdd(&cnt[2], nwt);
+    const long long k = counters[0];
+    if (tid <= p) {
+        double sum = 0.0;
+        for (int q = 0; q < R; ++q) sum += part[q * W + tid];
+        const double mean = sum / (double)B;
+        if (tid < p) {
+            const double d = -lr * mean, th = theta[tid] + d;
+            dtheta[tid] = d;
+            theta[tid] = th;
+            if (par_trace && k < trace_len) par_trace[k * p + tid] = th;
+        } else if (loss_trace && k < trace_len) loss_trace[k] = mean;
+    }
+    __syncthreads();
+    if (tid == 0) { counters[0] = k + 1; counters[1] += (long long)cnt[0]; counters[2] += (long long)cnt[1]; counters[3] += (long long)cnt[2]; }
+}
+
 template <int M>
 int launch_lqr(const pdp_lqr_problem& pr, int nt, double* X, double* U, double* Lam, int32_t* status, double* wg, double* wpw, hipStream_t s) {
     dim3 grid(pr.B), block(64);
@@ -230,6 +274,16 @@ int pdp_cp_grad_contract_batched(int B, int T, int n, int m, int p, const double
     if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !dcx || !dcu || !dhx || !X || !U || !grad) return PDP_E_ARG;
     PDP_CLEAR();
     hipLaunchKernelGGL(cp_grad_contract_kernel, dim3((p + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, dcx, dcu, dhx, X, U, grad);
+    return launched();
+}
+
+int pdp_gd_update_batched(int B, int p, const double* loss, const double* grad, int grad_bstride, const int32_t* status, const int32_t* converged, const int32_t* iterations,
+                          double lr, double* theta, double* dtheta, double* loss_trace, double* parameter_trace, int64_t trace_len, int64_t* counters, void* stream) {
+    if (B <= 0 || p <= 0 || !loss || !grad || grad_bstride < p || !theta || !dtheta || !counters) return PDP_E_ARG;
+    if (p + 1 > 1024) return PDP_E_SIZE;
+    PDP_CLEAR();
+    hipLaunchKernelGGL(gd_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, p, loss, grad, grad_bstride, status, converged, iterations, lr, theta, dtheta, loss_trace,
+                       parameter_trace, (long long)trace_len, (long long*)counters);
     return launched();
 }
 

@@ -3,8 +3,8 @@
 Reference loop (Examples/IRL/cartpole/cartpole_PDP.py:52-80, Examples/IRL/quadrotor/uav_PDP.py:52-62): at the current parameter solve every demonstration's OC problem
 (`OCSys.ocSolver`), differentiate the solutions (`getAuxSys` + `lqrSolver`), chain rule against the demonstrations, `theta <- theta - lr * mean gradient`.  Here an
 iteration is two kernels - the multiple-shooting solve from the first-order prediction of its solution (pdp_oc_solve_ms_batched with PDP_MS_PREDICT, in place on the previous
-solution) and the fused gradient unit that also leaves the prediction record for the next solve (pdp_oc_pdp_grad_sens_batched) - and four small tensor operations for the
-parameter update.  Nothing in the loop waits for the host: loss and parameter traces are written into device arrays (a device-side counter indexes them), convergence
+solution), the fused gradient unit that also leaves the prediction record for the next solve (pdp_oc_pdp_grad_sens_batched), and the parameter update with its traces
+and counters (pdp_gd_update_batched: one launch).  Nothing in the loop waits for the host: loss and parameter traces are written into device arrays (a device-side counter indexes them), convergence
 flags and iteration counts of the solves are accumulated on the device and read once at the end.  `IRLLoop.capture()` records the iteration once (torch.cuda.CUDAGraph =
 hipGraph on ROCm: every buffer, the parameter vector, the step and the traces live at fixed device addresses) and `IRLLoop.run(n)` replays it n times.  Measured
 (bench.py, `irl_loop_wall_clock`): with no synchronisation in the loop the Python-driven iterations already keep the GPU busy where the kernels are long (C3: 0.27 ms per
@@ -35,10 +35,9 @@ class IRLLoop:
         self.max_steps = int(max_steps)
         self.loss_trace = torch.zeros(self.max_steps, **f64)
         self.parameter_trace = torch.zeros(self.max_steps, mdl.p, **f64)
-        self.k = torch.zeros(1, dtype=torch.int64, device="cuda")                  # iterations done (device-side: the graph indexes the traces with it)
-        self.unconverged = torch.zeros(1, dtype=torch.int64, device="cuda")        # OC solves that did not converge, summed over the iterations
-        self.trouble = torch.zeros(1, dtype=torch.int64, device="cuda")            # trajectories on which the Riccati sweep reported numerical trouble
-        self.newton = torch.zeros(1, dtype=torch.int64, device="cuda")             # Newton iterations of all OC solves (the cold ones of start() included)
+        # device-side counters (pdp_gd_update_batched): iterations done (indexes the traces) | OC solves that did not converge | trajectories on which the Riccati sweep
+        # reported numerical trouble | Newton iterations of all OC solves (the cold ones of start() included)
+        self.counters = torch.zeros(4, dtype=torch.int64, device="cuda")
         self.sol = None                                                            # (x, u, lam) of the current parameter: the solver works in place on them
         self.bufs = {}                                                             # outputs of the gradient unit (fixed addresses)
         self.graph = None
@@ -46,16 +45,10 @@ class IRLLoop:
 
     # ---- one iteration, no host synchronisation anywhere
     def _update(self, out, sol):
-        torch = rt.torch_cuda()
-        k, conv = self.k, sol["converged"]
-        self.newton.add_(sol["iterations"].sum())
-        self.loss_trace.index_copy_(0, k, out["loss"].mean().reshape(1))
-        torch.mul(out["grad"].mean(dim=0), -self.lr, out=self.dtheta)              # theta_{k+1} - theta_k: also the step the next solve's prediction is made for
-        self.theta.add_(self.dtheta)
-        self.parameter_trace.index_copy_(0, k, self.theta.reshape(1, -1))
-        self.unconverged.add_((~conv).sum())
-        self.trouble.add_((out["status"] != 0).sum())
-        k.add_(1)
+        # mean loss and gradient, theta <- theta - lr * mean gradient, dtheta (also the step the next solve's prediction is made for), traces, counters: ONE launch
+        # (as tensor operations this was fourteen small kernels - 70 us per iteration, a quarter of a C3 iteration)
+        rt.gd_update(out["loss"], out["grad"], self.lr, self.theta, self.dtheta, self.counters, status=out["status"], converged=sol["converged_flags"],
+                     iterations=sol["iterations"], loss_trace=self.loss_trace, parameter_trace=self.parameter_trace)
 
     def _gradient(self):
         x, u, lam = self.sol
@@ -113,7 +106,6 @@ class IRLLoop:
 
     def results(self):
         """host copies (one synchronisation): the reference's result fields + the health counters"""
-        k = int(self.k.item())
+        k, unconverged, trouble, newton = (int(v) for v in self.counters.cpu().numpy())
         return {"loss_trace": self.loss_trace[:k].cpu().numpy(), "parameter_trace": self.parameter_trace[:k].cpu().numpy(), "learning_rate": self.lr,
-                "iterations": k, "unconverged_solves": int(self.unconverged.item()), "riccati_trouble": int(self.trouble.item()),
-                "newton_iterations_per_solve": float(self.newton.item()) / max(1, k * self.B)}
+                "iterations": k, "unconverged_solves": unconverged, "riccati_trouble": trouble, "newton_iterations_per_solve": newton / max(1, k * self.B)}

@@ -54,7 +54,7 @@ class PdpPolicy(C.Structure):
 
 
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
-                "pdp_sysid_aux_integrate_batched"]
+                "pdp_sysid_aux_integrate_batched", "pdp_gd_update_batched"]
 MODEL_SYMBOLS = ["pdp_model_get_info", "pdp_oc_rollout_batched", "pdp_oc_rollout_feedback_batched", "pdp_oc_costate_batched", "pdp_oc_ms_residuals_batched",
                  "pdp_oc_auxsys_batched",
                  "pdp_oc_solve_workspace_bytes", "pdp_oc_solve_batched", "pdp_oc_solve_ms_workspace_bytes", "pdp_oc_solve_ms_batched",
@@ -97,8 +97,32 @@ def load_core():
         lib.pdp_cp_aux_integrate_batched.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7 + [C.c_void_p]
         lib.pdp_sysid_aux_integrate_batched.restype = C.c_int
         lib.pdp_sysid_aux_integrate_batched.argtypes = [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_void_p]
+        lib.pdp_gd_update_batched.restype = C.c_int
+        lib.pdp_gd_update_batched.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4 + \
+                                             [C.c_int64, C.c_void_p, C.c_void_p]
         _core = lib
     return _core
+
+
+def gd_update(loss, grad, lr, theta, dtheta, counters, status=None, converged=None, iterations=None, loss_trace=None, parameter_trace=None):
+    """theta <- theta - lr * mean gradient with traces and health counters, one launch (pdp_gd_update_batched).  loss [B], grad [B, p] (rows may be strided: a view of
+    the packed [B, p + 1] output), theta / dtheta [p] fp64, counters int64 [4] = (iterations done, unconverged solves, numerical trouble, Newton iterations);
+    status / converged / iterations: int32 [B] or None."""
+    torch = torch_cuda()
+    B, p = grad.shape
+    assert loss.dtype == torch.float64 and grad.dtype == torch.float64 and grad.stride(1) == 1 and loss.is_contiguous() and counters.dtype == torch.int64 and counters.numel() >= 4
+    for t in (status, converged, iterations):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous() and t.numel() == B)
+    assert theta.dtype == torch.float64 and theta.numel() == p and dtheta.numel() == p and theta.is_contiguous() and dtheta.is_contiguous()
+    tl = 0
+    if loss_trace is not None:
+        tl = loss_trace.shape[0]
+        assert loss_trace.is_contiguous() and (parameter_trace is None or (parameter_trace.is_contiguous() and tuple(parameter_trace.shape) == (tl, p)))
+    elif parameter_trace is not None:
+        tl = parameter_trace.shape[0]
+        assert parameter_trace.is_contiguous() and parameter_trace.shape[1] == p
+    check(load_core().pdp_gd_update_batched(B, p, ptr(loss), ptr(grad), int(grad.stride(0)), ptr(status), ptr(converged), ptr(iterations), float(lr), ptr(theta), ptr(dtheta),
+                                            ptr(loss_trace), ptr(parameter_trace), int(tl), ptr(counters), current_stream_ptr()), "pdp_gd_update_batched")
 
 
 def torch_cuda():
@@ -398,7 +422,7 @@ class ModelLib:
                 opts.flags |= 32
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
-        out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "iterations": iters, "status": status}
+        out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "converged_flags": conv, "iterations": iters, "status": status}
         if want_gains:
             out["gains"] = gains
         if log is not None:

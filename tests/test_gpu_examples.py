@@ -93,3 +93,41 @@ def test_irl_example_with_graph_option(tmp_path):
     L = r["loss_trace"].flatten()
     assert L.size == 30 and L[-1] < 0.5 * L[0], out
     assert r["parameter_trace"].shape == (30, 7)
+
+
+@pytest.mark.parametrize("B,p", [(1, 1), (5, 7), (1024, 9), (8192, 420), (300, 1023)])
+def test_one_launch_parameter_update(B, p):
+    """pdp_gd_update_batched against numpy: batch means, theta <- theta - lr * mean gradient, traces at the device-side counter, health counters; strided gradient
+    rows (the packed [B, p + 1] output); rows beyond the trace length are dropped; p + 1 > 1024 is refused"""
+    import torch
+    sys.path.insert(0, ROOT)
+    from pdp_amd import runtime as rt
+    rng = np.random.default_rng(B + p)
+    packed = torch.as_tensor(rng.standard_normal((B, p + 1)), device="cuda")
+    loss = packed[:, p].contiguous()
+    status = torch.as_tensor((rng.random(B) < 0.1).astype(np.int32) * 3, device="cuda")
+    conv = torch.as_tensor((rng.random(B) < 0.8).astype(np.int32), device="cuda")
+    iters = torch.as_tensor(rng.integers(0, 9, B).astype(np.int32), device="cuda")
+    theta = torch.as_tensor(rng.standard_normal(p), device="cuda")
+    th0 = theta.cpu().numpy().copy()
+    dth = torch.zeros(p, dtype=torch.float64, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ltr, ptr_ = torch.zeros(2, dtype=torch.float64, device="cuda"), torch.zeros(2, p, dtype=torch.float64, device="cuda")
+    lr = 0.37
+    G = packed.cpu().numpy()[:, :p]
+    want_d = -lr * G.mean(axis=0)
+    for k in range(3):                      # the third call finds the traces full
+        rt.gd_update(loss, packed[:, :p], lr, theta, dth, cnt, status=status, converged=conv, iterations=iters, loss_trace=ltr, parameter_trace=ptr_)
+        sc = max(1e-300, np.abs(want_d).max())
+        assert np.abs(dth.cpu().numpy() - want_d).max() <= 1e-13 * max(sc, lr * np.abs(G).max())
+        assert np.abs(theta.cpu().numpy() - (th0 + (k + 1) * want_d)).max() <= 1e-12 * max(1.0, np.abs(th0).max())
+    c = cnt.cpu().numpy()
+    assert c[0] == 3 and c[1] == 3 * int((conv == 0).sum()) and c[2] == 3 * int((status != 0).sum()) and c[3] == 3 * int(iters.sum())
+    assert np.abs(ltr.cpu().numpy() - float(loss.mean())).max() <= 1e-13 * max(1.0, abs(float(loss.mean())))
+    assert np.abs(ptr_.cpu().numpy()[1] - (th0 + 2 * want_d)).max() <= 1e-12 * max(1.0, np.abs(th0).max())
+    rt.gd_update(loss, packed[:, :p], lr, theta, dth, cnt)          # everything optional left out
+    assert int(cnt[0]) == 4
+    if p == 1023:
+        big = torch.zeros(4, 1025, dtype=torch.float64, device="cuda")
+        with pytest.raises(RuntimeError):
+            rt.gd_update(big[:, 0].contiguous(), big[:, :1024], lr, torch.zeros(1024, dtype=torch.float64, device="cuda"), torch.zeros(1024, dtype=torch.float64, device="cuda"), cnt)
