@@ -7,8 +7,8 @@ solution), the fused gradient unit that also leaves the prediction record for th
 and counters (pdp_gd_update_batched: one launch).  Nothing in the loop waits for the host: loss and parameter traces are written into device arrays (a device-side counter indexes them), convergence
 flags and iteration counts of the solves are accumulated on the device and read once at the end.  `IRLLoop.capture()` records the iteration once (torch.cuda.CUDAGraph =
 hipGraph on ROCm: every buffer, the parameter vector, the step and the traces live at fixed device addresses) and `IRLLoop.run(n)` replays it n times.  Measured
-(bench.py, `irl_loop_wall_clock`): with no synchronisation in the loop the Python-driven iterations already keep the GPU busy where the kernels are long (C3: 0.27 ms per
-iteration either way); the graph pays where they are short (C2: 0.149 -> 0.123 ms).
+(bench.py, `irl_loop_wall_clock`): with three launches per iteration and no synchronisation the Python-driven loop keeps the GPU as busy as the graph replay does (C3: 0.236 /
+0.245 ms per iteration, C2: 0.096 / 0.100 ms); the graph is for callers whose host thread is busy elsewhere.
 """
 import numpy as np
 
