@@ -26,6 +26,7 @@
 namespace pdp {
 
 constexpr int MLP16_W = 16, MLP16_MAXL = 4;
+PDP_DEV int mlp_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 struct Mlp16Layout { int xs, us, zs, ds, misc, blk, total, actw; };
 template <class Mdl>
@@ -37,7 +38,7 @@ __host__ __device__ inline Mlp16Layout cp_mlp16_layout(int T, int rows) {
     L.zs = o; o += MLP16_MAXL * MLP16_W + 2;              // layer inputs of the current step | 1.0 (bias factor) | 0.0
     L.ds = o; o += MLP16_MAXL * MLP16_W;                  // layer deltas of the current step
     L.misc = o; o += Mdl::NX + Mdl::NU + 2;               // (d pi/dx)' v | spare
-    L.blk = o; o += 1 + Mdl::PATH_NCONST + rows * (Mdl::PATH_NVAR | 1);
+    L.blk = o; o += rows * ((Mdl::PATH_NVAR + 1 + Mdl::PATH_NCONST) | 1);      // pool rows [entries | 0.0 | constants]: every row carries its own zero and constants
     L.total = o + 8;
     L.actw = 64;                                           // workspace doubles per time step: one per lane
     return L;
@@ -49,12 +50,15 @@ __host__ inline bool cp_mlp16_ok(const pdp_policy& pol) {
     return true;
 }
 // pool rows per evaluation pass: as many as fit beside the trajectory in 40 KB (four wavefronts, one per SIMD, share a CU's 160 KB)
+// budget_kb: LDS per workgroup the rows are sized for - 40 (four wavefronts per CU, one per SIMD) or 20 (eight: two per SIMD, for batches beyond one trajectory per SIMD;
+// the kernel needs 240 VGPRs: two waves fit a SIMD)
 template <class Mdl>
-__host__ inline int cp_mlp16_rows(int T) {
-    const int stride = Mdl::PATH_NVAR | 1;
+__host__ inline int cp_mlp16_rows(int T, int budget_kb = 40) {
+    const int stride = (Mdl::PATH_NVAR + 1 + Mdl::PATH_NCONST) | 1;
     const int fixed = cp_mlp16_layout<Mdl>(T, 0).total;
-    int fit = (40 * 1024 / 8 - fixed) / stride;
-    if (fit < 8) fit = (160 * 1024 / 8 - fixed) / stride;     // long horizons: one workgroup per CU
+    int fit = (budget_kb * 1024 / 8 - fixed) / stride;
+    if (fit < 4 && budget_kb < 40) fit = (40 * 1024 / 8 - fixed) / stride;
+    if (fit < 8) { const int f2 = (160 * 1024 / 8 - fixed) / stride; if (f2 > fit) fit = f2; }     // long horizons: one workgroup per CU
     return fit < 1 ? 0 : (fit > 64 ? 64 : fit);
 }
 
@@ -63,10 +67,10 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
                                                             int tb, double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ xo,
                                                             double* __restrict__ uo, double* __restrict__ ws_acts, int CH) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU, W = MLP16_W;
-    constexpr int NC = 1 + Mdl::PATH_NCONST, STRIDE = Mdl::PATH_NVAR | 1;
+    constexpr int NV = Mdl::PATH_NVAR, STRIDE = (NV + 1 + Mdl::PATH_NCONST) | 1;      // row: [entries | 0.0 | constants]
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Mlp16Layout L = cp_mlp16_layout<Mdl>(T, CH);
-    double *xs = lds + L.xs, *us = lds + L.us, *zs = lds + L.zs, *ds = lds + L.ds, *dpx = lds + L.misc, *blk = lds + L.blk, *pool = blk + NC;
+    double *xs = lds + L.xs, *us = lds + L.us, *zs = lds + L.zs, *ds = lds + L.ds, *dpx = lds + L.misc, *pool = lds + L.blk;
     const int b = blockIdx.x, lane = threadIdx.x, grp = lane >> 4, idx = lane & 15;
     double* actg = ws_acts + (int64_t)b * T * 64;            // [T][64]: element (t, lane) written and re-read by the same lane
     const int nl = pol.n_layers;
@@ -94,25 +98,7 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
         Wcol[c] = (idx < my_cols && c < my_rows) ? thb[my_off + c + idx * my_rows] : 0.0;          // A[c][idx]
     }
     bias = idx < my_rows ? thb[my_off + my_rows * my_cols + idx] : 0.0;
-    if (lane == 0) { blk[0] = 0.0; zs[MLP16_MAXL * W] = 1.0; zs[MLP16_MAXL * W + 1] = 0.0; }
-    for (int i_ = lane; i_ < Mdl::PATH_NCONST; i_ += 64) blk[1 + i_] = Mdl::path_const(i_);
-    // per-lane parameter slots q = 0..7 (parameter index lane + 64 q): LDS offsets of the two factors of d cost / d theta_j (delta_k[r] * z_k[c], or 1.0)
-    int pr[8], pz[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int j = lane + 64 * q;
-        pr[q] = L.zs + MLP16_MAXL * W + 1; pz[q] = L.zs + MLP16_MAXL * W + 1;       // 0.0 * 0.0
-        if (j < p) {
-#pragma unroll
-            for (int k = 0; k < MLP16_MAXL; ++k) {
-                if (k < nl && j >= loff[k] && j < loff[k] + lrows[k] * lcols[k] + lrows[k]) {
-                    const int e = j - loff[k], nw = lrows[k] * lcols[k];
-                    if (e < nw) { pr[q] = L.ds + k * W + e % lrows[k]; pz[q] = L.zs + k * W + e / lrows[k]; }
-                    else { pr[q] = L.ds + k * W + (e - nw); pz[q] = L.zs + MLP16_MAXL * W; }
-                }
-            }
-        }
-    }
+    if (lane == 0) { zs[MLP16_MAXL * W] = 1.0; zs[MLP16_MAXL * W + 1] = 0.0; }
     wave_lds_sync();
 
     // ---------------- forward rollout: x_{t+1} = f(x_t, pi(x_t)), executed uniformly by the wave
@@ -171,6 +157,26 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
     }
     if (xo) for (int i = lane; i < (T + 1) * NX; i += 64) xo[(int64_t)b * (T + 1) * NX + i] = xs[i];
 
+    // (computed HERE, from a lane id the optimiser cannot see through: hoisted above the rollout these 16 registers - and the 50 of the pool offsets below - stay live
+    // across it and the kernel needs 266 VGPRs, one more than lets two wavefronts share a SIMD)
+    const int ln_ = mlp_opaque(lane);
+    // per-lane parameter slots q = 0..7 (parameter index lane + 64 q): LDS offsets of the two factors of d cost / d theta_j (delta_k[r] * z_k[c], or 1.0)
+    int pr[8], pz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = ln_ + 64 * q;
+        pr[q] = L.zs + MLP16_MAXL * W + 1; pz[q] = L.zs + MLP16_MAXL * W + 1;       // 0.0 * 0.0
+        if (j < p) {
+#pragma unroll
+            for (int k = 0; k < MLP16_MAXL; ++k) {
+                if (k < nl && j >= loff[k] && j < loff[k] + lrows[k] * lcols[k] + lrows[k]) {
+                    const int e = j - loff[k], nw = lrows[k] * lcols[k];
+                    if (e < nw) { pr[q] = L.ds + k * W + e % lrows[k]; pz[q] = L.zs + k * W + e / lrows[k]; }
+                    else { pr[q] = L.ds + k * W + (e - nw); pz[q] = L.zs + MLP16_MAXL * W; }
+                }
+            }
+        }
+    }
     // ---------------- adjoint sweep: mu_T = h_x ; v_t = c_u + G_t' mu_{t+1} ; grad += (d pi/d theta)' v_t ; mu_t = c_x + F_t' mu_{t+1} + (d pi/d x)' v_t
     double mu[NX];
     {
@@ -183,16 +189,19 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
 #pragma unroll
     for (int q = 0; q < 8; ++q) gacc[q] = 0.0;
     // per-lane pool offsets: column idx of F (group 0, idx < NX), column idx of G (the output layer's group, idx < NU), c_x[idx], c_u[idx]
-    const bool lane_x = grp == 0 && idx < NX, lane_u = grp == nl - 1 && idx < NU;
-    int fo[NX], fm[NX], go[NX], gm[NX], cxo = 0, cxm = 0, cuo = 0, cum = 0;
-    auto enc = [&](int code, int& o, int& m) { if (code >= 0) { o = NC + code; m = STRIDE; } else { o = (code == -1) ? 0 : 1 + (-2 - code); m = 0; } };
+    const int grp_ = ln_ >> 4, idx_ = ln_ & 15;
+    const bool lane_x = grp_ == 0 && idx_ < NX, lane_u = grp_ == nl - 1 && idx_ < NU;
+    // (slots inside a row: an entry, the row's 0.0, or one of its constants - the same distance from row to row whatever the element is, so the offsets need no stride
+    // of their own: 28 registers less than with a shared constant pool, which is what lets two wavefronts share a SIMD)
+    int fo[NX], go[NX], cxo = 0, cuo = 0;
+    auto enc = [&](int code, int& o) { o = code >= 0 ? code : (code == -1 ? NV : NV + 1 + (-2 - code)); };
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-        enc(lane_x ? Mdl::path_code(0, k * NX + idx) : -1, fo[k], fm[k]);
-        enc(lane_u ? Mdl::path_code(1, k * NU + idx) : -1, go[k], gm[k]);
+        enc(lane_x ? Mdl::path_code(0, k * NX + idx_) : -1, fo[k]);
+        enc(lane_u ? Mdl::path_code(1, k * NU + idx_) : -1, go[k]);
     }
-    enc(lane_x ? Mdl::path_code(2, idx) : -1, cxo, cxm);
-    enc(lane_u ? Mdl::path_code(3, idx) : -1, cuo, cum);
+    enc(lane_x ? Mdl::path_code(2, idx_) : -1, cxo);
+    enc(lane_u ? Mdl::path_code(3, idx_) : -1, cuo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the rollout's activation stores have landed (re-read by the same lanes below)
     double znext = actg[(T - 1) * 64 + lane];
     const int nchunk = (T + CH - 1) / CH;
@@ -207,8 +216,12 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
             for (int i = 0; i < NX; ++i) xc[i] = xs[t * NX + i];
 #pragma unroll
             for (int j = 0; j < NU; ++j) uc[j] = us[t * NU + j];
-            PackedSink sk{pool + lane * STRIDE};
+            double* row = pool + lane * STRIDE;
+            PackedSink sk{row};
             Mdl::eval_path(xc, uc, nullptr, nullptr, pc, sk);
+            row[NV] = 0.0;
+#pragma unroll
+            for (int i = 0; i < Mdl::PATH_NCONST; ++i) row[NV + 1 + i] = Mdl::path_const(i);
         }
         wave_lds_sync();
         for (int tl = cnt - 1; tl >= 0; --tl) {
@@ -220,9 +233,10 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
             if (lane < NX) zs[lane] = xs[t * NX + lane];
             if (grp + 1 < nl) zs[(grp + 1) * W + idx] = zk_own;
             // v = c_u + G' mu   (lanes of the output layer's group)
-            double delta = blk[cuo + tl * cum];
+            const double* rowt = pool + tl * STRIDE;
+            double delta = rowt[cuo];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) delta = fma(blk[go[k] + tl * gm[k]], mu[k], delta);
+            for (int k = 0; k < NX; ++k) delta = fma(rowt[go[k]], mu[k], delta);
             double dkeep = 0.0, back0 = 0.0;
 #pragma unroll
             for (int k = MLP16_MAXL - 1; k >= 0; --k) {
@@ -242,9 +256,9 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
 #pragma unroll
             for (int q = 0; q < 8; ++q) gacc[q] += lds[pr[q]] * lds[pz[q]];
             // mu_t = c_x + F' mu_{t+1} + (d pi/dx)' v   (lanes idx < NX of group 0), then broadcast
-            double m_new = blk[cxo + tl * cxm] + back0;
+            double m_new = rowt[cxo] + back0;
 #pragma unroll
-            for (int k = 0; k < NX; ++k) m_new = fma(blk[fo[k] + tl * fm[k]], mu[k], m_new);
+            for (int k = 0; k < NX; ++k) m_new = fma(rowt[fo[k]], mu[k], m_new);
 #pragma unroll
             for (int i = 0; i < NX; ++i) mu[i] = readlane_f64(m_new, i);
             wave_lds_sync();                                      // (zs / ds are rewritten by the next step)

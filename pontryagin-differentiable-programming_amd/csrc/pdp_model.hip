@@ -452,7 +452,9 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
             } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
             if (pol->kind == PDP_POLICY_MLP && cp_mlp_variant() == 2 && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
-                const int rows16 = cp_mlp16_rows<Mdl>(T);
+                // batches beyond one trajectory per SIMD: rows sized for eight workgroups per CU, i.e. two wavefronts per SIMD that fill each other's gaps (PDP_CP_MLP_LDS_KB overrides)
+                static const int kb_env = [] { const char* e = std::getenv("PDP_CP_MLP_LDS_KB"); return e ? std::atoi(e) : 0; }();
+                const int rows16 = cp_mlp16_rows<Mdl>(T, kb_env > 0 ? kb_env : (B > 4 * device_cu_count() ? 20 : 40));
                 const size_t lds16 = sizeof(double) * (size_t)cp_mlp16_layout<Mdl>(T, rows16).total;
                 if (rows16 >= 1 && lds16 <= 160 * 1024) {
                     (void)hipFuncSetAttribute((const void*)cp_step_mlp16_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
