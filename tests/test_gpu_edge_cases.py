@@ -446,3 +446,50 @@ def test_oc_solver_small_state_many_controls_takes_the_generic_lq_kernel():
         x_star = (free + Phi @ u_star.reshape(-1)).reshape(T + 1, n)
         assert np.abs(npy(sol["control"])[i] - u_star).max() <= 1e-9 * (1 + np.abs(u_star).max())
         assert np.abs(npy(sol["state"])[i] - x_star).max() <= 1e-9 * (1 + np.abs(x_star).max())
+
+
+@pytest.mark.parametrize("T", [1, 7, 70])
+def test_large_batch_routes_with_ragged_sizes_equal_the_small_batch_routes(T):
+    """the rollout pre-pass of SysID.step / ControlPlanning.step (batches beyond two trajectories per SIMD: one lane per trajectory, then the given-trajectory kernels) on a
+    batch that is no multiple of anything, at horizons from a single step to more than a wavefront's lanes: the same numbers as the same trajectories sent in
+    sub-batches that take the in-kernel rollouts; the MLP step's two-wavefronts-per-SIMD layout likewise"""
+    from pdp_amd import JinEnv, runtime as rt, zoo
+    rng = np.random.default_rng(T)
+    B = 2048 + 131
+    cuts = [(0, 1000), (1000, 2048), (2048, B)]
+    # SysID.step
+    sid = zoo.get("cartpole", "sysid")
+    assert int(sid.lib.pdp_sysid_step_workspace_bytes(B, T)) > 0 and int(sid.lib.pdp_sysid_step_workspace_bytes(2048, T)) == 0
+    u = rng.uniform(-1, 1, (B, T, 1))
+    x0 = np.tile(np.array([0, 0.1, 0, 0.0]), (B, 1)) + 0.05 * rng.standard_normal((B, 4))
+    xobs = npy(sid.sysid_integrate(x0, u, np.array([1.0, 1.0, 1.0])))
+    th = np.array([1.2, 0.9, 1.1])
+    L, G = (npy(a) for a in sid.sysid_step(u, xobs, th))
+    for lo, hi in cuts:
+        l2, g2 = (npy(a) for a in sid.sysid_step(u[lo:hi], xobs[lo:hi], th))
+        assert np.array_equal(g2, G[lo:hi]) and np.abs(l2 - L[lo:hi]).max() <= 1e-14 * max(1e-300, np.abs(L).max())
+    # ControlPlanning.step, Lagrange policy (per-sample parameters)
+    cp = zoo.get("pendulum", "oc")
+    npiv = 4 if T >= 3 else 2
+    pol = rt.make_policy("poly", pivots=np.linspace(0, T, npiv))
+    p = npiv * cp.m
+    thp = 0.3 * rng.standard_normal((B, p))
+    xc0 = rng.uniform(-0.5, 0.5, (B, cp.n))
+    assert int(cp.lib.pdp_cp_step_workspace_bytes(B, T, __import__("ctypes").byref(pol), p)) == B * ((T + 1) * cp.n + T * cp.m + cp.n) * 8
+    Lc, Gc, Xc, Uc = (npy(a) for a in cp.cp_step(pol, p, xc0, thp, T, want_traj=True))
+    L0, G0 = (npy(a) for a in cp.cp_step(pol, p, xc0, thp, T))
+    assert np.array_equal(L0, Lc) and np.array_equal(G0, Gc)
+    for lo, hi in cuts:
+        l2, g2, x2, u2 = (npy(a) for a in cp.cp_step(pol, p, xc0[lo:hi], thp[lo:hi], T, want_traj=True))
+        assert np.array_equal(l2, Lc[lo:hi]) and np.array_equal(g2, Gc[lo:hi]) and np.array_equal(x2, Xc[lo:hi]) and np.array_equal(u2, Uc[lo:hi])
+    # ControlPlanning.step, tanh MLP (shared parameters): 20 KB layout above one trajectory per SIMD, 40 KB below
+    if T > 1:
+        qd = zoo.get("cartpole", "oc")
+        polm = rt.make_policy("mlp", layers=[qd.n, qd.n, qd.m])
+        pm = 2 * (qd.n * qd.n + qd.n) + qd.m * qd.n + qd.m          # three weight layers: n x n, n x n, m x n (+ biases)
+        thm = 0.1 * rng.standard_normal(pm)
+        xq = 0.2 * rng.standard_normal((B, qd.n))
+        Lm, Gm = (npy(a) for a in qd.cp_step(polm, pm, xq, thm, T))
+        for lo, hi in cuts[:2]:
+            l2, g2 = (npy(a) for a in qd.cp_step(polm, pm, xq[lo:hi], thm, T))
+            assert np.array_equal(l2, Lm[lo:hi]) and np.array_equal(g2, Gm[lo:hi])
