@@ -351,7 +351,25 @@ def other_configs(torch):
     x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (B, 1))
     xobs = mdl.sysid_integrate(x0, u5, np.array([1, 1, 1, 1, .4]))
     th5 = rt.dev(np.array([1.1, .95, 1.08, 1.03, .38]))
-    entry("C5a_quadrotor_sysid_step_T100_p5_B1024", B, _event_ms(torch, lambda: mdl.sysid_step(u5, xobs, th5)), flop=0.18e6, T=T, latency_bound=True, note="one GPU's shard of C5")
+    gd5 = None
+    try:        # the gradient-descent loop of Examples/SysID/*/..._PDP.py around this step, on the device (pdp_amd.irl.GDLoop: step + pdp_gd_update_batched, replayed as a hipGraph)
+        from pdp_amd.irl import GDLoop
+        import time as _time
+        lp = GDLoop(lambda th: mdl.sysid_step(u5, xobs, th), np.array([1.1, .95, 1.08, 1.03, .38]), 1e-8, max_steps=400)
+        lp.capture()
+        lp.run(20)
+        torch.cuda.synchronize()
+        t0_ = _time.perf_counter()
+        lp.run(200)
+        torch.cuda.synchronize()
+        ms_ = 1e3 * (_time.perf_counter() - t0_) / 200
+        r_ = lp.results()
+        gd5 = {"ms_per_iteration_hipgraph_replay": ms_, "traj_per_s": B / (ms_ * 1e-3), "learning_rate": 1e-8, "iterations_run": r_["iterations"],
+               "loss_first_last": [float(r_["loss_trace"][0]), float(r_["loss_trace"][-1])]}
+    except Exception as e_:
+        gd5 = {"error": repr(e_)[:300]}
+    entry("C5a_quadrotor_sysid_step_T100_p5_B1024", B, _event_ms(torch, lambda: mdl.sysid_step(u5, xobs, th5)), flop=0.18e6, T=T, latency_bound=True, note="one GPU's shard of C5",
+          extra={"gd_loop_wall_clock": gd5})
     # ---- C5b: neural-policy ControlPlanning.step, hidden [13,13] (p = 420), T=100, B=1024
     mdl = zoo.get("quadrotor", "oc")
     B, T, p = 1024, 100, 420

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--sigma", type=float, default=0.6)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--graph", action="store_true", help="keep the loop on the device (pdp_amd.irl.GDLoop: two launches per iteration, replayed as a hipGraph); equal horizons only")
     ap.add_argument("--data", default=None, help="<stem>_iodata.mat in the reference's schema (default: the stored data of --system)")
     a = ap.parse_args()
     env, dt = zoo.make_env(a.system, "sysid")
@@ -54,7 +55,19 @@ def main():
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2
     loss_trace, parameter_trace = [], []
     t0 = time.time()
-    for k in range(a.iters):
+    if a.graph:
+        from pdp_amd import runtime as rt
+        from pdp_amd.irl import GDLoop
+        mdl = sid.model()
+        u_d, x_d = rt.dev(np.stack(batch_inputs)), rt.dev(np.stack(batch_states))
+        loop = GDLoop(lambda th: mdl.sysid_step(u_d, x_d, th), theta, a.lr, max_steps=a.iters + 8)
+        loop.run(a.iters)
+        r = loop.results()
+        loss_trace, parameter_trace = list(r["loss_trace"][:a.iters]), list(r["parameter_trace"][:a.iters])
+        theta = parameter_trace[-1]
+        for k in range(0, a.iters, max(1, a.iters // 10)):
+            print("iter %5d  loss %.6e  theta %s" % (k, loss_trace[k], np.array2string(parameter_trace[k], precision=4)))
+    for k in range(0 if not a.graph else a.iters, a.iters):
         loss, dp = sid.step(batch_inputs, batch_states, theta)
         theta = theta - a.lr * dp
         loss_trace.append(loss)

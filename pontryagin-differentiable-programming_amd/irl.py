@@ -1,4 +1,5 @@
-"""The reference's IRL loop kept on the device and replayed as ONE hipGraph per iteration.
+"""The reference's gradient-descent loops kept on the device and replayed as ONE hipGraph per iteration: IRLLoop (solve + PDP gradient + update) and GDLoop (any fused
+step + update: SysID.step, ControlPlanning.step).
 
 Reference loop (Examples/IRL/cartpole/cartpole_PDP.py:52-80, Examples/IRL/quadrotor/uav_PDP.py:52-62): at the current parameter solve every demonstration's OC problem
 (`OCSys.ocSolver`), differentiate the solutions (`getAuxSys` + `lqrSolver`), chain rule against the demonstrations, `theta <- theta - lr * mean gradient`.  Here an
@@ -15,33 +16,107 @@ import numpy as np
 from . import runtime as rt
 
 
-class IRLLoop:
+class _DeviceLoop:
+    """what the device-resident loops share: the parameter vector, its step, traces and counters at fixed device addresses, graph capture and replay"""
+
+    def _init_state(self, p, theta0, lr, max_steps):
+        torch = rt.torch_cuda()
+        f64 = dict(dtype=torch.float64, device="cuda")
+        self.lr = float(lr)
+        self.theta = rt.dev(np.asarray(theta0, dtype=float).reshape(-1)).clone()
+        assert self.theta.numel() == p
+        self.dtheta = torch.zeros(p, **f64)
+        self.max_steps = int(max_steps)
+        self.loss_trace = torch.zeros(self.max_steps, **f64)
+        self.parameter_trace = torch.zeros(self.max_steps, p, **f64)
+        # device-side counters (pdp_gd_update_batched): iterations done (indexes the traces) | OC solves that did not converge | trajectories on which a Riccati sweep
+        # reported numerical trouble | Newton iterations of all OC solves
+        self.counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+        self.graph = None
+        self.steps_done = 0
+
+    def _started(self):
+        return True
+
+    def start(self):
+        pass
+
+    def capture(self, warmup=2):
+        """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for)"""
+        torch = rt.torch_cuda()
+        if not self._started():
+            self.start()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step()
+                self.steps_done += 1
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step()                     # (capturing executes nothing)
+        return self
+
+    def run(self, n, graphed=True):
+        """n more iterations: graph replays (capture() first) or eager steps.  Returns the number of iterations done so far."""
+        if not self._started():
+            self.start()
+            n -= 1
+        assert self.steps_done + n <= self.max_steps, "traces are full: raise max_steps"
+        if graphed:
+            if self.graph is None:
+                before = self.steps_done
+                self.capture()
+                n -= self.steps_done - before
+            for _ in range(max(n, 0)):
+                self.graph.replay()
+        else:
+            for _ in range(max(n, 0)):
+                self.step()
+        self.steps_done += max(n, 0)
+        return self.steps_done
+
+    def results(self):
+        """host copies (one synchronisation): the reference's result fields + the health counters"""
+        k, unconverged, trouble, newton = (int(v) for v in self.counters.cpu().numpy())
+        return {"loss_trace": self.loss_trace[:k].cpu().numpy(), "parameter_trace": self.parameter_trace[:k].cpu().numpy(), "learning_rate": self.lr,
+                "iterations": k, "unconverged_solves": unconverged, "riccati_trouble": trouble, "newton_iterations": newton}
+
+
+class GDLoop(_DeviceLoop):
+    """The gradient-descent loop of the reference's SysID and planning drivers (Examples/SysID/*/..._PDP.py, PDP.py:1261-1296: loss, dp = step(...); parameter -= lr * dp
+    with the batch means of PDP.py:1293-1294) around ANY fused step: step_fn(theta [p], a CUDA tensor that is updated in place) -> (loss [B], grad [B, p]) CUDA tensors,
+    e.g.  lambda th: mdl.sysid_step(u, x_obs, th)  or  lambda th: mdl.cp_step(pol, p, x0, th, T).  Two launches per iteration (the step and pdp_gd_update_batched), no host
+    synchronisation, recordable as a hipGraph."""
+
+    def __init__(self, step_fn, theta0, lr, max_steps=100000):
+        self.step_fn = step_fn
+        self._init_state(int(np.asarray(theta0).size), theta0, lr, max_steps)
+
+    def step(self):
+        loss, grad = self.step_fn(self.theta)[:2]
+        rt.gd_update(loss, grad, self.lr, self.theta, self.dtheta, self.counters, loss_trace=self.loss_trace, parameter_trace=self.parameter_trace)
+
+
+class IRLLoop(_DeviceLoop):
     """mdl: runtime.ModelLib of an OC model (PDP.OCSys.model() or zoo.get(system, "irl")); demo_x [B, T+1, n], demo_u [B, T, m]: the demonstrations; theta0 [p]: the initial
     parameter (shared by all demonstrations, as in the reference); lr: learning rate; record: "full" (states, controls and multipliers are predicted) or "primal"
     (states and controls only: cheaper, enough where the multipliers move little per step); max_steps: length of the on-device traces."""
 
     def __init__(self, mdl, demo_x, demo_u, theta0, lr, record="full", tol=1e-10, max_iter=300, max_steps=100000):
-        torch = rt.torch_cuda()
         assert record in ("full", "primal")
-        self.mdl, self.lr, self.tol, self.max_iter, self.primal = mdl, float(lr), float(tol), int(max_iter), record == "primal"
+        self.mdl, self.tol, self.max_iter, self.primal = mdl, float(tol), int(max_iter), record == "primal"
         self.demo_x, self.demo_u = rt.dev(demo_x), rt.dev(demo_u)
         self.B, self.T = int(self.demo_u.shape[0]), int(self.demo_u.shape[1])
         assert self.demo_x.shape == (self.B, self.T + 1, mdl.n) and self.demo_u.shape == (self.B, self.T, mdl.m)
-        f64 = dict(dtype=torch.float64, device="cuda")
         self.x0 = self.demo_x[:, 0].contiguous()
-        self.theta = rt.dev(np.asarray(theta0, dtype=float).reshape(-1)).clone()
-        assert self.theta.numel() == mdl.p
-        self.dtheta = torch.zeros(mdl.p, **f64)
-        self.max_steps = int(max_steps)
-        self.loss_trace = torch.zeros(self.max_steps, **f64)
-        self.parameter_trace = torch.zeros(self.max_steps, mdl.p, **f64)
-        # device-side counters (pdp_gd_update_batched): iterations done (indexes the traces) | OC solves that did not converge | trajectories on which the Riccati sweep
-        # reported numerical trouble | Newton iterations of all OC solves (the cold ones of start() included)
-        self.counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+        self._init_state(mdl.p, theta0, lr, max_steps)
         self.sol = None                                                            # (x, u, lam) of the current parameter: the solver works in place on them
         self.bufs = {}                                                             # outputs of the gradient unit (fixed addresses)
-        self.graph = None
-        self.steps_done = 0
+
+    def _started(self):
+        return self.sol is not None
 
     # ---- one iteration, no host synchronisation anywhere
     def _update(self, out, sol):
@@ -67,45 +142,7 @@ class IRLLoop:
                                  predict=dict(dtheta=self.dtheta, record=self.bufs["predict_record"], primal=self.primal))
         self._update(self._gradient(), s)
 
-    def capture(self, warmup=2):
-        """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for)"""
-        torch = rt.torch_cuda()
-        if self.sol is None:
-            self.start()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.step()
-                self.steps_done += 1
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.step()
-        self.steps_done += 0            # (capturing executes nothing)
-        return self
-
-    def run(self, n, graphed=True):
-        """n more iterations: graph replays (capture() first) or eager steps.  Returns the number of iterations done so far."""
-        if self.sol is None:
-            self.start()
-            n -= 1
-        assert self.steps_done + n <= self.max_steps, "traces are full: raise max_steps"
-        if graphed:
-            if self.graph is None:
-                before = self.steps_done
-                self.capture()
-                n -= self.steps_done - before
-            for _ in range(max(n, 0)):
-                self.graph.replay()
-        else:
-            for _ in range(max(n, 0)):
-                self.step()
-        self.steps_done += max(n, 0)
-        return self.steps_done
-
     def results(self):
-        """host copies (one synchronisation): the reference's result fields + the health counters"""
-        k, unconverged, trouble, newton = (int(v) for v in self.counters.cpu().numpy())
-        return {"loss_trace": self.loss_trace[:k].cpu().numpy(), "parameter_trace": self.parameter_trace[:k].cpu().numpy(), "learning_rate": self.lr,
-                "iterations": k, "unconverged_solves": unconverged, "riccati_trouble": trouble, "newton_iterations_per_solve": newton / max(1, k * self.B)}
+        r = super().results()
+        r["newton_iterations_per_solve"] = r["newton_iterations"] / max(1, r["iterations"] * self.B)
+        return r

@@ -131,3 +131,36 @@ def test_one_launch_parameter_update(B, p):
         big = torch.zeros(4, 1025, dtype=torch.float64, device="cuda")
         with pytest.raises(RuntimeError):
             rt.gd_update(big[:, 0].contiguous(), big[:, :1024], lr, torch.zeros(1024, dtype=torch.float64, device="cuda"), torch.zeros(1024, dtype=torch.float64, device="cuda"), cnt)
+
+
+def test_device_resident_gd_loop_for_sysid():
+    """pdp_amd.irl.GDLoop around SysID.step (the loop of Examples/SysID/*/..._PDP.py: loss, dp = step(...); parameter -= lr * dp): graph replays = eager iterations bit for
+    bit, both = the host-driven loop through PDP.SysID.step to rounding, and the parameter moves towards the true one"""
+    sys.path.insert(0, ROOT)
+    from pdp_amd import PDP, runtime as rt, zoo
+    from pdp_amd.irl import GDLoop
+    d = np.load(os.path.join(ROOT, "tests", "golden", "iodata_robotarm.npz"))
+    inputs, states, th_true = d["inputs"], d["states"], d["true_parameter"]
+    env, dt = zoo.make_env("robotarm", "sysid")
+    sid = PDP.SysID("robotarm")
+    sid.setAuxvarVariable(env.dyn_auxvar); sid.setStateVariable(env.X); sid.setControlVariable(env.U); sid.setDyn(env.X + dt * env.f)
+    mdl = sid.model()
+    theta0 = th_true + 0.1 * np.cos(np.arange(th_true.size))
+    u_d, x_d = rt.dev(inputs), rt.dev(states)
+    n_it, lr = 25, 1e-4
+    runs = {}
+    for kind in ("graph", "eager"):
+        loop = GDLoop(lambda th: mdl.sysid_step(u_d, x_d, th), theta0, lr, max_steps=64)
+        loop.run(n_it, graphed=(kind == "graph"))
+        runs[kind] = loop.results()
+        assert runs[kind]["iterations"] >= n_it
+    g, e = runs["graph"], runs["eager"]
+    assert np.array_equal(g["loss_trace"][:n_it], e["loss_trace"][:n_it]) and np.array_equal(g["parameter_trace"][:n_it], e["parameter_trace"][:n_it])
+    theta, trace = theta0.copy(), []
+    for k in range(n_it):
+        loss, dp = sid.step([inputs[i] for i in range(inputs.shape[0])], [states[i] for i in range(states.shape[0])], theta)
+        theta = theta - lr * dp
+        trace.append((loss, theta.copy()))
+    assert np.allclose(g["loss_trace"][:n_it], [a for a, _ in trace], rtol=1e-11, atol=0)
+    assert np.abs(g["parameter_trace"][:n_it] - np.array([b for _, b in trace])).max() <= 1e-12 * max(1.0, np.abs(theta0).max())
+    assert g["loss_trace"][n_it - 1] < g["loss_trace"][0]
