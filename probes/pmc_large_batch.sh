@@ -1,0 +1,68 @@
+#!/bin/bash
+# Round 4: counters behind the large-batch routes.  SysID.step, quadrotor T = 100, 8192 trajectories on one GPU: the in-kernel rollout (PDP_SYSID_PREPASS=0,
+# sysid_step_kernel<1, false>) against pre-pass + given-trajectory kernel (sysid_integrate_kernel + sysid_step_kernel<1, true>); ControlPlanning.step with the MLP [13, 13],
+# 8192 trajectories: 40 KB against 20 KB of LDS per workgroup.  Two SQ passes (8 counters each) and the HBM passes (FETCH_SIZE / WRITE_SIZE, separate) per variant.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/pmc_lb
+cat > /tmp/lb_work.py <<'PY'
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+import torch
+from pdp_amd import JinEnv, zoo, runtime as rt
+which = sys.argv[1]
+rng = np.random.default_rng(0)
+B, T = 8192, 100
+if which == "sysid":
+    mdl = zoo.get("quadrotor", "sysid")
+    u = rng.uniform(-1, 1, (B, T, 4)) + 2.5
+    x0 = np.tile(np.array([-8, -6, 9.0, 0, 0, 0] + JinEnv.toQuaternion(0, [1, -1, 1]) + [0, 0, 0]), (B, 1))
+    x0[:, :3] += rng.standard_normal((B, 3))
+    xobs = mdl.sysid_integrate(x0, u, np.array([1, 1, 1, 1, .4]))
+    ud = torch.as_tensor(u, device="cuda")
+    th = np.array([1.1, 0.95, 1.08, 1.03, 0.38])
+    for _ in range(4):
+        mdl.sysid_step(ud, xobs, th)
+else:
+    mdl = zoo.get("quadrotor", "oc")
+    pol = rt.make_policy("mlp", layers=[13, 13, 4])
+    thp = rt.dev(0.1 * rng.standard_normal(420))
+    x0 = np.zeros((B, 13)); x0[:, :3] = rng.uniform(-2, 2, (B, 3)); x0[:, 6] = 1
+    x0d = rt.dev(x0)
+    for _ in range(4):
+        mdl.cp_step(pol, 420, x0d, thp, T)
+torch.cuda.synchronize()
+PY
+run() {   # tag, workload, env assignment
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" \
+             "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" \
+             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    env $3 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_lb/$1_$i -o p -- python /tmp/lb_work.py $2 > gpurun_out/pmc_lb/$1_$i.log 2>&1
+  done
+}
+run sysid_inkernel sysid PDP_SYSID_PREPASS=0
+run sysid_prepass sysid PDP_SYSID_PREPASS=1
+run mlp_40kb mlp PDP_CP_MLP_LDS_KB=40
+run mlp_20kb mlp PDP_CP_MLP_LDS_KB=20
+python - <<'PY'
+import csv, glob, collections, json
+out = collections.OrderedDict()
+for tag in ("sysid_inkernel", "sysid_prepass", "mlp_40kb", "mlp_20kb"):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob("gpurun_out/pmc_lb/%s_*/**/p_counter_collection.csv" % tag, recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "sysid" in k or "mlp16" in k:
+                short = "sysid_integrate_kernel" if "sysid_integrate" in k else ("sysid_step_kernel<given>" if "Lb1E" in k or ", true>" in k else ("sysid_step_kernel" if "sysid_step" in k else "cp_step_mlp16_kernel"))
+                per[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[tag] = {kern: {c: sum(v[-3:]) / len(v[-3:]) for c, v in cs.items()} for kern, cs in per.items()}
+for tag, kd in out.items():
+    for kern, cs in kd.items():
+        if "SQ_WAVE_CYCLES" in cs and "SQ_BUSY_CYCLES" in cs and cs["SQ_BUSY_CYCLES"] > 0:
+            cs["waves_per_busy_simd_cycle_x4"] = cs["SQ_WAVE_CYCLES"] / cs["SQ_BUSY_CYCLES"]
+        if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+            cs["hbm_bytes_per_launch"] = 1024.0 * (2.0 * cs.get("FETCH_SIZE", 0.0) + cs.get("WRITE_SIZE", 0.0))      # gfx950: FETCH_SIZE doubled (guide's correction), KB
+json.dump(out, open("gpurun_out/pmc_lb/summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
