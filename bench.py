@@ -143,17 +143,44 @@ def cpu_baseline(budget_s=16.0):
                       (best[2], best[1], "rebuilt on this host with gcc -O3 -march=native" if native else "portable -O2 build", r1, best[1], best[0], 100 * eff)}
 
 
+class Ms(float):
+    """a duration in ms that remembers which timing windows (see _event_ms) it was measured in; sums keep the windows of their terms"""
+
+    def __new__(cls, v, wins=()):
+        o = float.__new__(cls, v)
+        o.wins = tuple(wins)
+        return o
+
+    def __add__(self, other):
+        return Ms(float(self) + float(other), self.wins + tuple(getattr(other, "wins", ())))
+
+    __radd__ = __add__
+
+
+WINDOWS = []        # one record per _event_ms call: host clocks around its timed repetitions (PDP_BENCH_WINDOWS=<file>: written there at the end of the run)
+
+
+def _clocks():
+    return {"monotonic": time.clock_gettime_ns(time.CLOCK_MONOTONIC), "boottime": time.clock_gettime_ns(time.CLOCK_BOOTTIME), "realtime": time.time_ns()}
+
+
 def _event_ms(torch, fn, reps=10, warm=2):
-    """median HIP-event duration of fn() on the current stream"""
+    """median HIP-event duration of fn() on the current stream.  The host clocks around the timed repetitions are kept (WINDOWS): probes/rocprof_match.py finds the
+    kernel dispatches of a rocprofv3 --kernel-trace of the same run that fall into each window and checks every figure of the bench line against them."""
     for _ in range(warm):
         fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    torch.cuda.synchronize()
+    c0 = _clocks()
     for a, b in ev:
         a.record()
         fn()
         b.record()
     torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+    c1 = _clocks()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    WINDOWS.append({"window": len(WINDOWS), "reps": reps, "event_ms_median": ms, "t0": c0, "t1": c1})
+    return Ms(ms, (len(WINDOWS) - 1,))
 
 
 def other_configs(torch):
@@ -168,7 +195,7 @@ def other_configs(torch):
         """flop: SURVEY.md section 8d's figure for the unit (dense count of the reference formulation).  latency_bound: the kernel runs one serial chain
         per trajectory far below any throughput roofline (a fraction of the MFMA peak of 0.2 - 5 % says nothing): it is reported as time per time step
         of one wavefront's chain (ns_per_step: kernel time / T / rounds of one trajectory per SIMD) instead of a roofline fraction."""
-        e = {"batch": B, "kernel_ms": ms, "traj_per_s": B / (ms * 1e-3)}
+        e = {"batch": B, "kernel_ms": float(ms), "traj_per_s": B / (ms * 1e-3), "timing_windows": list(getattr(ms, "wins", ()))}
         if flop is not None:
             tf = flop * B / (ms * 1e-3) / 1e12
             e.update(algorithmic_flop_per_traj=flop)
@@ -402,7 +429,7 @@ def other_configs(torch):
     return res
 
 
-def scaling_configs(torch, dist, world, rank, steps):
+def scaling_configs(torch, dist, world, rank, steps, verify=False):
     """BASELINE.json configs[3] / configs[4] as they are DEFINED: a fixed total batch (C4: 4096 rocket trajectories, C5: 8192 quadrotor
     trajectories) cut into contiguous shards over the N ranks of this run (strong scaling; N = 1 runs the whole batch on one GPU), every rank
     running the same fused kernels on its shard, one RCCL all-gather of the per-sample [B/N, p+1] (gradient | loss) rows per step on a side
@@ -453,14 +480,43 @@ def scaling_configs(torch, dist, world, rank, steps):
         if distributed:
             dist.barrier()
         dt = time.perf_counter() - t0
-        stats = torch.tensor([kern_ms, exch_us if exch_us is not None else 0.0, dt / steps * 1e3, float(b), exch_ar_us if exch_ar_us is not None else 0.0],
+        stats = torch.tensor([float(kern_ms), exch_us if exch_us is not None else 0.0, dt / steps * 1e3, float(b), exch_ar_us if exch_ar_us is not None else 0.0],
                              dtype=torch.float64, device="cuda")
         if distributed:
             allr = torch.empty((world, 5), dtype=torch.float64, device="cuda")
-            dist.all_gather_into_tensor(allr, stats)
+            parallel.all_gather_into(allr, stats)
         else:
             allr = stats[None]
         allr = allr.cpu().numpy()
+        check = None
+        if verify:
+            # --verify-exchange: the rows every rank holds after ONE exchange == the single-process kernel on the whole batch, and the all-reduce form of the
+            # exchange == the mean of those rows (the reference's batch mean, PDP.py:1293-1294).  Ragged totals take gather_packed's padded route.
+            def rows_of(unit_, b_, buf=None):
+                out = unit_(buf)
+                if out is None:
+                    return buf
+                pk = torch.empty((b_, p + 1), dtype=torch.float64, device="cuda")
+                pk[:, :p].copy_(out[1])
+                pk[:, p].copy_(out[0])
+                return pk
+            mine = rows_of(unit, b, torch.zeros((b, p + 1), dtype=torch.float64, device="cuda"))
+            rows = parallel.gather_packed(mine, B_total) if distributed else mine
+            mean_ar = parallel.allreduce_mean_packed(mine, B_total)
+            full = make_unit(np.random.default_rng(1234), B_total, 0, B_total)
+            ref = rows_of(full, B_total, torch.zeros((B_total, p + 1), dtype=torch.float64, device="cuda"))
+            scale = float(ref.abs().amax())
+            mref = ref.mean(dim=0)
+            check = torch.tensor([1.0 if torch.equal(rows, ref) else 0.0, float((rows - ref).abs().amax()) / scale,
+                                  float(((mean_ar - mref).abs() / mref.abs().clamp_min(1e-300)).amax()), float(rows.shape[0])], dtype=torch.float64, device="cuda")
+            if distributed:
+                allc = torch.empty((world, 4), dtype=torch.float64, device="cuda")
+                parallel.all_gather_into(allc, check)
+            else:
+                allc = check[None]
+            allc = allc.cpu().numpy()
+            check = {"gathered_rows": int(allc[0, 3]), "gathered_rows_bit_equal_to_single_process_per_rank": [bool(v) for v in allc[:, 0]],
+                     "gathered_rows_max_rel_diff_per_rank": [float(v) for v in allc[:, 1]], "allreduce_mean_max_rel_err_per_rank": [float(v) for v in allc[:, 2]]}
         step_ms = float(allr[:, 2].max())
         tf = flop * B_total / (step_ms * 1e-3) / 1e12
         res[name] = {"total_batch": B_total, "shard_per_rank": [int(v) for v in allr[:, 3]], "scaling": "strong", "steps": steps,
@@ -469,7 +525,9 @@ def scaling_configs(torch, dist, world, rank, steps):
                      "exchange_allreduce_us_per_rank": [float(v) for v in allr[:, 4]] if distributed else None,
                      "exchange_allreduce_bytes": int((p + 1) * 8) if distributed else 0,
                      "ms_per_step": step_ms, "traj_per_s": B_total / (step_ms * 1e-3),
-                     "algorithmic_flop_per_traj": flop, "note": note}
+                     "algorithmic_flop_per_traj": flop, "note": note, "timing_windows": list(getattr(kern_ms, "wins", ()))}
+        if check is not None:
+            res[name]["verified"] = check
         if executed_flop is None:
             res[name]["achieved_tflops_all_gpus"] = tf
         if latency_bound:       # one serial chain per trajectory: time per time step of a wavefront's chain instead of a roofline fraction (see other_configs)
@@ -513,6 +571,8 @@ def scaling_configs(torch, dist, world, rank, steps):
         thp, pol = rt.dev(0.5 * rng.standard_normal(18)), rt.make_policy("poly", pivots=np.linspace(0, T4, 6))
         return lambda packed: mdl.cp_step(pol, 18, x0d, thp, T4)
 
+    if verify:          # a total the ranks cannot share evenly: shards differ by one trajectory, the exchange pads (parallel.gather_loss_grad)
+        run("ragged_rocket_oc_unit_T100_p10_B1001", 1001, 10, c4_oc, 6.9e6, "--verify-exchange only: ragged shards")
     run("C4_rocket_oc_unit_T100_p10_B4096", 4096, 10, c4_oc, 6.9e6, "BASELINE configs[3], U-OC: rollout + costates + aux system + Riccati + gradient")
     run("C4_rocket_cp_step_T100_p18_B4096", 4096, 18, c4_cp, 0.95e6, "BASELINE configs[3], U-CP: ControlPlanning.step, Lagrange policy", T=T4, latency_bound=True)
 
@@ -554,6 +614,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-scaling-configs", action="store_true", help="skip the sharded C4 / C5 measurements (BASELINE configs[3], configs[4])")
+    ap.add_argument("--verify-exchange", action="store_true",
+                    help="after timing, check on every rank that the exchanged rows equal the single-process kernel on the whole batch and that the all-reduce form "
+                         "gives their mean (adds a ragged total); results under `verified`")
     args = ap.parse_args()
 
     import torch
@@ -567,11 +630,16 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
+    # PDP_DIST_BACKEND (default "nccl" == RCCL on ROCm) / PDP_DIST_SAME_DEVICE=1: the TEST mode of the multi-rank path - N ranks share device 0 and exchange over gloo
+    # (staged through host memory, parallel.host_staged), so that sharding, packed rows, the side-stream exchange and the per-rank statistics run on a one-GPU box.
+    # A line produced that way says so (config.dist_backend / ranks_share_one_device) and is not a scaling measurement.
+    backend = os.environ.get("PDP_DIST_BACKEND", "nccl")
+    same_device = os.environ.get("PDP_DIST_SAME_DEVICE", "0") == "1"
+    torch.cuda.set_device(0 if same_device else local)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, T = args.batch, HORIZON
     mdl = zoo.get("quadrotor", "irl")
@@ -600,6 +668,7 @@ def main():
 
     # ---- kernel-only timing with HIP events on the launch stream (roofline.achieved)
     kern_ms = _event_ms(torch, lambda: mdl.oc_pdp_grad(u, theta, dx, du, x0=x0, buffers=bufs, packed=True), reps=min(max(args.steps, 5), 20), warm=0)
+    headline_window = kern_ms.wins[0]
     exch_us = None
     if distributed:       # the exchange alone, blocking, on the compute stream: what a non-overlapped step would add
         pk = og.buffers[0]
@@ -609,6 +678,7 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    c0 = _clocks()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -618,29 +688,48 @@ def main():
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
+    WINDOWS.append({"window": len(WINDOWS), "reps": args.steps, "event_ms_median": dt / args.steps * 1e3, "t0": c0, "t1": _clocks(), "what": "the timed region (K steps)"})
+    timed_window = len(WINDOWS) - 1
     per_rank = None
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        parallel.all_reduce_(tmax, op=dist.ReduceOp.MAX)
         mine = torch.tensor([kern_ms, exch_us, dt / args.steps * 1e3], dtype=torch.float64, device="cuda")
         allr = torch.empty((world, 3), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(allr, mine)
+        parallel.all_gather_into(allr, mine)
         per_rank = {"kernel_ms": allr[:, 0].tolist(), "exchange_us": allr[:, 1].tolist(), "ms_per_step": allr[:, 2].tolist()}
         dt = float(tmax.item())
+        if args.verify_exchange:
+            # the headline exchange: block r of the gathered rows == the kernel run here on rank r's inputs (weak scaling: rank r owns synth_inputs(B, 1000 + r))
+            rows = og.result((og.k - 1) % 2).clone()
+            ok, worst = True, 0.0
+            for r in range(world):
+                xr, ur, dxr, dur = (torch.as_tensor(a, device="cuda") for a in synth_inputs(B, 1000 + r))
+                ref = mdl.oc_pdp_grad(ur, theta, dxr, dur, x0=xr, packed=True)["packed"]
+                ok = ok and bool(torch.equal(rows[r * B:(r + 1) * B], ref))
+                worst = max(worst, float((rows[r * B:(r + 1) * B] - ref).abs().amax() / ref.abs().amax()))
+            mean_ar = parallel.allreduce_mean_packed(og.buffers[(og.k - 1) % 2], world * B)
+            mref = rows.mean(dim=0)
+            chk = torch.tensor([1.0 if ok else 0.0, worst, float(((mean_ar - mref).abs() / mref.abs().clamp_min(1e-300)).amax())], dtype=torch.float64, device="cuda")
+            allc = torch.empty((world, 3), dtype=torch.float64, device="cuda")
+            parallel.all_gather_into(allc, chk)
+            per_rank["verified"] = {"gathered_rows": int(rows.shape[0]), "gathered_rows_bit_equal_to_single_process_per_rank": [bool(v) for v in allc[:, 0].tolist()],
+                                    "gathered_rows_max_rel_diff_per_rank": allc[:, 1].tolist(), "allreduce_mean_max_rel_err_per_rank": allc[:, 2].tolist()}
 
     scal = None
     if not args.no_scaling_configs and B == BATCH:
         try:
-            scal = scaling_configs(torch, dist, world, rank, args.steps)
+            scal = scaling_configs(torch, dist, world, rank, args.steps, verify=args.verify_exchange)
         except Exception as ex:              # the headline line must survive a failure of the side measurements (all ranks fail alike: no collective is left half-way)
             scal = {"error": repr(ex)}
 
     if rank == 0:
         value = world * B * args.steps / dt
-        traffic = None
+        traffic, traffic_cal = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and B == BATCH:
-            traffic = json.load(open(tf)).get("oc_pdp_fused_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tf))
+            traffic, traffic_cal = tj.get("oc_pdp_fused_kernel_hbm_bytes_per_launch"), tj.get("calibration")
         ach_tflops = FLOP_PER_TRAJ * B / (kern_ms * 1e-3) / 1e12
         ach_gbps = BYTES_PER_TRAJ * B / (kern_ms * 1e-3) / 1e9
         kres = None
@@ -660,12 +749,15 @@ def main():
             "dtype": "f64", "data": "synthetic (seeded random initial poses and near-hover thrust sequences; no dataset exists for this path)",
             "config": {"workload": "C3: quadrotor OC/IRL unit n=13 m=4 p=9 T=50, batch=%d trajectories per GPU, shared theta" % B,
                        "batch_per_gpu": B, "horizon": T,
-                       "exchange": "all_gather([B,10] gradient|loss rows) over RCCL on a side stream, overlapped with the next step's kernel" if distributed else "none (1 GPU)"},
+                       "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the next step's kernel" %
+                                    ("RCCL" if backend == "nccl" else backend + " (staged through host memory: test mode)")) if distributed else "none (1 GPU)",
+                       "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and distributed)},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_resources": kres,
+                         "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_calibration": traffic_cal, "kernel_resources": kres,
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
-                                           "(probes/profile_bench.sh), not collected in this run", "kernel_ms": kern_ms,
-                         "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B,
+                                           "(probes/profile_r05.sh; counter values scaled by the factors measured on known byte counts in this repository's access "
+                                           "shapes, probes/pmc_calibrate.hip: `traffic_calibration`), not collected in this run", "kernel_ms": float(kern_ms),
+                         "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B, "timing_windows": [headline_window], "timed_region_window": timed_window,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,
                                                                "frac": FLOP_PER_TRAJ_SCHUR * B / (kern_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                                                "note": "the kernel solves the Schur-complement form (one m x m system per step, not two n x n "
@@ -692,6 +784,8 @@ def main():
             except Exception as ex:          # the headline line must survive a failure of the side measurements
                 res["other_configs"] = {"error": repr(ex)}
         print(json.dumps(res))
+        if os.environ.get("PDP_BENCH_WINDOWS"):
+            json.dump({"windows": WINDOWS, "line": res}, open(os.environ["PDP_BENCH_WINDOWS"], "w"))
     if distributed:
         dist.destroy_process_group()
 

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--sigma", type=float, default=0.3, help="initial parameter = true + U(-sigma/2, sigma/2)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--init", default=None, help="initial parameter: comma-separated values or a .npy file (default: true + U(-sigma/2, sigma/2)); e.g. row 0 of a stored "
+                                                 "parameter_trace to replay the reference's run")
     ap.add_argument("--out", default=None)
     ap.add_argument("--record", default="full", choices=["full", "primal"],
                     help="what the gradient unit keeps for the next solve's predicted start: states, controls and multipliers (full) or states and controls only "
@@ -71,6 +73,9 @@ def main():
     T = demo_u.shape[1]
     rng = np.random.default_rng(a.seed)
     theta = true_parameter + a.sigma * rng.random(true_parameter.size) - a.sigma / 2
+    if a.init is not None:
+        theta = np.load(a.init).astype(float).reshape(-1) if a.init.endswith(".npy") else np.array([float(v) for v in a.init.split(",")])
+        assert theta.size == true_parameter.size, "--init: %d values for %d parameters" % (theta.size, true_parameter.size)
     loss_trace, parameter_trace = [], []
     warm, predict, theta_prev = None, None, None
     fused = oc.model().n <= 16 and oc.model().m <= 4 and oc.model().m + oc.model().p <= 16      # the kernels that keep the sensitivities

@@ -429,11 +429,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
                         dxb[sg * NX + i] = dx;
                         s0[i * TS + t + 1] = xb[(t + 1) * NX + i] + dx;
-                        if (i < NU) {
+                        // control rows: lane (stage, i) takes rows i, i + NX, ... - one row per lane when NU <= NX, and every row is still written when a model has more
+                        // controls than states (round-4 advice: rows >= NX used to be skipped)
+#pragma unroll
+                        for (int iu = i; iu < NU; iu += NX) {
                             double du = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + i * NP + j], dth[j], du);
-                            s0[OU + i * TS + t] = ub[t * NU + i] + du;
+                            for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + iu * NP + j], dth[j], du);
+                            s0[OU + iu * TS + t] = ub[t * NU + iu] + du;
                         }
                     }
                     wave_lds_sync();

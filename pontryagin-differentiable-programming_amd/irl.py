@@ -42,10 +42,12 @@ class _DeviceLoop:
         pass
 
     def capture(self, warmup=2):
-        """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for)"""
+        """record step() as a graph (after `warmup` eager iterations on a side stream, as torch asks for).  The warm-up iterations are real iterations of the loop
+        (they advance theta, the traces and steps_done): run() passes the number it still owes so that a short run is never overshot."""
         torch = rt.torch_cuda()
         if not self._started():
             self.start()
+        assert self.steps_done + warmup <= self.max_steps, "traces are full: raise max_steps"
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -65,10 +67,11 @@ class _DeviceLoop:
             n -= 1
         assert self.steps_done + n <= self.max_steps, "traces are full: raise max_steps"
         if graphed:
-            if self.graph is None:
+            if self.graph is None and n > 0:
                 before = self.steps_done
-                self.capture()
+                self.capture(warmup=min(2, n))
                 n -= self.steps_done - before
+                assert n >= 0
             for _ in range(max(n, 0)):
                 self.graph.replay()
         else:

@@ -10,6 +10,35 @@ import torch
 import torch.distributed as dist
 
 
+def host_staged(t):
+    """gloo moves host memory: CUDA tensors are staged through it.  That is the TEST mode of the multi-rank path (two ranks sharing one GPU, bench.py with
+    PDP_DIST_BACKEND=gloo PDP_DIST_SAME_DEVICE=1: sharding, packing, ordering and overlap logic run, RCCL does not); "nccl" (= RCCL) takes device pointers as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_gather_into(out, inp):
+    """dist.all_gather_into_tensor on the current stream; through host memory on gloo (see host_staged)"""
+    if host_staged(inp):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, inp.contiguous().cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+    return out
+
+
+def all_reduce_(t, op=None):
+    """dist.all_reduce in place; through host memory on gloo"""
+    op = dist.ReduceOp.SUM if op is None else op
+    if host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def shard_bounds(n_total, world, rank):
     """contiguous block partition; the first (n_total % world) ranks get one extra trajectory"""
     base, rem = divmod(n_total, world)
@@ -32,10 +61,9 @@ def gather_loss_grad(loss, grad, n_total=None):
     world, rank = dist.get_world_size(), dist.get_rank()
     b, p = grad.shape
     if n_total is None:
-        sizes = torch.tensor([b], device=grad.device)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)
-        counts = [int(s.item()) for s in all_sizes]
+        all_sizes = torch.zeros(world, dtype=torch.int64, device=grad.device)
+        all_gather_into(all_sizes, torch.tensor([b], dtype=torch.int64, device=grad.device))
+        counts = [int(v) for v in all_sizes.cpu()]
     else:
         counts = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
     bmax = max(counts)
@@ -43,7 +71,7 @@ def gather_loss_grad(loss, grad, n_total=None):
     packed[:b, :p] = grad
     packed[:b, p] = loss
     out = torch.empty((world * bmax, p + 1), dtype=grad.dtype, device=grad.device)
-    dist.all_gather_into_tensor(out, packed)
+    all_gather_into(out, packed)
     out = out.view(world, bmax, p + 1)
     rows = torch.cat([out[r, :counts[r]] for r in range(world)], dim=0)
     return rows[:, p].contiguous(), rows[:, :p].contiguous()
@@ -60,9 +88,9 @@ def allreduce_mean_packed(packed, n_total=None):
         return s / float(packed.shape[0] if n_total is None else n_total)
     if n_total is None:
         s = torch.cat([s, torch.tensor([float(packed.shape[0])], dtype=s.dtype, device=s.device)])
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        all_reduce_(s)
         return s[:-1] / s[-1]
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    all_reduce_(s)
     return s / float(n_total)
 
 
@@ -104,8 +132,7 @@ def gather_packed(packed, n_total=None, out=None):
         return torch.cat([G, L[:, None]], dim=1)
     if out is None:
         out = torch.empty((world * b, p1), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous())
-    return out
+    return all_gather_into(out, packed.contiguous())
 
 
 class OverlappedGather:
@@ -140,13 +167,13 @@ class OverlappedGather:
             self.gathered[i] = self.buffers[i]
             return i
         if not self.cuda:
-            dist.all_gather_into_tensor(self.gathered[i], self.buffers[i])
+            all_gather_into(self.gathered[i], self.buffers[i])
             return i
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
-            dist.all_gather_into_tensor(self.gathered[i], self.buffers[i])
+            all_gather_into(self.gathered[i], self.buffers[i])
             self.done[i] = torch.cuda.Event()
             self.done[i].record(self.side)
         return i

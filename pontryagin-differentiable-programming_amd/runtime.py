@@ -388,7 +388,12 @@ class ModelLib:
         f64 = dict(dtype=torch.float64, device="cuda")
         if warm is not None:
             assert u_init is None, "warm and u_init exclude each other"
-            x, u, lam = ((dev(a).contiguous() if consume_warm else dev(a).clone().contiguous()) for a in warm)
+            if consume_warm:        # in place: the caller's tensors ARE the outputs - a silent copy would leave an IRL loop re-solving from a stale point
+                for a in warm:
+                    assert torch.is_tensor(a) and a.is_cuda and a.dtype == torch.float64 and a.is_contiguous(), "consume_warm needs contiguous fp64 CUDA tensors"
+                x, u, lam = warm
+            else:
+                x, u, lam = (dev(a).clone().contiguous() for a in warm)
             assert x.shape == (B, T + 1, self.n) and u.shape == (B, T, self.m) and lam.shape == (B, T, self.n)
         elif u_init is not None:
             u = dev(u_init).clone().contiguous()

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-5 profiles (run on the GPU box through gpurun; everything lands in gpurun_out/prof5, what is to be judged is copied into profiles/r05_*):
+#   1. ONE `rocprofv3 --kernel-trace --stats` run of the default bench line (headline + other_configs + scaling_configs at N = 1; the CPU baseline is skipped - it launches
+#      nothing) with bench.py's timing windows kept (PDP_BENCH_WINDOWS): the FULL per-kernel CSV, and probes/rocprof_match.py's table that holds every event-timed
+#      figure of that line against the dispatches rocprofv3 recorded in the same run.
+#   2. the PMC calibration (probes/pmc_calibrate.hip): FETCH_SIZE / WRITE_SIZE against known byte counts in this repository's access shapes -> factors.
+#   3. FETCH_SIZE / WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes) over the same bench command -> HBM bytes per launch of the headline kernel, the
+#      lqrSolver stream kernel, getAuxSys, the OC solver, scaled by the measured factors instead of the blanket x2 of rounds 1-4 -> traffic.json.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/prof5
+mkdir -p $O
+BENCH="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+PDP_BENCH_WINDOWS=$O/windows.json rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $BENCH > $O/stats.log 2>&1
+grep '^{' $O/stats.log | tail -1 > $O/bench_line_under_rocprof.json
+python probes/rocprof_match.py $O/stats $O/windows.json > $O/rocprof_match.txt 2>&1
+echo "rocprof_match exit $?" >> $O/rocprof_match.txt
+for f in $(find $O/stats -name 'p_kernel_stats.csv'); do cp $f $O/bench_full_kernel_stats.csv; done
+# ---- calibration
+hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate probes/pmc_calibrate.hip > $O/calib_build.log 2>&1
+/tmp/pmc_calibrate 1024 4 > $O/calib_truth.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o p -- /tmp/pmc_calibrate 1024 4 > $O/calib_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o p -- /tmp/pmc_calibrate 1024 4 > $O/calib_write.log 2>&1
+# ---- traffic of the bench kernels
+BENCH2="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-configs"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $BENCH2 > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $BENCH2 > $O/write.log 2>&1
+python probes/pmc_traffic_r05.py $O > $O/traffic_summary.txt 2>&1
+cat $O/rocprof_match.txt | tail -60
+cat $O/traffic_summary.txt | tail -60

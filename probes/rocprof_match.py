@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Match every event-timed figure of a bench.py line with the kernel dispatches rocprofv3 recorded in the SAME run (round-4 verdict, "make profiles/ reproduce every
+figure in the bench line").
+
+    PDP_BENCH_WINDOWS=w.json rocprofv3 --kernel-trace --stats --output-format csv -d DIR -o p -- python bench.py ...
+    python probes/rocprof_match.py DIR w.json  >  table
+
+bench.py keeps the host clocks (monotonic / boottime / realtime) around the timed repetitions of every _event_ms call ("timing windows"); rocprofv3's kernel trace
+carries start / end timestamps per dispatch.  The clock domain of the trace is found by trying the three (the right one puts `reps` dispatches of the headline kernel into
+the headline window); then, per window: the dispatches that START inside it, grouped by kernel, their summed duration divided by the window's repetitions = the kernel
+time of one call as rocprofv3 saw it, against the median HIP-event time bench.py printed.  An entry whose call is several launches (the IRL iteration: solve + gradient
+unit; the large-batch steps: rollout pre-pass + step) gets the sum; event time above the sum is launch gap, not kernel time.  Output: one row per entry of
+`other_configs`, the headline window and the timed region, with the ratio and a PASS / GAP verdict at 5 %."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel\w*)\s*<([^>]*)>", name)
+    if m:
+        args = ",".join(a.strip() for a in m.group(2).split(",")[1:])
+        return m.group(1) + ("<" + args + ">" if args else "")
+    return re.sub(r"\(.*", "", name)[:60]
+
+
+def main():
+    d, wfile = sys.argv[1], sys.argv[2]
+    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r.get("Grid_Size_X", r.get("Grid_Size", 0))), int(r.get("Workgroup_Size_X", 0))))
+    rows.sort()
+    w = json.load(open(wfile))
+    wins, line = w["windows"], w["line"]
+    hw = line["roofline"]["timing_windows"][0]
+
+    def inside(win, clock, off=0):
+        t0, t1 = win["t0"][clock] + off, win["t1"][clock] + off
+        return [r for r in rows if t0 <= r[0] <= t1]
+    # clock domain: the one that puts exactly reps fused-kernel dispatches into the headline window
+    clock = None
+    for c in ("monotonic", "boottime", "realtime"):
+        got = [r for r in inside(wins[hw], c) if "oc_pdp_fused" in r[2]]
+        if len(got) == wins[hw]["reps"]:
+            clock = c
+            break
+    if clock is None:
+        print("no clock domain of the host matches the trace timestamps (headline window holds %s dispatches)" %
+              {c: len(inside(wins[hw], c)) for c in ("monotonic", "boottime", "realtime")})
+        sys.exit(2)
+    print("# trace timestamps are in the host's %s clock; %d dispatches in the trace; tolerance %.0f %%" % (clock, len(rows), 100 * tol))
+
+    def window_kernels(k):
+        win = wins[k]
+        by = collections.OrderedDict()
+        for r in inside(win, clock):
+            key = (short(r[2]), r[3], r[4])
+            by.setdefault(key, []).append((r[1] - r[0]) * 1e-6)
+        tot = sum(sum(v) for v in by.values()) / win["reps"]
+        parts = ["%s grid %d x wg %d: %d dispatches, %.4f ms avg" % (k_[0], k_[1], k_[2], len(v), sum(v) / len(v)) for k_, v in by.items()]
+        return tot, parts
+
+    out = []
+
+    def report(label, event_ms, windows):
+        tot, parts = 0.0, []
+        for k in windows:
+            t, p = window_kernels(k)
+            tot += t
+            parts += p
+        ratio = event_ms / tot if tot > 0 else float("nan")
+        verdict = "PASS" if abs(ratio - 1) <= tol else ("GAP (event time above the kernels' sum: launch gaps between several launches / a short kernel)" if ratio > 1 else "FAIL")
+        out.append((label, event_ms, tot, ratio, verdict, parts))
+
+    report("headline kernel_ms (roofline.achieved)", line["roofline"]["kernel_ms"], [hw])
+    report("timed region ms_per_step", line["ms_per_step"], [line["roofline"]["timed_region_window"]])
+    for name, e in (line.get("other_configs") or {}).items():
+        if isinstance(e, dict) and e.get("timing_windows"):
+            report("other_configs." + name + ".kernel_ms", e["kernel_ms"], e["timing_windows"])
+    for name, e in (line.get("scaling_configs") or {}).items():
+        if isinstance(e, dict) and e.get("timing_windows"):
+            report("scaling_configs." + name + ".kernel_ms_per_rank[0]", e["kernel_ms_per_rank"][0], e["timing_windows"])
+    bad = 0
+    for label, ev, tot, ratio, verdict, parts in out:
+        print("%-70s event %.4f ms   rocprof %.4f ms   ratio %.3f   %s" % (label, ev, tot, ratio, verdict))
+        for p in parts:
+            print("        " + p)
+        bad += verdict == "FAIL"
+    print("# %d rows, %d within %.0f %%, %d with launch gaps, %d FAIL" % (len(out), sum(o[4] == "PASS" for o in out), 100 * tol, sum(o[4].startswith("GAP") for o in out), bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ machine) into small .npz fixtures.  Runs ONLY in the build container (needs /roo
 
 Sources (all under /root/reference/Examples):
   IRL/<sys>/data/<name>_demos.mat            -> demos_<sys>.npz   (x*,u*,lambda*,cost,theta*,dt)
-  IRL/<sys>/data/PDP_results_trial_0.mat     -> irltrace_<sys>.npz (selected rows of the GD trace)
+  IRL/<sys>/data/PDP_results_trial_0.mat     -> irltrace_<sys>.npz (selected rows of the GD trace), irltrace_head_<sys>.npz (its first 202 rows, consecutive)
   SysID/<sys>/data/<name>_iodata.mat         -> iodata_<sys>.npz
   OC/quadrotor/data/PDP_OC_results_trial_0   -> oc_quadrotor.npz  (solved_solution / true_solution)
   OC/cartpole/data/PDP_Neural_trial_0        -> oc_cartpole_neural.npz (final MLP params + rollout)
@@ -18,6 +18,8 @@ import scipy.io as sio
 REF = os.environ.get("PDP_REFERENCE", "/root/reference")
 EX = os.path.join(REF, "Examples")
 OUT = os.path.dirname(os.path.abspath(__file__))
+
+HEAD_ROWS = 202   # rows 0..201 of parameter_trace / loss_trace: 200 consecutive gradient-descent iterations
 
 SYS = {  # system -> (demo file stem, iodata stem)
     "pendulum": ("pendulum", "pendulum"),
@@ -54,6 +56,9 @@ def irltrace(sysname):
     np.savez_compressed(os.path.join(OUT, "irltrace_%s.npz" % sysname), k=np.array(ks), param=P[ks], param_next=P[[k + 1 for k in ks]],
                         loss_next=L[[k + 1 for k in ks]], lr=lr, K=K, time_passed=float(r["time_passed"].squeeze()))
     print("irltrace", sysname, "K", K, "p", P.shape[1], "lr", lr, "rows", ks)
+    # the head of the stored gradient-descent trace, every row: what a replay of the reference's loop (Examples/IRL/<sys>/<sys>_PDP.py) from P[0] must reproduce
+    H = min(HEAD_ROWS, K)
+    np.savez_compressed(os.path.join(OUT, "irltrace_head_%s.npz" % sysname), param=P[:H], loss=L[:H], lr=lr, K=K)
 
 
 def iodata(sysname, stem):

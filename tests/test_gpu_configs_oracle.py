@@ -152,3 +152,47 @@ def test_C2_cartpole_fused_unit_batch256_against_the_40_digit_evaluation(margins
         l, g = po.irl_loss_grad(xs[i], us[i], dx[i], du[i], list(Xe), list(Ue))
         margins.check("C2 cart-pole fused unit B=256 sample %d: loss (relative)" % i, abs(npy(out["loss"])[i] - l) / l, 1e-12)
         margins.check("C2 cart-pole fused unit B=256 sample %d: gradient (relative to its largest entry)" % i, rel(npy(out["grad"])[i], g), tol_i)
+
+
+def test_C3_headline_unit_on_the_benchmarks_own_inputs_against_the_oracle(margins):
+    """C3 U-OC - the workload bench.py times: quadrotor n = 13, m = 4, p = 9, T = 50, B = 1024 on bench.synth_inputs(1024, seed of rank 0), through the kernel the
+    bench launches (oc_pdp_fused3_kernel, four trajectories per workgroup).  Samples 0, 511, 1023 against the restatement of the reference's unit (oracle.pdp_oc_unit:
+    rollout PDP.py:186-196 / costates 199-209 / getAuxSys 272-314 / lqrSolver 557-608 / chain rule cartpole_PDP.py:63-74), with lqrSolver additionally evaluated in 40-digit
+    arithmetic on the aux system of the kernel's own point (the reference's order of operations inverts I + P R on an off-optimal trajectory: where it loses digits its own
+    error is the yardstick, as in the other U-OC tests)."""
+    import bench
+    from oracle import pdp_oracle as po
+    from test_gpu_models import oracle_oc, rel, TOL
+    from pdp_amd import zoo
+    mdl = zoo.get("quadrotor", "irl")
+    oc = oracle_oc("quadrotor")
+    th = np.array(bench.THETA)
+    x0, u, dx, du = bench.synth_inputs(bench.BATCH, 1000)                     # bench.main: synth_inputs(BATCH, 1000 + rank), rank 0
+    assert x0.shape == (1024, 13) and u.shape == (1024, 50, 4)
+    out = mdl.oc_pdp_grad(u, th, dx, du, x0=x0, want_sens=True)
+    plain = mdl.oc_pdp_grad(u, th, dx, du, x0=x0)                            # the instantiation bench.py launches (no sensitivity outputs): same loss / gradient
+    assert int(out["status"].sum()) == 0 and int(plain["status"].sum()) == 0
+    L, G, X, Lam = (npy(out[k]) for k in ("loss", "grad", "x", "lam"))
+    assert np.abs(npy(plain["grad"]) - G).max() <= 1e-13 * np.abs(G).max() and np.abs(npy(plain["loss"]) - L).max() <= 1e-13 * np.abs(L).max()
+    for i in (0, 511, 1023):
+        xs = oc.rollout(x0[i], u[i], th)
+        ls = oc.costate(xs, u[i], th)
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs oracle: state trajectory" % i, rel(X[i], xs), TOL)
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs oracle: costate trajectory" % i, rel(Lam[i], ls), TOL)
+        aux = oc.getAuxSys(X[i], u[i], Lam[i], th)
+        ref64 = po.lqr_from_aux(aux, oc.n, oc.p, 50)
+        ex = po.lqr_solver_mp(aux["dynF"], aux["dynG"], aux["dynE"], aux["Hxx"], aux["Huu"], aux["Hxu"], aux["Hxe"], aux["Hue"], aux["hxx"], aux["hxe"],
+                              np.zeros((oc.n, oc.p)), 50)
+        Xe, Ue = np.stack(ex["state_traj_opt"]), np.stack(ex["control_traj_opt"])
+        tol_i = max(TOL, 2 * rel(np.stack(ref64["state_traj_opt"]), Xe))
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs 40-digit lqrSolver: dx/dtheta" % i, rel(npy(out["dxdp"])[i], Xe), tol_i)
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs 40-digit lqrSolver: du/dtheta" % i, rel(npy(out["dudp"])[i], Ue), tol_i)
+        l, g = po.irl_loss_grad(X[i], u[i], dx[i], du[i], list(Xe), list(Ue))
+        margins.check("C3 headline unit B=1024 bench inputs sample %d: loss (relative)" % i, abs(L[i] - l) / abs(l), 1e-12)
+        margins.check("C3 headline unit B=1024 bench inputs sample %d: gradient vs 40-digit lqrSolver (relative to its largest entry)" % i, rel(G[i], g), tol_i)
+        # and the reference's unit end to end in its own fp64 order of operations
+        unit = po.pdp_oc_unit(oc, x0[i], u[i], th, dx[i], du[i])
+        l64, g64 = unit["loss"], unit["grad"]
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs oracle.pdp_oc_unit (fp64 reference order): loss (relative)" % i, abs(L[i] - l64) / abs(l64), 1e-11)
+        margins.check("C3 headline unit B=1024 bench inputs sample %d vs oracle.pdp_oc_unit (fp64 reference order): gradient" % i, rel(G[i], g64),
+                      max(TOL, 10 * rel(g64, g)))

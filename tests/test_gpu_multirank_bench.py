@@ -1,0 +1,71 @@
+"""GPU: bench.py's multi-rank path EXECUTED on a one-GPU box (round-4 verdict, item 3).
+
+The driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` on an 8-GPU node; no such node was available in rounds 1-4, so nccl init,
+the side-stream OverlappedGather, the per-rank statistics and scaling_configs with world > 1 had never run.  Here two ranks share device 0 and exchange over gloo
+(PDP_DIST_BACKEND=gloo PDP_DIST_SAME_DEVICE=1: parallel.host_staged moves the rows through host memory) - everything but RCCL itself runs: sharding (equal and ragged),
+the packed [B/G, p+1] rows written by the kernels, the double-buffered side-stream exchange, both forms of the exchange, the max-over-ranks timing, the JSON line.
+--verify-exchange makes every rank compare what it received with the single-process kernel on the whole batch.  Reference semantics: the batch mean,
+PDP/PDP.py:1293-1294, Examples/IRL/cartpole/cartpole_PDP.py:77-78.  The timings of such a run are NOT scaling measurements (two processes time-slice one GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _torchrun_bench(world, extra=()):
+    env = dict(os.environ, PDP_DIST_BACKEND="gloo", PDP_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--verify-exchange"] + list(extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                   # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_path_on_one_gpu(world):
+    res = _torchrun_bench(world)
+    assert res["n_gpus"] == world and res["steps"] == 5 and res["warmup"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["dist_backend"] == "gloo" and res["config"]["ranks_share_one_device"] is True
+    assert res["value"] > 0 and abs(res["value"] - world * 1024 * 5 / (res["ms_per_step"] * 5e-3)) <= 1e-6 * res["value"]
+    pr = res["per_rank"]
+    for key in ("kernel_ms", "exchange_us", "ms_per_step"):
+        assert len(pr[key]) == world and all(v > 0 for v in pr[key]), pr
+    assert res["ms_per_step"] >= max(pr["ms_per_step"]) * (1 - 1e-9)          # max over ranks
+    v = pr["verified"]
+    assert v["gathered_rows"] == world * 1024 and all(v["gathered_rows_bit_equal_to_single_process_per_rank"]), v
+    assert max(v["allreduce_mean_max_rel_err_per_rank"]) <= 1e-13, v
+    sc = res["scaling_configs"]
+    assert "error" not in sc, sc
+    totals = {"ragged_rocket_oc_unit_T100_p10_B1001": 1001, "C4_rocket_oc_unit_T100_p10_B4096": 4096, "C4_rocket_cp_step_T100_p18_B4096": 4096,
+              "C5_quadrotor_sysid_step_T100_p5_B8192": 8192, "C5_quadrotor_mlp_step_T100_p420_B8192": 8192}
+    assert set(sc) == set(totals)
+    for name, total in totals.items():
+        e = sc[name]
+        assert e["total_batch"] == total and sum(e["shard_per_rank"]) == total and len(e["shard_per_rank"]) == world, (name, e)
+        assert max(e["shard_per_rank"]) - min(e["shard_per_rank"]) <= 1
+        assert len(e["kernel_ms_per_rank"]) == world and e["ms_per_step"] > 0
+        if total % world == 0:
+            assert len(e["exchange_us_per_rank"]) == world and all(x > 0 for x in e["exchange_us_per_rank"]) and all(x > 0 for x in e["exchange_allreduce_us_per_rank"])
+        ver = e["verified"]
+        assert ver["gathered_rows"] == total, (name, ver)
+        # shards and the whole batch may run in different workgroup shapes / rollout routes (chosen by batch size): rows agree to the last bits, bit for bit where the route is the same
+        assert max(ver["gathered_rows_max_rel_diff_per_rank"]) <= 1e-12, (name, ver)
+        assert max(ver["allreduce_mean_max_rel_err_per_rank"]) <= 1e-12, (name, ver)
+    assert all(sc["C4_rocket_oc_unit_T100_p10_B4096"]["verified"]["gathered_rows_bit_equal_to_single_process_per_rank"])
+    assert sc["ragged_rocket_oc_unit_T100_p10_B1001"]["shard_per_rank"][0] == -(-1001 // world)

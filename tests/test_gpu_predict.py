@@ -283,3 +283,43 @@ def test_primal_prediction_record(golden_dir, name, B):
     with pytest.raises(RuntimeError):
         mdl.oc_solve_ms(x0, th1, T, warm=warm, predict=dict(dtheta=dth, dxdp=torch.zeros(B, T + 1, n, p, dtype=torch.float64, device="cuda"),
                                                            dudp=torch.zeros(B, T, m, p, dtype=torch.float64, device="cuda"), primal=True))
+
+
+def test_record_prediction_with_more_controls_than_states():
+    """n = 2, m = 3 (round-4 advice): the in-launch prediction from the packed record maps lanes to (stage, state row) and used to load the control rows under `i < NU`
+    inside that mapping - rows >= NX were never written and the solver started from uninitialised LDS.  The point the solver starts from inside the launch must be the
+    point pdp_oc_predict_record_batched computes (which has always handled m > n): same iterates bit for bit, full and primal record."""
+    from pdp_amd import PDP
+    from pdp_amd.sx import SX, dot, mtimes, sin
+    rng = np.random.default_rng(8)
+    n, m, T, B = 2, 3, 20, 6
+    A = np.eye(n) + 0.1 * rng.standard_normal((n, n))
+    Bm = 0.5 * rng.standard_normal((n, m))
+    X, U, w = SX.sym("x", n), SX.sym("u", m), SX.sym("w", 3)
+    oc = PDP.OCSys("more controls than states")
+    oc.setAuxvarVariable(w)
+    oc.setStateVariable(X)
+    oc.setControlVariable(U)
+    oc.setDyn(mtimes(SX(A), X) + mtimes(SX(Bm), U) + 0.05 * w[2] * sin(X))
+    oc.setPathCost(w[0] * dot(X, X) + w[1] * dot(U, U))
+    oc.setFinalCost(3.0 * w[0] * dot(X, X))
+    mdl = oc.model()
+    assert (mdl.n, mdl.m, mdl.p) == (2, 3, 3)
+    th = np.array([1.3, 0.4, 1.0])
+    x0 = rng.standard_normal((B, n))
+    sol = mdl.oc_solve_ms(x0, th, T, tol=1e-10)
+    assert bool(sol["converged"].all())
+    dem_x, dem_u = np.zeros((B, T + 1, n)), np.zeros((B, T, m))
+    th1 = th[None] * (1 + 0.05 * rng.uniform(-1, 1, (B, 3)))
+    dth = th1 - th[None]
+    warm = (sol["state"], sol["control"], sol["costate"])
+    for primal in (False, True):
+        g = mdl.oc_pdp_grad(sol["control"], th, dem_x, dem_u, x=sol["state"], lam=sol["costate"], want_predict_record="primal" if primal else True)
+        xp, up, lp = mdl.oc_predict_from_record(sol["state"], sol["control"], sol["costate"], dth, g["predict_record"], primal=primal)
+        assert float((up - sol["control"]).abs().max()) > 0            # every control row moves
+        assert bool(((up - sol["control"]).abs().amax(dim=(0, 1)) > 0).all())
+        inl = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, record=g["predict_record"], primal=primal), log_rows=6)
+        pre = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(xp, up, lp), log_rows=6)
+        assert bool(inl["converged"].all()) and bool((inl["iterations"] == pre["iterations"]).all())
+        for k in ("state", "control", "costate", "cost"):
+            assert bool((inl[k] == pre[k]).all()), (primal, k)
