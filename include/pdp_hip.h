@@ -232,10 +232,16 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                                      loads the point: no extra launch, no copy).  riccati may be NULL: multipliers as they are */
 #define PDP_MS_PREDICT_PRIMAL 32  /* opts.flags, with PDP_MS_PREDICT and opts.predict_record: states and controls only - the multipliers stay as they are and the P | W part
                                      of the record is not read (it need not have been written: PDP_OC_RECORD_PRIMAL) */
+#define PDP_MS_PREDICT_GUARD 64   /* opts.flags, with PDP_MS_PREDICT (runner / evaluator kernel): the previous solution itself (the plain warm start) is evaluated beside its
+                                     prediction and the prediction is kept only if its scaled KKT error - max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|)), the
+                                     quantities of the convergence test - is finite and not larger; otherwise the solve starts from the previous solution and status gets
+                                     PDP_MS_PREDICT_REJECTED.  One more residual pass per solve.  Needed where parameter steps are large against the curvature: on the
+                                     reference's stored rocket IRL run the unguarded prediction of row 1 sends Newton's method to another stationary point */
+#define PDP_MS_PREDICT_REJECTED 512 /* status, informational: PDP_MS_PREDICT_GUARD preferred the previous solution to its prediction */
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;
-    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT, PDP_MS_PREDICT_PRIMAL */
+    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT, PDP_MS_PREDICT_PRIMAL, PDP_MS_PREDICT_GUARD */
     int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
     int dtheta_bstride;        /* PDP_MS_PREDICT: dtheta [B][p] (stride p) or shared [p] (stride 0) ... */
     const double* dtheta;

@@ -103,7 +103,11 @@ struct Ms2Layout {
     //     residual set 0 | residual set 1 (grad_x L | grad_u L | defect c)
     // followed by the gains, (P, W) and the filter.  The API arrays are read once (warm start) and written once (the result).
     // PDP_MS_PREDICT inside the kernel: staging block of the sensitivity rows (64 rows of NP, or 64 / NX stages of the Riccati record) + dx of every node, in the pool
-    static constexpr int PRED_STG = 64 * NP > (64 / NX) * (NX * NX + NX * NP + 1) ? 64 * NP : (64 / NX) * (NX * NX + NX * NP + 1);
+    // (third candidate: 64 / NX stages of the packed fp32 record X | U | tri(P) | W plus the block's dx - with many controls and few states, e.g. n = 2, m = 3, the U part
+    // makes it the largest; a model of that shape did not compile before round 5)
+    static constexpr int PRED_STG_A = 64 * NP > (64 / NX) * (NX * NX + NX * NP + 1) ? 64 * NP : (64 / NX) * (NX * NX + NX * NP + 1);
+    static constexpr int PRED_STG_R = ((64 / NX) * (2 * NX * NP + NU * NP + NX * (NX + 1) / 2) + 1) / 2 + (64 / NX) * NX + 2;
+    static constexpr int PRED_STG = PRED_STG_A > PRED_STG_R ? PRED_STG_A : PRED_STG_R;
     __host__ __device__ static constexpr bool predict_fits(int T) { return (int64_t)(T + 1) * NX + PRED_STG <= 2 * BUF; }
     __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
@@ -866,6 +870,28 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         int st = 0, it = 0, nfilt = 0, conv = 0, phase = ph1 ? 1 : 0, cur = 0;
         double hs = ph1 ? 1.0 : 0.0, dw = ph1 ? 0.0 : 1.0, dw_last = 0.0, theta_max = 0.0, theta_min = 0.0;
         bool gains_ok = false, pending = false;         // pending: the evaluator is already on the sweep of the current iterate (TRIAL_SWEEP)
+        // PDP_MS_PREDICT_GUARD (round 5): a first-order prediction is only as good as the linearisation it comes from.  On the reference's own rocket IRL run (stored trace,
+        // row 1: a parameter step of 1 % where the sensitivities are of order 1e2) the predicted point has FIFTY times the KKT error of the previous solution it was meant
+        // to improve, and Newton's method started there ends in another stationary point (loss 10289.86 where IPOPT stored 1301.24; oracle/ipopt_ms.py reproduces both).
+        // So the previous solution itself - the plain warm start - is loaded into point set 1 and evaluated first (one residual pass, ~5 % of a two-iteration solve);
+        // the predicted point in set 0 is evaluated next, with the first sweep speculated behind it as always; the prediction is kept iff its scaled KKT error
+        //     max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|))        (the quantities of the convergence test)
+        // is finite and not larger than the plain point's.  Otherwise the speculative sweep is dropped and the iteration starts from set 1 (PDP_MS_PREDICT_REJECTED).
+        const bool guard = ph1 && (rec || pred) && (op.flags & PDP_MS_PREDICT_GUARD) != 0;
+        double g_f = 0.0, g_th = 0.0, g_pr = 0.0, g_du = 0.0, g_z = 0.0, g_l = 0.0, g_lc = 0.0, g_err = 0.0;
+        bool g_fin = false;
+        if (guard) {
+            double* s1 = Pt(1);
+            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : xb[q]; }
+            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s1[OU + i * TS + t] = ub[q]; }
+            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[OL + i * TS + t] = lb[q]; }
+            issue(MS2_CMD_TRIAL, 0.0, 1, 1);
+            if constexpr (SPLIT) { /* (a plain TRIAL is evaluated by the evaluator alone in both forms) */ }
+            wait_done();
+            read_res();
+            g_f = f_cur; g_th = th_cur; g_pr = inf_pr; g_du = inf_du; g_z = zmax; g_l = lmax; g_lc = lamc; g_fin = finite;
+            g_err = fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
+        }
         // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays).  Unless the point has to be built first
         // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
         // the trial half is done and finds chunk 0 of the sweep already under way instead of asking for it then
@@ -873,6 +899,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         else if constexpr (SPLIT) { issue(MS2_CMD_TRIAL, 0.0, cur, cur); wait_done(); }      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
         else { issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur); wait_slot(MS2_TDONE); pending = true; }
         read_res();
+        if (guard && !dead) {
+            const double p_err = fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
+            if (g_fin && !(finite && p_err <= g_err)) {            // the prediction is no improvement (or not finite): start from the previous solution
+                if (pending) { abort_sweep(); pending = false; }
+                cur = 1;
+                f_cur = g_f; th_cur = g_th; inf_pr = g_pr; inf_du = g_du; zmax = g_z; lmax = g_l; lamc = g_lc; finite = true;
+                st |= PDP_MS_PREDICT_REJECTED;
+            }
+        }
         for (;;) {
             if (dead) break;
             if (phase == 1 && dw == 0.0) {              // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)

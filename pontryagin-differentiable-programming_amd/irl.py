@@ -105,11 +105,13 @@ class GDLoop(_DeviceLoop):
 class IRLLoop(_DeviceLoop):
     """mdl: runtime.ModelLib of an OC model (PDP.OCSys.model() or zoo.get(system, "irl")); demo_x [B, T+1, n], demo_u [B, T, m]: the demonstrations; theta0 [p]: the initial
     parameter (shared by all demonstrations, as in the reference); lr: learning rate; record: "full" (states, controls and multipliers are predicted) or "primal"
-    (states and controls only: cheaper, enough where the multipliers move little per step); max_steps: length of the on-device traces."""
+    (states and controls only: cheaper, enough where the multipliers move little per step); max_steps: length of the on-device traces; guard (default): every solve
+    checks its predicted start against the previous solution and starts from the better one (PDP_MS_PREDICT_GUARD) - the first iterations of the reference's stored
+    rocket run take parameter steps across which the unguarded prediction leads Newton's method to another stationary point (tests/test_gpu_gd_replay.py)."""
 
-    def __init__(self, mdl, demo_x, demo_u, theta0, lr, record="full", tol=1e-10, max_iter=300, max_steps=100000):
+    def __init__(self, mdl, demo_x, demo_u, theta0, lr, record="full", tol=1e-10, max_iter=300, max_steps=100000, guard=True):
         assert record in ("full", "primal")
-        self.mdl, self.tol, self.max_iter, self.primal = mdl, float(tol), int(max_iter), record == "primal"
+        self.mdl, self.tol, self.max_iter, self.primal, self.guard = mdl, float(tol), int(max_iter), record == "primal", bool(guard)
         self.demo_x, self.demo_u = rt.dev(demo_x), rt.dev(demo_u)
         self.B, self.T = int(self.demo_u.shape[0]), int(self.demo_u.shape[1])
         assert self.demo_x.shape == (self.B, self.T + 1, mdl.n) and self.demo_u.shape == (self.B, self.T, mdl.m)
@@ -142,7 +144,7 @@ class IRLLoop(_DeviceLoop):
     def step(self):
         """one warm iteration: solve at the moved parameter from the predicted start (in place), gradient + record, update"""
         s = self.mdl.oc_solve_ms(self.x0, self.theta, self.T, tol=self.tol, max_iter=self.max_iter, warm=self.sol, consume_warm=True,
-                                 predict=dict(dtheta=self.dtheta, record=self.bufs["predict_record"], primal=self.primal))
+                                 predict=dict(dtheta=self.dtheta, record=self.bufs["predict_record"], primal=self.primal, guard=self.guard))
         self._update(self._gradient(), s)
 
     def results(self):

@@ -379,6 +379,8 @@ class ModelLib:
         (no copies: for callers that built the starting point for this call, e.g. oc_predict).  predict = dict(dtheta [p] or [B, p], dxdp, dudp[, riccati]) with
         warm = the solution at the previous parameter: the kernel starts from its first-order prediction for the step dtheta (PDP_MS_PREDICT: what oc_predict computes,
         applied while the point is loaded - no extra launch; with consume_warm the previous solution's tensors are overwritten by the new one, as an IRL loop wants it).
+        predict["guard"] (default True, PDP_MS_PREDICT_GUARD): the previous solution is evaluated beside its prediction and the solve starts from whichever has the smaller
+        scaled KKT error (a first-order prediction across a large parameter step can be worse than no prediction: status & 512 marks the trajectories where it was dropped).
         Returns dict(state, control, costate, cost,
         resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
@@ -425,6 +427,8 @@ class ModelLib:
                 opts.riccati = keep[3].data_ptr() if keep[3] is not None else None
             if predict.get("primal"):                       # PDP_MS_PREDICT_PRIMAL: states and controls only (a record written with want_predict_record="primal" holds nothing else)
                 opts.flags |= 32
+            if predict.get("guard", True):                  # PDP_MS_PREDICT_GUARD (default): the prediction is kept only if its KKT error does not exceed the previous solution's;
+                opts.flags |= 64                            # status bit 512 (PDP_MS_PREDICT_REJECTED) says where it was not
         check(self.lib.pdp_oc_solve_ms_batched(B, T, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(lam), ptr(cost), ptr(resid), ptr(conv), ptr(iters),
                                                ptr(status), ptr(gains), ptr(log), C.byref(opts), ptr(ws), nbytes, current_stream_ptr()), "pdp_oc_solve_ms_batched")
         out = {"state": x, "control": u, "costate": lam, "cost": cost, "resid": resid, "converged": conv != 0, "converged_flags": conv, "iterations": iters, "status": status}

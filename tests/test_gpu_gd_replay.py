@@ -51,6 +51,24 @@ def test_irl_loop_replays_the_stored_trace(golden_dir, margins, name, mode):
     _check(margins, "IRLLoop (%s) replay of the stored %s trace from P[0]" % (mode, name), r["loss_trace"], r["parameter_trace"], h, lr)
 
 
+def test_unguarded_prediction_leaves_the_stored_rocket_trace():
+    """why IRLLoop guards its predicted starts (PDP_MS_PREDICT_GUARD): without the guard the loop leaves the reference's rocket trace at its SECOND iteration - the
+    unguarded prediction across the first parameter step ends in another stationary point, loss 10289.857 where IPOPT stored 1301.237; the oracle's unguarded loop does
+    exactly the same (tests/test_oracle_gd_replay.py), i.e. this is the algorithm's behaviour, not a kernel defect"""
+    from pdp_amd import zoo
+    from pdp_amd.irl import IRLLoop
+    d = np.load(os.path.join(ROOT, "tests", "golden", "demos_rocket.npz"))
+    h = np.load(os.path.join(ROOT, "tests", "golden", "irltrace_head_rocket.npz"))
+    loop = IRLLoop(zoo.get("rocket", "irl"), d["state"], d["control"], h["param"][0], float(h["lr"]), max_steps=2, guard=False)
+    loop.run(2, graphed=False)
+    L = loop.results()["loss_trace"]
+    assert abs(L[0] - h["loss"][1]) <= 1e-9 * h["loss"][1] and abs(L[1] - 10289.857357) <= 1e-3, L
+    guarded = IRLLoop(zoo.get("rocket", "irl"), d["state"], d["control"], h["param"][0], float(h["lr"]), max_steps=2)
+    guarded.run(2, graphed=False)
+    L = guarded.results()["loss_trace"]
+    assert abs(L[1] - h["loss"][2]) <= 1e-9 * h["loss"][2], L
+
+
 def test_short_graphed_runs_do_not_overshoot():
     """run(n, graphed=True) with n below the capture warm-up count does n iterations (round-4 advice: the warm-up used to run unconditionally)"""
     from pdp_amd import zoo

@@ -31,7 +31,13 @@ def _torchrun_bench(world, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--verify-exchange"] + list(extra)
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    try:                                     # (kept for the record and for debugging: pytest shortens long assertion messages)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "multirank_bench_world%d.log" % world), "w") as f:
+            f.write("rc %d\n---- stdout\n%s\n---- stderr\n%s\n" % (r.returncode, r.stdout, r.stderr))
+    except OSError:
+        pass
+    assert r.returncode == 0, "\n".join(r.stderr.splitlines()[-25:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                                   # ONE JSON line, from rank 0
     return json.loads(lines[0])

@@ -323,3 +323,60 @@ def test_record_prediction_with_more_controls_than_states():
         assert bool(inl["converged"].all()) and bool((inl["iterations"] == pre["iterations"]).all())
         for k in ("state", "control", "costate", "cost"):
             assert bool((inl[k] == pre[k]).all()), (primal, k)
+
+
+def test_prediction_guard_on_the_stored_rocket_trace(golden_dir):
+    """PDP_MS_PREDICT_GUARD on the reference's own rocket IRL run, parameter step row 0 -> row 1 (tests/golden/irltrace_head_rocket.npz): the first-order prediction has
+    ~50 times the KKT error of the previous solution.  Guarded (the default of oc_solve_ms(predict=...)): the kernel drops the prediction (status & 512), starts from the
+    previous solution and takes the iterations the oracle takes from there to the optimum IPOPT stored (loss_trace[2] = 1301.2367).  Unguarded: it follows the oracle from
+    the predicted point into the other stationary point (loss 10289.857) - the kernel is faithful either way, the guard is what keeps the LOOP on the reference's trace."""
+    from oracle import ipopt_ms
+    d, oc, mdl = setup(golden_dir, "rocket")
+    h = np.load(os.path.join(golden_dir, "irltrace_head_rocket.npz"))
+    T, x0 = d["control"].shape[1], d["state"][:1, 0]
+    th0, th1 = h["param"][0], h["param"][1]
+    sol = mdl.oc_solve_ms(x0, th0, T, tol=1e-10)
+    assert bool(sol["converged"].all())
+    g = mdl.oc_pdp_grad(sol["control"], th0, d["state"][:1], d["control"][:1], x=sol["state"], lam=sol["costate"], want_predict_record=True)
+    warm = (sol["state"], sol["control"], sol["costate"])
+    xs, us, ls = (sol[k][0].cpu().numpy() for k in ("state", "control", "costate"))
+    start, rejected = ipopt_ms.guarded_start(oc, x0[0], xs, us, ls, th0, th1 - th0)
+    assert rejected
+    ref = ipopt_ms.solve(oc, x0[0], T, th1, tol=1e-10, warm=start)
+    ref_pred = ipopt_ms.solve(oc, x0[0], T, th1, tol=1e-10, warm=ipopt_ms.predict_start(oc, xs, us, ls, th0, th1 - th0))
+
+    def loss_of(x, u):
+        return float(np.linalg.norm(x - d["state"][0]) ** 2 + np.linalg.norm(u - d["control"][0]) ** 2)
+    for guard, want in ((True, ref), (False, ref_pred)):
+        s = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=th1 - th0, record=g["predict_record"], guard=guard))
+        assert bool(s["converged"].all())
+        assert (int(s["status"][0]) & 512 != 0) == guard
+        assert int(s["iterations"][0]) == want["iterations"], (guard, int(s["iterations"][0]), want["iterations"])
+        for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+            assert np.abs(s[k][0].cpu().numpy() - want[kr]).max() <= 1e-8 * max(1.0, np.abs(want[kr]).max()), (guard, k)
+    guarded = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=th1 - th0, record=g["predict_record"]))
+    assert abs(loss_of(guarded["state"][0].cpu().numpy(), guarded["control"][0].cpu().numpy()) - h["loss"][2]) <= 1e-9 * h["loss"][2]
+
+
+@pytest.mark.parametrize("name,B", [("cartpole", 5), ("quadrotor", 3)])
+def test_prediction_guard_changes_nothing_where_the_prediction_is_good(golden_dir, name, B):
+    """a 2 % parameter step from the stored demos' optimum: the guard evaluates the previous solution, keeps the prediction (no status bit) and the solve is the unguarded
+    one bit for bit - full and primal record, record and fp64 sensitivity inputs"""
+    d, oc, mdl = setup(golden_dir, name)
+    th = d["true_parameter"]
+    T = d["control"].shape[1]
+    x0 = np.repeat(d["state"][:1, 0], B, axis=0)
+    x0[:, 1] += 0.01 * np.arange(B)
+    sol = solve_at(mdl, x0, th, T)
+    dem = (d["state"][:1].repeat(B, axis=0), d["control"][:1].repeat(B, axis=0))
+    a = mdl.oc_pdp_grad(sol["control"], th, dem[0], dem[1], x=sol["state"], lam=sol["costate"], want_sens=True, want_riccati=True, want_predict_record=True)
+    rng = np.random.default_rng(5)
+    dth = th[None] * 0.02 * rng.uniform(-1, 1, (B, oc.p))
+    th1 = th[None] + dth
+    warm = (sol["state"], sol["control"], sol["costate"])
+    for pred in (dict(record=a["predict_record"]), dict(record=a["predict_record"], primal=True), dict(dxdp=a["dxdp"], dudp=a["dudp"], riccati=a["riccati"])):
+        on = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, guard=True, **pred), log_rows=6)
+        off = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, guard=False, **pred), log_rows=6)
+        assert bool(on["converged"].all()) and int((on["status"] & 512).sum()) == 0 and bool((on["status"] == off["status"]).all())
+        for k in ("state", "control", "costate", "cost", "iterations", "log"):
+            assert bool((on[k] == off[k]).all()), (sorted(pred), k)
