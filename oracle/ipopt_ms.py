@@ -258,16 +258,19 @@ def predict_start(oc, state, control, costate, auxvar_value, dtheta, with_costat
     return state + X @ d, control + U @ d, (costate + L @ d) if with_costate else np.array(costate, dtype=float)
 
 
-def scaled_kkt_error(oc, xs, us, lam, auxvar_value):
-    """max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|)) - the two quantities of solve()'s convergence test, each over the scale it is tested against"""
+def scaled_kkt_error(oc, xs, us, lam, auxvar_value, primal_only=False):
+    """max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|)) - the two quantities of solve()'s convergence test, each over the scale it is tested against;
+    primal_only: the first of them alone"""
     ev = evaluate(oc, xs, us, lam, _vec(auxvar_value))
-    return max(ev["inf_pr"] / (1.0 + max(np.abs(xs).max(), np.abs(us).max())), ev["inf_du"] / (1.0 + np.abs(lam).max()))
+    pr = ev["inf_pr"] / (1.0 + max(np.abs(xs).max(), np.abs(us).max()))
+    return pr if primal_only else max(pr, ev["inf_du"] / (1.0 + np.abs(lam).max()))
 
 
 def guarded_start(oc, ini_state, state, control, costate, auxvar_prev, dtheta, with_costate=True):
     """PDP_MS_PREDICT_GUARD restated: the first-order prediction (predict_start) of the solution at auxvar_prev + dtheta is kept only if its scaled KKT error AT the new
     parameter is finite and not larger than that of the previous solution itself (the plain warm start); both points carry the new initial state in row 0.
-    Returns ((x, u, lam) to start solve(..., warm=...) from, rejected: bool).
+    A prediction of states and controls only (with_costate=False) is judged by the primal part alone: both candidates carry the same multipliers, so the dual
+    residual says nothing about the prediction.  Returns ((x, u, lam) to start solve(..., warm=...) from, rejected: bool).
     Why: along the reference's stored rocket IRL run (Examples/IRL/rocket/data/PDP_results_trial_0.mat, rows 0 -> 1) the parameter moves by 1 % where the
     sensitivities are of order 1e2: the predicted point has ~50 times the KKT error of the point it was meant to improve, and the Newton iteration started there
     converges to another stationary point (loss 10289.86 where IPOPT - from the all-zero guess - stored 1301.24, which the plain warm start reproduces)."""
@@ -276,9 +279,9 @@ def guarded_start(oc, ini_state, state, control, costate, auxvar_prev, dtheta, w
     plain[0][0] = _vec(ini_state)
     pred = [np.array(a, dtype=float) for a in predict_start(oc, state, control, costate, auxvar_prev, dtheta, with_costate=with_costate)]
     pred[0][0] = _vec(ini_state)
-    e_plain = scaled_kkt_error(oc, *plain, th1)
+    e_plain = scaled_kkt_error(oc, *plain, th1, primal_only=not with_costate)
     with np.errstate(all="ignore"):
-        e_pred = scaled_kkt_error(oc, *pred, th1) if all(np.all(np.isfinite(a)) for a in pred) else np.inf
+        e_pred = scaled_kkt_error(oc, *pred, th1, primal_only=not with_costate) if all(np.all(np.isfinite(a)) for a in pred) else np.inf
     if np.isfinite(e_plain) and not (np.isfinite(e_pred) and e_pred <= e_plain):
         return tuple(plain), True
     return tuple(pred), False

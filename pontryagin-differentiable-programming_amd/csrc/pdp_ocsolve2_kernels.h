@@ -877,7 +877,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // the predicted point in set 0 is evaluated next, with the first sweep speculated behind it as always; the prediction is kept iff its scaled KKT error
         //     max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|))        (the quantities of the convergence test)
         // is finite and not larger than the plain point's.  Otherwise the speculative sweep is dropped and the iteration starts from set 1 (PDP_MS_PREDICT_REJECTED).
+        // A prediction of states and controls only (PDP_MS_PREDICT_PRIMAL, or no Riccati record) is judged by the primal part alone: both candidates carry the SAME
+        // multipliers, so the dual residual says nothing about the quality of the prediction (at a 2 % step it is a coin flip that would throw away predictions which
+        // save an iteration - oracle: cart-pole and quadrotor demos, primal infeasibility 1e-4 against 3e-2, dual 5.3 against 5.1).
         const bool guard = ph1 && (rec || pred) && (op.flags & PDP_MS_PREDICT_GUARD) != 0;
+        const bool g_primal = rec ? recp : !predl;
         double g_f = 0.0, g_th = 0.0, g_pr = 0.0, g_du = 0.0, g_z = 0.0, g_l = 0.0, g_lc = 0.0, g_err = 0.0;
         bool g_fin = false;
         if (guard) {
@@ -890,7 +894,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             wait_done();
             read_res();
             g_f = f_cur; g_th = th_cur; g_pr = inf_pr; g_du = inf_du; g_z = zmax; g_l = lmax; g_lc = lamc; g_fin = finite;
-            g_err = fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
+            g_err = g_primal ? inf_pr / (1.0 + zmax) : fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
         }
         // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays).  Unless the point has to be built first
         // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
@@ -900,7 +904,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         else { issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur); wait_slot(MS2_TDONE); pending = true; }
         read_res();
         if (guard && !dead) {
-            const double p_err = fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
+            const double p_err = g_primal ? inf_pr / (1.0 + zmax) : fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
             if (g_fin && !(finite && p_err <= g_err)) {            // the prediction is no improvement (or not finite): start from the previous solution
                 if (pending) { abort_sweep(); pending = false; }
                 cur = 1;

@@ -17,13 +17,17 @@ def host_staged(t):
 
 
 def all_gather_into(out, inp):
-    """dist.all_gather_into_tensor on the current stream; through host memory on gloo (see host_staged)"""
+    """dist.all_gather_into_tensor on the current stream, rank r's `inp` landing in the r-th block of the contiguous `out`; through host memory on gloo (see
+    host_staged).  Both sides are passed flat: gloo checks that the output splits into pieces of exactly the input's SHAPE ([world, 3] from [3] is refused), RCCL only
+    counts elements."""
+    assert out.is_contiguous() and out.numel() == inp.numel() * dist.get_world_size()
+    inp = inp.contiguous()
     if host_staged(inp):
-        h = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(h, inp.contiguous().cpu())
-        out.copy_(h)
+        h = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(h, inp.cpu().view(-1))
+        out.copy_(h.view(out.shape))
     else:
-        dist.all_gather_into_tensor(out, inp)
+        dist.all_gather_into_tensor(out.view(-1), inp.view(-1))
     return out
 
 

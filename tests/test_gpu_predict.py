@@ -351,9 +351,14 @@ def test_prediction_guard_on_the_stored_rocket_trace(golden_dir):
         s = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=th1 - th0, record=g["predict_record"], guard=guard))
         assert bool(s["converged"].all())
         assert (int(s["status"][0]) & 512 != 0) == guard
-        assert int(s["iterations"][0]) == want["iterations"], (guard, int(s["iterations"][0]), want["iterations"])
+        if guard:       # (from the bad point both take 200+ iterations through inertia corrections and restorations: the same stationary point, not the same path)
+            assert int(s["iterations"][0]) == want["iterations"], (int(s["iterations"][0]), want["iterations"])
         for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
-            assert np.abs(s[k][0].cpu().numpy() - want[kr]).max() <= 1e-8 * max(1.0, np.abs(want[kr]).max()), (guard, k)
+            assert np.abs(s[k][0].cpu().numpy() - want[kr]).max() <= (1e-8 if guard else 1e-6) * max(1.0, np.abs(want[kr]).max()), (guard, k)
+    assert abs(loss_of(ref_pred["state_traj_opt"], ref_pred["control_traj_opt"]) - 10289.857357) <= 1e-3
+    for primal in (True, False):        # the primal-only record is judged by the primal residual alone: rejected here as well
+        s = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=th1 - th0, record=g["predict_record"], primal=primal))
+        assert int(s["status"][0]) & 512 and abs(loss_of(s["state"][0].cpu().numpy(), s["control"][0].cpu().numpy()) - h["loss"][2]) <= 1e-9 * h["loss"][2]
     guarded = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=th1 - th0, record=g["predict_record"]))
     assert abs(loss_of(guarded["state"][0].cpu().numpy(), guarded["control"][0].cpu().numpy()) - h["loss"][2]) <= 1e-9 * h["loss"][2]
 
