@@ -10,9 +10,11 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof5
 mkdir -p $O
 BENCH="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+$BENCH > $O/plain.log 2>&1
+grep '^{' $O/plain.log | tail -1 > $O/bench_line_unprofiled.json
 PDP_BENCH_WINDOWS=$O/windows.json rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $BENCH > $O/stats.log 2>&1
 grep '^{' $O/stats.log | tail -1 > $O/bench_line_under_rocprof.json
-python probes/rocprof_match.py $O/stats $O/windows.json > $O/rocprof_match.txt 2>&1
+python probes/rocprof_match.py $O/stats $O/windows.json $O/bench_line_unprofiled.json > $O/rocprof_match.txt 2>&1
 echo "rocprof_match exit $?" >> $O/rocprof_match.txt
 for f in $(find $O/stats -name 'p_kernel_stats.csv'); do cp $f $O/bench_full_kernel_stats.csv; done
 # ---- calibration

@@ -3,14 +3,15 @@
 figure in the bench line").
 
     PDP_BENCH_WINDOWS=w.json rocprofv3 --kernel-trace --stats --output-format csv -d DIR -o p -- python bench.py ...
-    python probes/rocprof_match.py DIR w.json  >  table
+    python probes/rocprof_match.py DIR w.json [unprofiled_line.json]  >  table
 
 bench.py keeps the host clocks (monotonic / boottime / realtime) around the timed repetitions of every _event_ms call ("timing windows"); rocprofv3's kernel trace
 carries start / end timestamps per dispatch.  The clock domain of the trace is found by trying the three (the right one puts `reps` dispatches of the headline kernel into
 the headline window); then, per window: the dispatches that START inside it, grouped by kernel, their summed duration divided by the window's repetitions = the kernel
 time of one call as rocprofv3 saw it, against the median HIP-event time bench.py printed.  An entry whose call is several launches (the IRL iteration: solve + gradient
 unit; the large-batch steps: rollout pre-pass + step) gets the sum; event time above the sum is launch gap, not kernel time.  Output: one row per entry of
-`other_configs`, the headline window and the timed region, with the ratio and a PASS / GAP verdict at 5 %."""
+`other_configs` / `scaling_configs`, the headline window and the timed region, with the ratio and a verdict: PASS within 5 %, or within 6 us per launch of event / launch
+overhead (a HIP event pair brackets the launches: under the profiler it reads ~5 us more than a kernel it brackets, which exceeds 5 % for kernels below 0.1 ms)."""
 import collections
 import csv
 import glob
@@ -30,7 +31,10 @@ def short(name):
 
 def main():
     d, wfile = sys.argv[1], sys.argv[2]
-    tol = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+    tol = 0.05
+    # optional: the line of an UNPROFILED run of the same command on the same box - a call shorter than the host can issue calls under the profiler (the 27 us C2 gradient
+    # unit: ~39 us per call under rocprofv3) is event-timed host-bound there; its unprofiled event time is what the driver's bench line holds
+    plain = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -68,31 +72,50 @@ def main():
 
     out = []
 
-    def report(label, event_ms, windows):
+    def report(label, event_ms, windows, plain_ms=None):
         tot, parts = 0.0, []
         for k in windows:
             t, p = window_kernels(k)
             tot += t
             parts += p
         ratio = event_ms / tot if tot > 0 else float("nan")
-        verdict = "PASS" if abs(ratio - 1) <= tol else ("GAP (event time above the kernels' sum: launch gaps between several launches / a short kernel)" if ratio > 1 else "FAIL")
+        n_launch = len(parts)
+        # a HIP event pair brackets the launches, not the kernels: under rocprofv3 it reads ~5 us more than the kernel it brackets (measured on every single-kernel row),
+        # plus the gaps between the launches of a multi-launch call
+        over_us = (event_ms - tot) * 1e3
+        if abs(ratio - 1) <= tol:
+            verdict = "PASS"
+        elif 0 <= over_us <= 6.0 * max(1, n_launch):
+            verdict = "PASS (+%.1f us of event / launch overhead around %d launch(es): above %.0f %% only because the kernel is short)" % (over_us, n_launch, 100 * tol)
+        elif plain_ms is not None and (abs(plain_ms / tot - 1) <= tol or 0 <= (plain_ms - tot) * 1e3 <= 6.0 * max(1, n_launch)):
+            verdict = "PASS on the unprofiled line (%.4f ms); under the profiler the host cannot issue this call as fast as the GPU finishes it" % plain_ms
+        else:
+            verdict = "FAIL"
         out.append((label, event_ms, tot, ratio, verdict, parts))
 
-    report("headline kernel_ms (roofline.achieved)", line["roofline"]["kernel_ms"], [hw])
-    report("timed region ms_per_step", line["ms_per_step"], [line["roofline"]["timed_region_window"]])
+    def pl(*keys):
+        v = plain
+        for k in keys:
+            v = v.get(k) if isinstance(v, dict) else (v[k] if isinstance(v, list) and isinstance(k, int) and k < len(v) else None)
+            if v is None:
+                return None
+        return float(v)
+    report("headline kernel_ms (roofline.achieved)", line["roofline"]["kernel_ms"], [hw], pl("roofline", "kernel_ms"))
+    report("timed region ms_per_step", line["ms_per_step"], [line["roofline"]["timed_region_window"]], pl("ms_per_step"))
     for name, e in (line.get("other_configs") or {}).items():
         if isinstance(e, dict) and e.get("timing_windows"):
-            report("other_configs." + name + ".kernel_ms", e["kernel_ms"], e["timing_windows"])
+            report("other_configs." + name + ".kernel_ms", e["kernel_ms"], e["timing_windows"], pl("other_configs", name, "kernel_ms"))
     for name, e in (line.get("scaling_configs") or {}).items():
         if isinstance(e, dict) and e.get("timing_windows"):
-            report("scaling_configs." + name + ".kernel_ms_per_rank[0]", e["kernel_ms_per_rank"][0], e["timing_windows"])
+            report("scaling_configs." + name + ".kernel_ms_per_rank[0]", e["kernel_ms_per_rank"][0], e["timing_windows"], pl("scaling_configs", name, "kernel_ms_per_rank", 0))
     bad = 0
     for label, ev, tot, ratio, verdict, parts in out:
         print("%-70s event %.4f ms   rocprof %.4f ms   ratio %.3f   %s" % (label, ev, tot, ratio, verdict))
         for p in parts:
             print("        " + p)
         bad += verdict == "FAIL"
-    print("# %d rows, %d within %.0f %%, %d with launch gaps, %d FAIL" % (len(out), sum(o[4] == "PASS" for o in out), 100 * tol, sum(o[4].startswith("GAP") for o in out), bad))
+    print("# %d rows, %d within %.0f %%, %d within the event overhead, %d on the unprofiled line, %d FAIL" %
+          (len(out), sum(o[4] == "PASS" for o in out), 100 * tol, sum(o[4].startswith("PASS (") for o in out), sum(o[4].startswith("PASS on") for o in out), bad))
     sys.exit(1 if bad else 0)
 
 
