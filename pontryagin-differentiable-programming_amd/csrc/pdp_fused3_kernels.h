@@ -472,11 +472,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                 Run3 rFT = run3_at(gFT, pb), rGT = run3_at(gGT, pb), rE = run3_at(gE, pb), rDX = run3_at(gDX, pb), rDU = run3_at(gDU, pb);
                 auto move_all = [&](int bytes) { move3(rFT, bytes); move3<1>(rGT, bytes); move3(rE, bytes); move3(rDX, bytes); move3<1>(rDU, bytes); };
                 auto fstep = [&](int tl, unsigned imm, const d4 Xc, d4& Xn, const d4 KTc, const d4 kc, d4& KTnx, d4& knx) {
-#ifdef PDP_F3_EXP_GAINS_STEP0     // timing experiment only (wrong results): every step re-reads the gains of step 0 - always a cache hit: the forward loop without load latency
-                    const int t = t0 + tl, tnx = 0;
-#else
                     const int t = t0 + tl, tnx = (t + PDP_F3_GAIN_AHEAD < T) ? t + PDP_F3_GAIN_AHEAD : T - 1;
-#endif
                     KTnx = -load_all<4>(gw + tnx * GSZ, mKT);
                     knx = -load_all<1>(gw + tnx * GSZ + NX * NU, mIK);
                     d4 FT = read3(rFT, imm);
@@ -609,9 +605,6 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                 F3_W0();
                 f3_wait_ge(fl + 3, g - 1);                       // the buffer's previous chunk has been consumed
                 F3_W1();
-#ifdef PDP_F3_EXP_IDLE_EVALUATOR      // timing experiment only (wrong results): chunks >= 2 are not evaluated, the runner re-uses old pool contents
-                if (g >= 2) { f3_signal(fl + 2, g + 1); continue; }
-#endif
                 if (lane < cnt) {
                     PDP_F3_PAR();
                     const int t = t0 + lane;

@@ -56,9 +56,6 @@ PDP_DEV StoreMap lqs_store_map(const TileMap& m) {
 #define LQS_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 template <int NR = 4, class R>
 PDP_DEV void lqs_store(R rs, const StoreMap& m, unsigned soff, const d4 v) {
-#ifdef PDP_LQS_EXP_NOSTORE      // timing experiment only (wrong results)
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const double x = v[k];          // (bit-casting the vector element directly made every store write register 0's value)
