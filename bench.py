@@ -410,6 +410,37 @@ def other_configs(torch):
           executed_flop=4.8e3 * T,
           note="register-resident MLP adjoint kernel (cp_step_mlp16_kernel): O(T (n^2 + p)) work - executed_flop_per_traj - instead of the O(T n^2 p) forward "
                "sensitivities that section 8d's 24.4 MFLOP figure counts and the kernel does not execute; one GPU's shard of C5")
+    # ---- the recovery-matrix drivers (Examples/OC/quadrotor/uav_PDP_Recmat.py: T = 35, p = 140; Examples/OC/rocket/rocket_PDP_Recmat.py: T = 50, p = 150): ONE trajectory,
+    # one parameter per control and time step, gradient descent with recmat_step.  BASELINE.md section 2 records 112 - 226 iterations/s for the reference on its author's
+    # machine.  Here recmat_step is one launch (PDP_POLICY_TABLE on the size-generic adjoint kernel) and the loop is step + update replayed as a hipGraph.
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import oc_recmat_pdp as rex
+        from pdp_amd.irl import GDLoop
+        import time as _time
+        for system, ref_its in (("quadrotor", "112-226 it/s (BASELINE.md section 2, uav_PDP_Recmat.py)"), ("rocket", "112-226 it/s (BASELINE.md section 2, rocket_PDP_Recmat.py)")):
+            cp_, _, _ = rex.build(system)
+            T_ = rex.SETUP[system]["horizon"]
+            x0_ = np.array(rex.SETUP[system]["x0"], dtype=float)
+            cp_.recmat_init_step(T_, -1)
+            th_ = rt.dev((2.5 if system == "quadrotor" else 3.0) + 0.1 * rng.standard_normal(cp_.n_auxvar))
+            fn = cp_.warped_step_fn(x0_)
+            ms = _event_ms(torch, lambda: fn(th_), reps=10, warm=2)
+            lp = GDLoop(fn, th_.cpu().numpy(), 1e-4, max_steps=1200)
+            lp.capture()
+            lp.run(50)
+            torch.cuda.synchronize()
+            t0_ = _time.perf_counter()
+            lp.run(1000)
+            torch.cuda.synchronize()
+            it_ms = 1e3 * (_time.perf_counter() - t0_) / 1000
+            r_ = lp.results()
+            entry("recmat_%s_T%d_p%d_B1" % (system, T_, cp_.n_auxvar), 1, ms, T=T_, latency_bound=True,
+                  note="recmat_step for ONE trajectory (the reference's driver): rollout + costates + per-cell H_u sums in one launch of the size-generic adjoint kernel",
+                  extra={"gd_loop_iterations_per_s_hipgraph_replay": 1e3 / it_ms, "gd_loop_ms_per_iteration": it_ms, "reference_recorded": ref_its,
+                         "loss_first_last": [float(r_["loss_trace"][0]), float(r_["loss_trace"][-1])], "parameters": int(cp_.n_auxvar)})
+    except Exception as e_:
+        res["recmat_drivers"] = {"error": repr(e_)[:300]}
     # ---- the reference's materialised API route on C3 sizes (HBM-bound by construction)
     mdl = zoo.get("quadrotor", "irl")
     B, T = 1024, 50

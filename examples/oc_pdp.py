@@ -60,7 +60,15 @@ def main():
         if k % max(1, a.iters // 10) == 0:
             print("iter %5d  mean loss %.6e" % (k, loss_trace[-1]))
     sol = oc.integrateSys(x0[0], a.horizon, theta[0])
-    save = {"trail_no": 0, "parameter_trace": [theta[0]], "loss_trace": loss_trace, "learning_rate": a.lr, "solved_solution": sol,
+    # the "true" solution the reference stores beside it (Examples/OC/quadrotor/uav_PDP.py:34-41, 76-83): OCSys.ocSolver on the same problem from the same initial state
+    true_oc = PDP.OCSys(a.system + " true oc")
+    true_oc.setStateVariable(env.X)
+    true_oc.setControlVariable(env.U)
+    true_oc.setDyn(env.X + dt * env.f)
+    true_oc.setPathCost(env.path_cost)
+    true_oc.setFinalCost(env.final_cost)
+    true_sol = true_oc.ocSolver(ini_state=x0[0], horizon=a.horizon)
+    save = {"trail_no": 0, "parameter_trace": [theta[0]], "loss_trace": loss_trace, "learning_rate": a.lr, "solved_solution": sol, "true_solution": true_sol,
             "time_passed": time.time() - t0, "dt": dt, "horizon": a.horizon}
     if a.out:
         sio.savemat(a.out, {"results": save})

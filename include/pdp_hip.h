@@ -316,12 +316,18 @@ int pdp_oc_predict_record_batched(int B, int T, const double* dtheta, int dtheta
  * column-major vec, layers = hidden + [m]). */
 #define PDP_POLICY_POLY 0
 #define PDP_POLICY_MLP 1
+#define PDP_POLICY_TABLE 2   /* u_t = sum_i table[t][i] theta[i m .. i m + m): an open-loop policy given by its basis values at every step.  recmat_* (PDP.py:1081-1141):
+                                table[t][i] = 1 where step t lies in grid cell i (theta = the control of every cell); warp_* (PDP.py:960-1008): the Lagrange basis on the cell
+                                index.  Served by pdp_cp_integrate_batched and pdp_cp_step_batched (size-generic adjoint kernel) */
 typedef struct pdp_policy {
     int kind;
     int n_pivots;            /* POLY: number of pivots (<= 16) */
     double pivots[16];       /* POLY: pivot times */
-    int n_layers;            /* MLP: number of weight layers (<= 8), sizes[k] = rows of A_k, last = m */
-    int sizes[8];
+    int n_layers;            /* MLP: number of weight layers (<= 16), sizes[k] = rows of A_k, last = m.  Up to 4 layers of <= 16 units: register-resident kernel; up to 8 of
+                                <= 32 (p <= 512): LDS-resident adjoint kernel; anything else: the size-generic kernel (csrc/pdp_cp_generic_kernels.h) */
+    int sizes[16];
+    int n_basis;             /* TABLE: number of basis functions (p = n_basis * m) */
+    const double* table;     /* TABLE: device memory, [T][n_basis] row-major */
 } pdp_policy;
 
 /* ControlPlanning.integrateSys (PDP.py:763-786): x0 [B][n], theta -> x [B][T+1][n], u [B][T][m], cost [B]. */

@@ -507,19 +507,12 @@ class ControlPlanning:
 
 
     # ---- warped / recovery-matrix variants (reference PDP.py:882-1141) -----------------------------------------------
-    # The horizon is cut into <= 10 grid cells with one control per cell.  The reference composes the dynamics symbolically
-    # over every cell (warp_dynCost) and, for recmat, builds ONE symbolic expression of the whole-horizon gradient
-    # (recmat_recoveryMatrix).  That gradient is d cost / d (cell control) = sum over the cell of H_u(x_t, u_t, lambda_{t+1})
-    # with the PMP costates lambda - so here it is ONE adjoint sweep with kernels that already exist:
-    # rollout -> costates -> dH/du per step -> segment sums.  No symbolic composition, cost O(T n^2) instead of O(T n^2 p).
-    def _adjoint_model(self):
-        if getattr(self, "_adj", None) is None:
-            pb = codegen.Problem(codegen.KIND_OC, self.state, self.control, self.dyn, SX.sym("unused_auxvar"), self.path_cost, self.final_cost,
-                                 label=_label(self.project_name))
-            lib, _ = codegen.build_problem(pb)
-            self._adj = runtime.load_model(lib)
-        return self._adj
-
+    # The horizon is cut into grid cells with one control per cell.  The reference composes the dynamics symbolically over every cell (warp_dynCost) and, for
+    # recmat, builds ONE symbolic expression of the whole-horizon gradient (recmat_recoveryMatrix).  That gradient is d cost / d (cell control) = the sum over the
+    # cell of H_u(x_t, u_t, lambda_{t+1}) with the PMP costates lambda - one adjoint sweep.  Both variants are OPEN-LOOP policies whose control at step t is a fixed
+    # linear combination of the parameter blocks:  u_t = sum_i table[t][i] theta_i  (recmat: table[t][i] = 1 for the cell of t; warp: the Lagrange basis on the cell
+    # index), i.e. PDP_POLICY_TABLE of pdp_cp_step_batched: rollout, costates and the per-cell sums in ONE launch of the size-generic adjoint kernel
+    # (csrc/pdp_cp_generic_kernels.h), any number of cells.  The table is built once in *_init_step.
     def _make_time_grid(self, horizon, time_grid, full_grid_points):
         if time_grid is None:
             time_grid = numpy.linspace(0, 1, numpy.amin([horizon + 1, 11]))
@@ -534,6 +527,16 @@ class ControlPlanning:
     def warp_init_step(self, horizon, time_grid=None):                          # PDP.py:960-978
         self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon - 1, horizon))
         self.setPolyControl(numpy.linspace(0, self.whorizon, self.whorizon + 1))
+        # Lagrange basis on the cell index, factors applied left to right as PDP.py:705-716: basis[w, i] = prod_{j != i} (w - tau_j) / (tau_i - tau_j)
+        W, piv = self.whorizon, numpy.asarray(self.pivots)
+        w = numpy.arange(W, dtype=float)[:, None]
+        basis = numpy.ones((W, W + 1))
+        for j in range(W + 1):
+            own = numpy.arange(W + 1)[None, :] == j                                               # (column j itself takes no factor)
+            basis = numpy.where(own, basis, basis * (w - piv[j]) / numpy.where(own, 1.0, piv[None, :] - piv[j]))
+        self._wbasis = basis
+        self._wtable, self._wpolicy = basis[self._cell_of_t], None            # (the device copy of the table is made on the first step: *_init_step needs no GPU)
+        self._wmode = "warp"
 
     # ---- the symbolic internals of the warped / recovery-matrix variants, for callers that use them directly.  warp_step / recmat_step above do
     # NOT go through them (they run one adjoint sweep on the GPU); these three build the reference's per-cell Function lists and its whole-horizon
@@ -592,61 +595,59 @@ class ControlPlanning:
         self._make_time_grid(horizon, time_grid, numpy.linspace(0, horizon, horizon + 1))
         self.n_auxvar = self.whorizon * self.n_control
         self.auxvar = SX.sym("U", self.n_auxvar)
+        table = numpy.zeros((len(self._cell_of_t), self.whorizon))
+        table[numpy.arange(len(self._cell_of_t)), self._cell_of_t] = 1.0          # theta IS the control of every cell
+        self._wtable, self._wpolicy = table, None
+        self._wmode = "recmat"
 
     def _cell_controls(self, theta, mode):
-        """[B, whorizon, m] control of every grid cell"""
+        """[B, whorizon, m] control of every grid cell (host arithmetic for the result dictionaries, not on the step's path)"""
         th = np.atleast_2d(np.asarray(theta, float))
         if mode == "recmat":
             return th.reshape(th.shape[0], self.whorizon, self.n_control)
-        W = self.whorizon
-        piv = np.asarray(self.pivots)
-        basis = np.ones((W, W + 1))
-        for wt in range(W):
-            for i in range(W + 1):
-                for j in range(W + 1):
-                    if j != i:
-                        basis[wt, i] = basis[wt, i] * (wt - piv[j]) / (piv[i] - piv[j])
-        self._wbasis = basis
-        return np.einsum("wi,bim->bwm", basis, th.reshape(th.shape[0], W + 1, self.n_control))
+        return np.einsum("wi,bim->bwm", self._wbasis, th.reshape(th.shape[0], self.whorizon + 1, self.n_control))
 
     def _warped_adjoint(self, ini_state, auxvar_value, mode):
-        """(cost [B], d cost / d cell-control [B, whorizon, m], state [B,T+1,n], control [B,T,m])"""
-        torch = runtime.torch_cuda()
-        mdl = self._adjoint_model()
-        x0 = np.atleast_2d(np.asarray(ini_state, float))
-        uc = self._cell_controls(auxvar_value, mode)
-        if uc.shape[0] == 1 and x0.shape[0] > 1:
-            uc = np.repeat(uc, x0.shape[0], axis=0)
-        u = runtime.dev(uc[:, self._cell_of_t, :])
-        dummy = np.zeros(1)
-        x, cost = mdl.oc_rollout(x0, u, dummy)
-        lam = mdl.oc_costate(x, u, dummy)
-        dHu = mdl.oc_auxsys(x, u, lam, dummy, only=("dHu",))["dHu"]                 # [B,T,m]
-        g = torch.zeros((u.shape[0], self.whorizon, self.n_control), dtype=torch.float64, device="cuda")
-        g.index_add_(1, torch.as_tensor(self._cell_of_t, device="cuda"), dHu)
-        return cost, g, x, u
+        """(cost [B], d cost / d theta [B, p], state [B,T+1,n], control [B,T,m]) - one launch (pdp_cp_step_batched with the table policy of *_init_step)"""
+        assert getattr(self, "_wmode", None) == mode, "run %s_init_step first!" % mode
+        return self.model().cp_step(self._table_policy(), self.n_auxvar, ini_state, auxvar_value, len(self._cell_of_t), want_traj=True)
+
+    def _table_policy(self):
+        if self._wpolicy is None:
+            self._wpolicy = runtime.make_policy("table", table=self._wtable)
+        return self._wpolicy
+
+    def warped_step_fn(self, ini_state):
+        """theta (a CUDA tensor [p] or [B, p]) -> (loss [B], grad [B, p]): the step of the variant set up by warp_init_step / recmat_init_step as a function of the
+        parameter alone - what pdp_amd.irl.GDLoop replays (Examples/OC/rocket/rocket_PDP_Recmat.py:47-64 as two launches per iteration)"""
+        x0 = runtime.dev(np.atleast_2d(np.asarray(ini_state, float)))
+        mdl, pol, p, T = self.model(), self._table_policy(), self.n_auxvar, len(self._cell_of_t)
+        return lambda th: mdl.cp_step(pol, p, x0, th, T)
 
     def recmat_step(self, ini_state, horizon, auxvar_value):                    # PDP.py:1100-1114
-        cost, g, _, _ = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "recmat")
-        return float(cost[0]), _np(g)[0].reshape(-1)
+        cost, g, _, _ = self._warped_adjoint(_vec(ini_state)[None], _vec(auxvar_value), "recmat")
+        return float(cost[0]), _np(g)[0]
 
     def recmat_step_batch(self, ini_state, horizon, auxvar_value):
         cost, g, _, _ = self._warped_adjoint(ini_state, auxvar_value, "recmat")
-        return cost, g.reshape(g.shape[0], -1)
+        return cost, g
 
     def warp_step(self, ini_state, horizon, auxvar_value):                      # PDP.py:980-1008
         assert hasattr(self, "time_grid"), "Run warp_init_step first!"
-        cost, g, _, _ = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "warp")
-        dtheta = np.einsum("wi,wm->im", self._wbasis, _np(g)[0])                 # chain rule through the Lagrange policy on the cell index
-        return float(cost[0]), dtheta.reshape(-1)
+        cost, g, _, _ = self._warped_adjoint(_vec(ini_state)[None], _vec(auxvar_value), "warp")       # (the chain rule through the Lagrange policy on the cell index is in the table)
+        return float(cost[0]), _np(g)[0]
+
+    def warp_step_batch(self, ini_state, horizon, auxvar_value):
+        cost, g, _, _ = self._warped_adjoint(ini_state, auxvar_value, "warp")
+        return cost, g
 
     def warp_integrateSys(self, ini_state, whorizon, auxvar_value):             # PDP.py:917-938
-        cost, _, x, u = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), "warp")
+        cost, _, x, u = self._warped_adjoint(_vec(ini_state)[None], _vec(auxvar_value), "warp")
         x, uc = _np(x)[0], self._cell_controls(_vec(auxvar_value), "warp")[0]
         return {"wstate_traj": x[self.time_grid], "wcontrol_traj": uc, "wcost": float(cost[0])}
 
     def _unwarp(self, ini_state, auxvar_value, mode):
-        cost, _, x, u = self._warped_adjoint(_vec(ini_state), _vec(auxvar_value), mode)
+        cost, _, x, u = self._warped_adjoint(_vec(ini_state)[None], _vec(auxvar_value), mode)
         return {"state_traj": _np(x)[0], "control_traj": _np(u)[0], "cost": np.array([float(cost[0])])}
 
     def warp_unwarp(self, ini_state, horizon, auxvar_value):                    # PDP.py:1010-1035

@@ -167,6 +167,87 @@ __global__ void __launch_bounds__(1024) gd_update_kernel(int B, int p, const dou
     if (tid == 0) { counters[0] = k + 1; counters[1] += (long long)cnt[0]; counters[2] += (long long)cnt[1]; counters[3] += (long long)cnt[2]; }
 }
 
+// the same update for parameter vectors beyond one workgroup's width (p + 1 > 1024: a [64, 64] policy has 5316): a thread owns the columns tid, tid + 1024, ... and sums
+// each over the batch in ascending order
+__global__ void __launch_bounds__(1024) gd_update_wide_kernel(int B, int p, const double* __restrict__ loss, const double* __restrict__ grad, int gs, const int32_t* __restrict__ status,
+                                                              const int32_t* __restrict__ converged, const int32_t* __restrict__ iterations, double lr, double* __restrict__ theta,
+                                                              double* __restrict__ dtheta, double* __restrict__ loss_trace, double* __restrict__ par_trace, long long trace_len,
+                                                              long long* __restrict__ counters) {
+    __shared__ unsigned long long cnt[3];
+    const int tid = threadIdx.x;
+    if (tid < 3) cnt[tid] = 0;
+    unsigned long long unc = 0, trb = 0, nwt = 0;
+    for (int b = tid; b < B; b += 1024) {
+        if (converged) unc += converged[b] == 0;
+        if (status) trb += status[b] != 0;
+        if (iterations) nwt += (unsigned long long)iterations[b];
+    }
+    __syncthreads();
+    if (unc) atomicAdd(&cnt[0], unc);
+    if (trb) atomicAdd(&cnt[1], trb);
+    if (nwt) atomicAdd(&cnt[2], nwt);
+    const long long k = counters[0];
+    for (int j = tid; j <= p; j += 1024) {
+        double sum = 0.0;
+        if (j < p) { for (int b = 0; b < B; ++b) sum += grad[(int64_t)b * gs + j]; }
+        else { for (int b = 0; b < B; ++b) sum += loss[b]; }
+        const double mean = sum / (double)B;
+        if (j < p) {
+            const double d = -lr * mean, th = theta[j] + d;
+            dtheta[j] = d;
+            theta[j] = th;
+            if (par_trace && k < trace_len) par_trace[k * p + j] = th;
+        } else if (loss_trace && k < trace_len) loss_trace[k] = mean;
+    }
+    __syncthreads();
+    if (tid == 0) { counters[0] = k + 1; counters[1] += (long long)cnt[0]; counters[2] += (long long)cnt[1]; counters[3] += (long long)cnt[2]; }
+}
+
+// ---- integrateAuxSys beyond one tile per matrix (ControlPlanning PDP.py:813-838, SysID PDP.py:1241-1259; n > 16): one LANE per (trajectory, parameter column), plain
+// loops over global memory - U_t[:, j] = Ux_t X_t[:, j] + Ue_t[:, j], X_{t+1}[:, j] = F_t X_t[:, j] + G_t U_t[:, j] (+ E_t[:, j]).  The column of X_t is read back from
+// the output array the same lane wrote.  Correctness first: these are the materialised drop-ins, the fused step kernels do not come through here.
+__global__ void __launch_bounds__(64) cp_aux_generic_kernel(int B, int T, int n, int m, int p, const double* __restrict__ F, const double* __restrict__ G,
+                                                            const double* __restrict__ Ux, const double* __restrict__ Ue, const double* __restrict__ X0,
+                                                            double* __restrict__ X, double* __restrict__ U) {
+    const int64_t id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (id >= (int64_t)B * p) return;
+    const int b = (int)(id / p), j = (int)(id - (int64_t)b * p);
+    double* Xb = X + (int64_t)b * (T + 1) * n * p;
+    double* Ub = U + (int64_t)b * T * m * p;
+    for (int i = 0; i < n; ++i) Xb[i * p + j] = X0 ? X0[((int64_t)b * n + i) * p + j] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double *Ft = F + ((int64_t)b * T + t) * n * n, *Gt = G + ((int64_t)b * T + t) * n * m, *Uxt = Ux + ((int64_t)b * T + t) * m * n,
+                     *Uet = Ue + ((int64_t)b * T + t) * m * p;
+        const double* xc = Xb + (int64_t)t * n * p;
+        double* xn = Xb + (int64_t)(t + 1) * n * p;
+        double* ut = Ub + (int64_t)t * m * p;
+        for (int r = 0; r < m; ++r) { double s = Uet[r * p + j]; for (int k = 0; k < n; ++k) s += Uxt[r * n + k] * xc[k * p + j]; ut[r * p + j] = s; }
+        __threadfence_block();
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += Ft[i * n + k] * xc[k * p + j];
+            for (int r = 0; r < m; ++r) s += Gt[i * m + r] * ut[r * p + j];
+            xn[i * p + j] = s;
+        }
+        __threadfence_block();
+    }
+}
+__global__ void __launch_bounds__(64) sysid_aux_generic_kernel(int B, int T, int n, int p, const double* __restrict__ F, const double* __restrict__ E,
+                                                               const double* __restrict__ X0, double* __restrict__ X) {
+    const int64_t id = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (id >= (int64_t)B * p) return;
+    const int b = (int)(id / p), j = (int)(id - (int64_t)b * p);
+    double* Xb = X + (int64_t)b * (T + 1) * n * p;
+    for (int i = 0; i < n; ++i) Xb[i * p + j] = X0 ? X0[((int64_t)b * n + i) * p + j] : 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double *Ft = F + ((int64_t)b * T + t) * n * n, *Et = E + ((int64_t)b * T + t) * n * p;
+        const double* xc = Xb + (int64_t)t * n * p;
+        double* xn = Xb + (int64_t)(t + 1) * n * p;
+        for (int i = 0; i < n; ++i) { double s = Et[i * p + j]; for (int k = 0; k < n; ++k) s += Ft[i * n + k] * xc[k * p + j]; xn[i * p + j] = s; }
+        __threadfence_block();
+    }
+}
+
 template <int M>
 int launch_lqr(const pdp_lqr_problem& pr, int nt, double* X, double* U, double* Lam, int32_t* status, double* wg, double* wpw, hipStream_t s) {
     dim3 grid(pr.B), block(64);
@@ -190,9 +271,13 @@ const char* pdp_hip_version(void) { return "pdp_hip 0.1 gfx950"; }
 int pdp_lqs_read_stamps(long long* out, void* stream) { hipLaunchKernelGGL(lqs_read_stamps, dim3(1), dim3(64), 0, (hipStream_t)stream, out); return launched(); }
 #endif
 
+// gains (+ P, W for the costate output) per stage; systems beyond one tile per matrix whose working set does not fit the LDS add their scratch per trajectory
+static int64_t lqr_stage_doubles(int n, int m, int p, int want_costate) { return (int64_t)n * m + (int64_t)m * p + (want_costate ? (int64_t)n * n + (int64_t)n * p : 0); }
 int64_t pdp_lqr_workspace_bytes(int B, int T, int n, int m, int p, int want_costate) {
-    int64_t per = (int64_t)n * m + (int64_t)m * p + (want_costate ? (int64_t)n * n + (int64_t)n * p : 0);
-    return (int64_t)B * T * per * (int64_t)sizeof(double);
+    int64_t d = (int64_t)B * T * lqr_stage_doubles(n, m, p, want_costate);
+    const int pl = p < GEN_PMAX ? p : GEN_PMAX;
+    if ((n > 16 || m > 4) && !lqr_generic_in_lds(n, m, pl)) d += (int64_t)B * (int64_t)lqr_generic_lds_doubles(n, m, pl);
+    return d * (int64_t)sizeof(double);
 }
 
 int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, double* Lam, int32_t* status, void* workspace,
@@ -201,15 +286,20 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
     const pdp_lqr_problem& pr = *prob;
     if (pr.B <= 0 || pr.T <= 0 || pr.n <= 0 || pr.m <= 0 || pr.p <= 0) return PDP_E_ARG;
     if (!pr.F.ptr || !pr.G.ptr || !pr.Hxx.ptr || !pr.Huu.ptr || !pr.hxx.ptr) return PDP_E_ARG;
-    if (pr.n > 16 || pr.m > 4) {                   // beyond one tile per matrix: the generic LDS kernel (n <= 32, m <= 8, p <= 32 per launch)
-        if (pr.n > GEN_NMAX || pr.m > GEN_MMAX || pr.p > GEN_PMAX) return PDP_E_SIZE;
+    if (pr.n > 16 || pr.m > 4) {                   // beyond one tile per matrix: the size-generic kernel (any n, m; p <= 32 per launch - the callers cut more into column blocks)
+        if (pr.p > GEN_PMAX) return PDP_E_SIZE;
         if (workspace_bytes < pdp_lqr_workspace_bytes(pr.B, pr.T, pr.n, pr.m, pr.p, Lam != nullptr)) return PDP_E_ARG;
         double* wg = (double*)workspace;
-        double* wpw = Lam ? wg + (int64_t)pr.B * pr.T * (pr.n * pr.m + pr.m * pr.p) : nullptr;
-        const size_t lds = sizeof(double) * lqr_generic_lds_doubles(pr.n, pr.m, pr.p);
-        (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        double* wpw = Lam ? wg + (int64_t)pr.B * pr.T * ((int64_t)pr.n * pr.m + (int64_t)pr.m * pr.p) : nullptr;
+        double* wscr = wg + (int64_t)pr.B * pr.T * lqr_stage_doubles(pr.n, pr.m, pr.p, Lam != nullptr);
         PDP_CLEAR();
-        hipLaunchKernelGGL(lqr_solve_generic_kernel, dim3(pr.B), dim3(64), lds, (hipStream_t)stream, pr, X, U, Lam, status, wg, wpw);
+        if (lqr_generic_in_lds(pr.n, pr.m, pr.p)) {
+            const size_t lds = sizeof(double) * lqr_generic_lds_doubles(pr.n, pr.m, pr.p);
+            (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(lqr_solve_generic_kernel<false>, dim3(pr.B), dim3(64), lds, (hipStream_t)stream, pr, X, U, Lam, status, wg, wpw, (double*)nullptr);
+        } else {
+            hipLaunchKernelGGL(lqr_solve_generic_kernel<true>, dim3(pr.B), dim3(64), 0, (hipStream_t)stream, pr, X, U, Lam, status, wg, wpw, wscr);
+        }
         return launched();
     }
     for (const pdp_mat* mt : {&pr.F, &pr.G, &pr.E, &pr.Hxx, &pr.Hxu, &pr.Hxe, &pr.Huu, &pr.Hue})       // per-lane byte strides are 32-bit
@@ -261,8 +351,11 @@ int pdp_lqr_solve_batched(const pdp_lqr_problem* prob, double* X, double* U, dou
 int pdp_cp_aux_integrate_batched(int B, int T, int n, int m, int p, const double* F, const double* G, const double* Ux, const double* Ue,
                                  const double* X0, double* X, double* U, void* stream) {
     if (B <= 0 || T <= 0 || n <= 0 || m <= 0 || p <= 0 || !F || !G || !Ux || !Ue || !X || !U) return PDP_E_ARG;
-    if (n > 16 || m > 16) return PDP_E_SIZE;
     PDP_CLEAR();
+    if (n > 16 || m > 16) {         // beyond one tile per matrix: lane per (trajectory, column), any size
+        hipLaunchKernelGGL(cp_aux_generic_kernel, dim3((unsigned)(((int64_t)B * p + 63) / 64)), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
+        return launched();
+    }
     const int ntile = (p + 15) / 16;
     if (ntile == 1) hipLaunchKernelGGL(cp_aux_kernel<1>, dim3(B, 1), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
     else hipLaunchKernelGGL(cp_aux_kernel<2>, dim3(B, (ntile + 1) / 2), dim3(64), 0, (hipStream_t)stream, B, T, n, m, p, F, G, Ux, Ue, X0, X, U);
@@ -280,8 +373,12 @@ int pdp_cp_grad_contract_batched(int B, int T, int n, int m, int p, const double
 int pdp_gd_update_batched(int B, int p, const double* loss, const double* grad, int grad_bstride, const int32_t* status, const int32_t* converged, const int32_t* iterations,
                           double lr, double* theta, double* dtheta, double* loss_trace, double* parameter_trace, int64_t trace_len, int64_t* counters, void* stream) {
     if (B <= 0 || p <= 0 || !loss || !grad || grad_bstride < p || !theta || !dtheta || !counters) return PDP_E_ARG;
-    if (p + 1 > 1024) return PDP_E_SIZE;
     PDP_CLEAR();
+    if (p + 1 > 1024) {
+        hipLaunchKernelGGL(gd_update_wide_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, p, loss, grad, grad_bstride, status, converged, iterations, lr, theta, dtheta,
+                           loss_trace, parameter_trace, (long long)trace_len, (long long*)counters);
+        return launched();
+    }
     hipLaunchKernelGGL(gd_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, p, loss, grad, grad_bstride, status, converged, iterations, lr, theta, dtheta, loss_trace,
                        parameter_trace, (long long)trace_len, (long long*)counters);
     return launched();
@@ -289,8 +386,11 @@ int pdp_gd_update_batched(int B, int p, const double* loss, const double* grad, 
 
 int pdp_sysid_aux_integrate_batched(int B, int T, int n, int p, const double* F, const double* E, const double* X0, double* X, void* stream) {
     if (B <= 0 || T <= 0 || n <= 0 || p <= 0 || !F || !E || !X) return PDP_E_ARG;
-    if (n > 16) return PDP_E_SIZE;
     PDP_CLEAR();
+    if (n > 16) {
+        hipLaunchKernelGGL(sysid_aux_generic_kernel, dim3((unsigned)(((int64_t)B * p + 63) / 64)), dim3(64), 0, (hipStream_t)stream, B, T, n, p, F, E, X0, X);
+        return launched();
+    }
     hipLaunchKernelGGL(sysid_aux_kernel, dim3(B, (p + 15) / 16), dim3(64), 0, (hipStream_t)stream, B, T, n, p, F, E, X0, X);
     return launched();
 }

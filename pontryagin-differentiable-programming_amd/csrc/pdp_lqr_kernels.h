@@ -377,21 +377,31 @@ __global__ void __launch_bounds__(64) lqr_solve_small_kernel(pdp_lqr_problem pr,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// Larger systems (16 < n <= 32 or 4 < m <= 8; p <= 32 per launch): the reference accepts any size (PDP.py:446-555).  Beyond one 16x16 tile
-// per matrix the recursion runs as plain lane-parallel fp64 loops over LDS-resident P, W and products - one wavefront per trajectory, every
-// output element of a product owned by one lane, the m x m system solved by Gauss-Jordan with partial pivoting on the augmented block
-// [Quu | Qux | Que].  Same Schur-complement algebra, inputs, outputs and workspace layout as lqr_solve_kernel; not tuned - it exists so
-// that models outside the tile kernels' limits run on the GPU at all.
+// Larger systems (n > 16 or m > 4; p <= 32 per launch - more parameters go through the caller's column blocks): the reference accepts any size
+// (PDP.py:446-555), so does this kernel.  Beyond one 16x16 tile per matrix the recursion runs as plain lane-parallel fp64 loops over P, W and the
+// products - one wavefront per trajectory, every output element of a product owned by one lane, the m x m system solved by Gauss-Jordan with
+// partial pivoting on the augmented block [Quu | Qux | Que].  The working set (3 n^2 + 2 n p + ... doubles) lives in LDS while it fits 150 KB
+// (n up to ~70) and in the caller's workspace beyond (GLOBAL = true: the same code on global pointers, the lanes' hand-overs ordered by a
+// workgroup-scope fence - a CU's vector cache is coherent for its own stores).  Same Schur-complement algebra, inputs, outputs and workspace
+// layout as lqr_solve_kernel; not tuned - it exists so that no model size is refused (round 4: n > 32 or m > 8 returned PDP_E_SIZE).
 // ---------------------------------------------------------------------------------------------------------------------------------------
-constexpr int GEN_NMAX = 32, GEN_MMAX = 8, GEN_PMAX = 32;
-__host__ __device__ inline size_t lqr_generic_lds_doubles(int n, int m, int p) {
-    return (size_t)3 * n * n + (size_t)2 * n * p + (size_t)n * m + (size_t)m * (m + n + p) + (size_t)m * n + (size_t)m * p + 2 * (size_t)n * p + 8 + (size_t)GEN_MMAX * GEN_MMAX;
+constexpr int GEN_PMAX = 32;
+__host__ __device__ constexpr size_t lqr_generic_lds_doubles(int n, int m, int p) {
+    return (size_t)3 * n * n + (size_t)2 * n * p + (size_t)n * m + (size_t)m * (m + n + p) + (size_t)m * n + (size_t)m * p + 2 * (size_t)n * p + 8 + (size_t)m * m;
 }
+__host__ __device__ constexpr bool lqr_generic_in_lds(int n, int m, int p) { return lqr_generic_lds_doubles(n, m, p) * sizeof(double) <= 150 * 1024; }
 
+template <bool GLOBAL>
 __global__ void __launch_bounds__(64) lqr_solve_generic_kernel(pdp_lqr_problem pr, double* __restrict__ Xo, double* __restrict__ Uo, double* __restrict__ Lo,
-                                                                int32_t* __restrict__ status, double* __restrict__ ws_gain, double* __restrict__ ws_pw) {
-    extern __shared__ __attribute__((aligned(16))) double gl[];
+                                                                int32_t* __restrict__ status, double* __restrict__ ws_gain, double* __restrict__ ws_pw,
+                                                                double* __restrict__ ws_scratch) {
+    extern __shared__ __attribute__((aligned(16))) double gl_lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
+    double* gl = GLOBAL ? ws_scratch + (int64_t)b * (int64_t)lqr_generic_lds_doubles(pr.n, pr.m, pr.p) : gl_lds;
+    auto wave_lds_sync = [&]() {        // (shadows the LDS-only wait: the working set may be in global memory)
+        if constexpr (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     const int n = pr.n, m = pr.m, p = pr.p, T = pr.T, wa = m + n + p;
     double* P = gl;                  // n x n
     double* PF = P + n * n;          // n x n

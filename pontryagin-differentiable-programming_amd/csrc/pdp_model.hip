@@ -19,6 +19,7 @@ namespace pdp { extern __device__ long long g_rb_stamp[16]; }
 #include "pdp_cp_mlp_kernels.h"
 #include "pdp_fused3_kernels.h"
 #include "pdp_cp_pair_kernels.h"
+#include "pdp_cp_generic_kernels.h"
 #include <cstdlib>
 
 using namespace pdp;
@@ -193,7 +194,7 @@ struct OcSolveWs {
 template <class Mdl>
 int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u, double* x, double* lam, double* cost, double* grad_norm,
              int32_t* converged, double* gains, const pdp_oc_solve_opts* op, int* iterations, void* ws, int64_t wsb, void* stv) {
-    if constexpr (Mdl::KIND == PDP_KIND_OC && Mdl::NX <= GEN_NMAX && Mdl::NU <= GEN_MMAX) {      // beyond n = 16 / m = 4 the LQ step runs on the generic LDS kernel
+    if constexpr (Mdl::KIND == PDP_KIND_OC && lqr_generic_in_lds(Mdl::NX, Mdl::NU, 1)) {      // beyond n = 16 / m = 4 the LQ step runs on the size-generic kernel (working set in LDS: n up to ~75)
         constexpr int n = Mdl::NX, m = Mdl::NU;
         if (B <= 0 || T <= 0 || !x0 || !th || !u || !x || !lam || !op || !ws) return PDP_E_ARG;
         const int K = op->ls_trials > 0 ? op->ls_trials : 10, every = op->check_every > 0 ? op->check_every : 4;
@@ -221,8 +222,9 @@ int oc_solve(int B, int T, const double* x0, const double* th, int tb, double* u
                 hipLaunchKernelGGL((lqr_solve_kernel<m, 1>), dim3(B), dim3(64), 0, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
             else {
                 const size_t lds = sizeof(double) * lqr_generic_lds_doubles(n, m, 1);
-                (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(lqr_solve_generic_kernel, dim3(B), dim3(64), lds, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr);
+                (void)hipFuncSetAttribute((const void*)lqr_solve_generic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(lqr_solve_generic_kernel<false>, dim3(B), dim3(64), lds, st, pr, w.dX, w.dU, (double*)nullptr, w.st.lqr_status, w.lqr, (double*)nullptr,
+                                   (double*)nullptr);
             }
         };
         pdp_oc_auxsys only_hu{}, hess{};
@@ -335,12 +337,14 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
     } else { return Mdl::KIND == PDP_KIND_OC ? PDP_E_SIZE : PDP_E_MODE; }
 }
 
+template <class Mdl> bool cp_policy_args_ok(const pdp_policy* pol, int p);
 template <class Mdl>
 int cp_integrate(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* x, double* u, double* cost, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
         if (B <= 0 || T <= 0 || !pol || !x0 || !th) return PDP_E_ARG;
-        if (pol->kind == PDP_POLICY_MLP) for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return PDP_E_SIZE;
-        if (Mdl::NX > MLP_MAX_WIDTH) return PDP_E_SIZE;
+        // (networks beyond the lane-local arrays of this lane-per-trajectory integrator: PDP_E_SIZE tells the caller to take pdp_cp_step_batched's size-generic kernel,
+        // which rolls out as well - runtime.cp_integrate does)
+        if (pol->kind == PDP_POLICY_MLP) { if (pol->n_layers > 8) return PDP_E_SIZE; for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return PDP_E_SIZE; }
         PDP_CLEAR();
         hipLaunchKernelGGL((cp_integrate_kernel<Mdl>), dim3((B + 63) / 64), dim3(64), 0, S(st), B, T, *pol, p, x0, th, tb, x, u, cost);
         return launched();
@@ -351,10 +355,22 @@ int cp_auxsys(int B, int T, const pdp_policy* pol, int p, const double* x, const
               double* Ux, double* Ue, double* cx, double* cu, double* hx, void* st) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
         if (B <= 0 || T <= 0 || !pol || !x || !u || !th) return PDP_E_ARG;
-        if (pol->kind == PDP_POLICY_MLP) for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return PDP_E_SIZE;
+        bool wide = false;                       // a network beyond the lane-local arrays of cp_auxsys_kernel: its Jacobians come from the wave-per-(b, t) kernel
+        if (pol->kind == PDP_POLICY_MLP) { wide = pol->n_layers > 8; for (int k = 0; k < pol->n_layers && k < GEN_MAXL; ++k) wide = wide || pol->sizes[k] > MLP_MAX_WIDTH; }
         const int64_t n = (int64_t)B * (T + 1);
         PDP_CLEAR();
-        hipLaunchKernelGGL((cp_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, *pol, p, x, u, th, tb, F, G, Ux, Ue, cx, cu, hx);
+        hipLaunchKernelGGL((cp_auxsys_kernel<Mdl>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, S(st), B, T, *pol, p, x, u, th, tb, F, G, wide ? nullptr : Ux,
+                           wide ? nullptr : Ue, cx, cu, hx);
+        if (wide && Ux && Ue) {
+            if (!cp_policy_args_ok<Mdl>(pol, p)) return PDP_E_ARG;
+            int sum_in = Mdl::NX, maxw = Mdl::NX;
+            for (int k = 0; k < pol->n_layers; ++k) { if (k + 1 < pol->n_layers) sum_in += pol->sizes[k]; maxw = pol->sizes[k] > maxw ? pol->sizes[k] : maxw; }
+            const size_t lds = sizeof(double) * ((size_t)sum_in + 2 * (size_t)maxw + 8);
+            if (lds > 150 * 1024) return PDP_E_SIZE;           // (layer inputs of more than ~19 000 units in total)
+            (void)hipFuncSetAttribute((const void*)cp_policy_jac_generic_kernel<Mdl::NX, Mdl::NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cp_policy_jac_generic_kernel<Mdl::NX, Mdl::NU>), dim3((unsigned)((int64_t)B * T)), dim3(64), lds, S(st), B, T, *pol, p, x, th, tb, Ux, Ue,
+                               sum_in, maxw);
+        }
         return launched();
     } else { return PDP_E_MODE; }
 }
@@ -420,11 +436,50 @@ int cp_step2_launch(int B, int gy, int T, const pdp_policy* pol, int p, const do
 // MLP kernel variants (environment PDP_CP_MLP_VARIANT overrides): 2 = network in registers (pdp_cp_mlp_kernels.h), the default for networks of at
 // most 4 layers of width <= 16; 1 = the general adjoint kernel (any policy up to 8 layers x 32 units)
 inline int cp_mlp_variant() { static const int v = [] { const char* e = std::getenv("PDP_CP_MLP_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
+// ---- the size-generic route of ControlPlanning.step (csrc/pdp_cp_generic_kernels.h): whatever the tuned kernels below do not take
+template <class Mdl>
+bool cp_policy_args_ok(const pdp_policy* pol, int p) {        // the parameter vector has the length the policy implies
+    if (pol->kind == PDP_POLICY_POLY) return pol->n_pivots >= 1 && pol->n_pivots <= 16 && p == pol->n_pivots * Mdl::NU;
+    if (pol->kind == PDP_POLICY_TABLE) return pol->n_basis >= 1 && pol->table != nullptr && p == pol->n_basis * Mdl::NU;
+    if (pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > GEN_MAXL) return false;
+    int64_t cnt = 0;
+    int cols = Mdl::NX;
+    for (int k = 0; k < pol->n_layers; ++k) { if (pol->sizes[k] < 1) return false; cnt += (int64_t)pol->sizes[k] * cols + pol->sizes[k]; cols = pol->sizes[k]; }
+    return cnt == p && cols == Mdl::NU;
+}
+template <class Mdl>
+bool cp_needs_generic(const pdp_policy* pol, int p) {
+    if (Mdl::NX > 16 || Mdl::NU > 4) return true;                                  // beyond one tile per matrix
+    if (pol->kind == PDP_POLICY_TABLE) return true;
+    if (pol->kind == PDP_POLICY_MLP) {
+        if (p > 512 || pol->n_layers > 8) return true;
+        for (int k = 0; k < pol->n_layers; ++k) if (pol->sizes[k] > MLP_MAX_WIDTH) return true;
+    }
+    return false;
+}
+template <class Mdl>
+int cp_step_generic(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
+                    void* ws, int64_t wsb, void* st) {
+    if (!cp_policy_args_ok<Mdl>(pol, p)) return PDP_E_ARG;
+    const CpGenLayout L = cp_generic_layout<Mdl>(*pol, T, x != nullptr, u != nullptr);
+    if (L.rows < 1 || (size_t)L.lds_total * sizeof(double) > 160 * 1024) return PDP_E_SIZE;       // (a model whose single Jacobian row exceeds the LDS: not a policy size)
+    if (L.ws_per_traj > 0 && (!ws || wsb < (int64_t)B * L.ws_per_traj * (int64_t)sizeof(double))) return PDP_E_ARG;
+    const size_t lds = sizeof(double) * (size_t)L.lds_total;
+    (void)hipFuncSetAttribute((const void*)cp_step_generic_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    PDP_CLEAR();
+    hipLaunchKernelGGL((cp_step_generic_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, L);
+    return launched();
+}
 template <class Mdl>
 int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
+        if (pol && cp_needs_generic<Mdl>(pol, p)) {
+            if (!cp_policy_args_ok<Mdl>(pol, p)) return 0;
+            return (int64_t)B * cp_generic_layout<Mdl>(*pol, T, false, false).ws_per_traj * (int64_t)sizeof(double);
+        }
         if (pol && pol->kind == PDP_POLICY_POLY && p <= 64 && cp_prepass(B)) return cp_prepass_ws_bytes<Mdl>(B, T);
         if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;
+        if constexpr (Mdl::NX > 16 || Mdl::NU > 4) return 0; else {
         int64_t need = 0;
         if (cp_mlp16_ok<Mdl>(*pol)) need = (int64_t)B * T * 64 * (int64_t)sizeof(double);       // one double per lane and time step
         bool offload; int rows;
@@ -436,13 +491,18 @@ int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
             need = a > need ? a : need;
         }
         return need;
+        }
     } else { return 0; }
 }
 template <class Mdl>
 int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
             void* ws, int64_t wsb, void* st) {
-    if constexpr (Mdl::KIND == PDP_KIND_CP && Mdl::NX <= 16 && Mdl::NU <= 4) {
+    if constexpr (Mdl::KIND == PDP_KIND_CP && !(Mdl::NX <= 16 && Mdl::NU <= 4)) {
         if (B <= 0 || T <= 0 || !pol || !x0 || !th || !loss || !grad) return PDP_E_ARG;
+        return cp_step_generic<Mdl>(B, T, pol, p, x0, th, tb, loss, grad, x, u, ws, wsb, st);
+    } else if constexpr (Mdl::KIND == PDP_KIND_CP && Mdl::NX <= 16 && Mdl::NU <= 4) {
+        if (B <= 0 || T <= 0 || !pol || !x0 || !th || !loss || !grad) return PDP_E_ARG;
+        if (cp_needs_generic<Mdl>(pol, p)) return cp_step_generic<Mdl>(B, T, pol, p, x0, th, tb, loss, grad, x, u, ws, wsb, st);
         if (pol->kind == PDP_POLICY_MLP || p > 64) {          // adjoint (reverse-mode) kernel: MLP policy, or many Lagrange pivots
             if (p > 512) return PDP_E_SIZE;
             if (pol->kind == PDP_POLICY_MLP) {

@@ -82,7 +82,7 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     torch = runtime.torch_cuda()
     mdl = oc.model()
     big = mdl.n > 16 or mdl.m > 4                         # beyond the multiple-shooting kernel's tiles
-    generic = big and method != "single" and u_init is None and warm_start is None and mdl.n <= 32 and mdl.m <= 8
+    generic = big and method != "single" and u_init is None and warm_start is None
     if not generic and (method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start)):
         return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
                                            neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)

@@ -50,7 +50,8 @@ class PdpOcSensOut(C.Structure):
 
 
 class PdpPolicy(C.Structure):
-    _fields_ = [("kind", C.c_int), ("n_pivots", C.c_int), ("pivots", C.c_double * 16), ("n_layers", C.c_int), ("sizes", C.c_int * 8)]
+    _fields_ = [("kind", C.c_int), ("n_pivots", C.c_int), ("pivots", C.c_double * 16), ("n_layers", C.c_int), ("sizes", C.c_int * 16), ("n_basis", C.c_int),
+                ("table", C.c_void_p)]
 
 
 CORE_SYMBOLS = ["pdp_hip_version", "pdp_lqr_workspace_bytes", "pdp_lqr_solve_batched", "pdp_cp_aux_integrate_batched",
@@ -282,7 +283,10 @@ _MODEL_SIGS = {
 _models = {}
 
 
-def make_policy(kind, pivots=None, layers=None):
+def make_policy(kind, pivots=None, layers=None, table=None):
+    """pdp_policy (include/pdp_hip.h): "poly" (Lagrange pivots, PDP.py:699-725), "mlp" (layers = hidden + [m], PDP.py:727-759) or "table" (table [T, n_basis]: the basis
+    values of an open-loop policy at every step, u_t = sum_i table[t, i] theta_i - the warped / recovery-matrix variants, PDP.py:882-1141).  A table policy keeps its
+    device tensor alive through the returned struct (pol._table)."""
     pol = PdpPolicy()
     if kind == "poly":
         pol.kind = 0
@@ -290,10 +294,16 @@ def make_policy(kind, pivots=None, layers=None):
         assert pol.n_pivots <= 16, "at most 16 Lagrange pivots"
         for i, v in enumerate(pivots):
             pol.pivots[i] = float(v)
+    elif kind == "table":
+        pol.kind = 2
+        pol._table = dev(np.ascontiguousarray(np.asarray(table, dtype=float)))
+        assert pol._table.dim() == 2
+        pol.n_basis = int(pol._table.shape[1])
+        pol.table = pol._table.data_ptr()
     else:
         pol.kind = 1
         pol.n_layers = len(layers)
-        assert pol.n_layers <= 8, "at most 8 MLP layers"
+        assert pol.n_layers <= 16, "at most 16 weight layers"
         for i, v in enumerate(layers):
             pol.sizes[i] = int(v)
     return pol
@@ -535,9 +545,9 @@ class ModelLib:
         else:
             rc = self.lib.pdp_oc_pdp_grad_batched(B, T, flags, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss),
                                                   ptr(pk), ptr(dxdp), ptr(dudp), ptr(status), ptr(ws), nbytes, current_stream_ptr())
-        if rc == -2 and self.n <= 32 and self.m <= 8:
-            # m + p > 16 (beyond the fused kernel's single parameter tile), n > 16 / m > 4 (beyond one tile per matrix: the generic LQR
-            # kernel takes over), or a horizon whose staging exceeds the LDS: the reference's own route, kernel by kernel
+        if rc == -2:
+            # m + p > 16 (beyond the fused kernel's single parameter tile), n > 16 / m > 4 (beyond one tile per matrix: the size-generic LQR
+            # kernel takes over - any n, m), or a horizon whose staging exceeds the LDS: the reference's own route, kernel by kernel
             if not getattr(self, "_warned_materialised", False):
                 import warnings
                 warnings.warn("pdp_oc_pdp_grad_batched: problem outside the fused kernel's limits (n = %d, m = %d, p = %d, T = %d): taking the "
@@ -646,8 +656,11 @@ class ModelLib:
         x = torch.empty((B, T + 1, self.n), dtype=torch.float64, device="cuda")
         u = torch.empty((B, T, self.m), dtype=torch.float64, device="cuda")
         cost = torch.empty((B,), dtype=torch.float64, device="cuda")
-        check(self.lib.pdp_cp_integrate_batched(B, T, C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(cost), current_stream_ptr()),
-              "pdp_cp_integrate_batched")
+        rc = self.lib.pdp_cp_integrate_batched(B, T, C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(x), ptr(u), ptr(cost), current_stream_ptr())
+        if rc == -2:        # a network wider than the lane-per-trajectory integrator's local arrays: the size-generic step kernel rolls out as well (its gradient is dropped)
+            loss, _, x, u = self.cp_step(pol, p, x0, th, T, want_traj=True)
+            return x, u, loss
+        check(rc, "pdp_cp_integrate_batched")
         return x, u, cost
 
     def cp_integrate_T(self, pol, p, x0, theta, T):
@@ -670,9 +683,8 @@ class ModelLib:
         return out
 
     def cp_step(self, pol, p, x0, theta, T, want_traj=False):
-        """ControlPlanning.step (pdp_cp_step_batched): forward-sensitivity kernel for the Lagrange policy, adjoint kernel for the MLP
-        policy (its optional activation workspace is allocated here); policies outside the kernels' limits fall back to the
-        reference's materialised route (cp_step_materialised)."""
+        """ControlPlanning.step (pdp_cp_step_batched): forward-sensitivity kernels for the Lagrange policy, adjoint kernels for the MLP
+        policy, the size-generic adjoint kernel for everything beyond their limits and for table policies (the workspace any of them asks for is allocated here)."""
         torch = torch_cuda()
         x0 = dev(x0).reshape(-1, self.n)
         B = x0.shape[0]
@@ -685,9 +697,7 @@ class ModelLib:
         ws = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda") if nbytes > 0 else None
         rc = self.lib.pdp_cp_step_batched(B, int(T), C.byref(pol), p, ptr(x0), ptr(th), tb, ptr(loss), ptr(grad), ptr(x), ptr(u), ptr(ws), nbytes,
                                           current_stream_ptr())
-        if rc == -2 and pol.kind == 1:          # policy outside the fused kernel's limits: the reference's materialised route
-            return self.cp_step_materialised(pol, p, x0, th, T, want_traj)
-        check(rc, "pdp_cp_step_batched")
+        check(rc, "pdp_cp_step_batched")        # (no size is refused since round 5: what the tuned kernels do not take runs on the size-generic adjoint kernel)
         return (loss, grad, x, u) if want_traj else (loss, grad)
 
     def cp_step_materialised(self, pol, p, x0, theta, T, want_traj=False):

@@ -95,10 +95,11 @@ def test_irl_example_with_graph_option(tmp_path):
     assert r["parameter_trace"].shape == (30, 7)
 
 
-@pytest.mark.parametrize("B,p", [(1, 1), (5, 7), (1024, 9), (8192, 420), (300, 1023)])
+@pytest.mark.parametrize("B,p", [(1, 1), (5, 7), (1024, 9), (8192, 420), (300, 1023), (3, 1024), (70, 5316)])
 def test_one_launch_parameter_update(B, p):
     """pdp_gd_update_batched against numpy: batch means, theta <- theta - lr * mean gradient, traces at the device-side counter, health counters; strided gradient
-    rows (the packed [B, p + 1] output); rows beyond the trace length are dropped; p + 1 > 1024 is refused"""
+    rows (the packed [B, p + 1] output); rows beyond the trace length are dropped; parameter vectors beyond one workgroup's width (p + 1 > 1024: a [64, 64] policy has
+    5316 parameters) take the wide kernel"""
     import torch
     sys.path.insert(0, ROOT)
     from pdp_amd import runtime as rt
@@ -127,10 +128,6 @@ def test_one_launch_parameter_update(B, p):
     assert np.abs(ptr_.cpu().numpy()[1] - (th0 + 2 * want_d)).max() <= 1e-12 * max(1.0, np.abs(th0).max())
     rt.gd_update(loss, packed[:, :p], lr, theta, dth, cnt)          # everything optional left out
     assert int(cnt[0]) == 4
-    if p == 1023:
-        big = torch.zeros(4, 1025, dtype=torch.float64, device="cuda")
-        with pytest.raises(RuntimeError):
-            rt.gd_update(big[:, 0].contiguous(), big[:, :1024], lr, torch.zeros(1024, dtype=torch.float64, device="cuda"), torch.zeros(1024, dtype=torch.float64, device="cuda"), cnt)
 
 
 def test_device_resident_gd_loop_for_sysid():
@@ -164,3 +161,33 @@ def test_device_resident_gd_loop_for_sysid():
     assert np.allclose(g["loss_trace"][:n_it], [a for a, _ in trace], rtol=1e-11, atol=0)
     assert np.abs(g["parameter_trace"][:n_it] - np.array([b for _, b in trace])).max() <= 1e-12 * max(1.0, np.abs(theta0).max())
     assert g["loss_trace"][n_it - 1] < g["loss_trace"][0]
+
+
+def test_recmat_example_writes_the_reference_schema(tmp_path, golden_dir):
+    """examples/oc_recmat_pdp.py (Examples/OC/quadrotor/uav_PDP_Recmat.py, rocket_PDP_Recmat.py:40-90): the loop runs, the loss falls, the .mat carries the reference's
+    fields - and `true_solution`, OCSys.ocSolver from the driver's own initial state at its horizon, is the solution IPOPT stored for that problem
+    (tests/golden/oc_quadrotor.npz: true_solution of Examples/OC/quadrotor/data/PDP_OC_results_trial_0.mat, cost 3122.99940085)"""
+    import scipy.io as sio
+    g = np.load(os.path.join(golden_dir, "oc_quadrotor.npz"))
+    for extra in (["--graph"], []):
+        out = str(tmp_path / ("r%d.mat" % len(extra)))
+        txt = run("oc_recmat_pdp.py", "--system", "quadrotor", "--iters", "40", "--lr", "1e-4", "--sigma", "0.5", "--out", out, *extra)
+        r = sio.loadmat(out)["results"][0, 0]
+        assert set(["trail_no", "parameter_trace", "loss_trace", "learning_rate", "solved_solution", "true_solution", "time_passed", "dt", "horizon"]) <= set(r.dtype.names)
+        L = r["loss_trace"].flatten()
+        assert L.size == 40 and L[-1] < L[0], txt
+        assert np.asarray(r["parameter_trace"]).shape == (41, 140) and int(r["horizon"].squeeze()) == 35
+        ts, ss = r["true_solution"][0, 0], r["solved_solution"][0, 0]
+        assert abs(float(ts["cost"].squeeze()) - float(g["true_cost"])) <= 1e-9 * float(g["true_cost"])
+        assert np.abs(ts["state_traj_opt"] - g["true_state"]).max() <= 1e-6 and np.abs(ts["control_traj_opt"] - g["true_control"]).max() <= 1e-6
+        assert ss["state_traj"].shape == (36, 13) and ss["control_traj"].shape == (35, 4)
+
+
+def test_oc_example_stores_the_true_solution(tmp_path):
+    import scipy.io as sio
+    out = str(tmp_path / "oc.mat")
+    run("oc_pdp.py", "--system", "quadrotor", "--horizon", "20", "--iters", "5", "--batch", "4", "--out", out)
+    r = sio.loadmat(out)["results"][0, 0]
+    ts = r["true_solution"][0, 0]
+    assert ts["state_traj_opt"].shape == (21, 13) and ts["control_traj_opt"].shape == (20, 4) and ts["costate_traj_opt"].shape == (20, 13)
+    assert float(ts["cost"].squeeze()) <= float(r["solved_solution"][0, 0]["cost"].squeeze()) * (1 + 1e-9)      # the optimum bounds any policy's cost from below

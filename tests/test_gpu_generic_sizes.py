@@ -1,0 +1,224 @@
+"""GPU: no size is refused (round-4 verdict, item 7; reference: PDP/PDP.py:727-759 any list of hidden layers, 446-615 any n / m in lqrSolver, 1081-1114 one parameter
+per control and time step).  Whatever exceeds the tuned kernels' limits runs the same algorithms on size-generic kernels (csrc/pdp_cp_generic_kernels.h,
+lqr_solve_generic_kernel with its scratch in global memory) and is held to the oracle with the stated fp64 tolerances: loss 1e-11 relative, gradient / trajectories /
+sensitivities 1e-10 of their largest entry."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def quad_cp_oracle():
+    from oracle import models, pdp_oracle as po
+    return po.make_cp(models.quadrotor(Jx=1, Jy=1, Jz=1, mass=1, l=0.4, c=0.01, wr=1, wv=1, wq=5, ww=1, wthrust=0.1), 0.1)
+
+
+@pytest.mark.parametrize("hidden", [[64, 64], [40], [8] * 9, [13] * 5, [100, 3, 70]])
+def test_neural_policies_of_any_shape_against_the_oracle(margins, hidden):
+    """ControlPlanning.step through the class surface with tanh-MLP policies beyond the register kernel (4 layers x 16) and beyond the LDS kernel (8 x 32, p <= 512):
+    [64, 64] (p = 5316, the verdict's example), one wide layer, ten narrow layers, and - inside the LDS kernel's range, as a control - five layers of 13"""
+    from pdp_amd import PDP, zoo
+    env, dt = zoo.make_env("quadrotor", "oc")
+    cp = PDP.ControlPlanning("quadrotor generic mlp")
+    cp.setStateVariable(env.X)
+    cp.setControlVariable(env.U)
+    cp.setDyn(env.X + dt * env.f)
+    cp.setPathCost(env.path_cost)
+    cp.setFinalCost(env.final_cost)
+    cp.init_step_neural_policy(hidden)
+    orc = quad_cp_oracle()
+    orc.init_step_neural_policy(hidden)
+    assert orc.n_auxvar == cp.n_auxvar
+    rng = np.random.default_rng(len(hidden) + hidden[0])
+    B, T, p = 3, 12, cp.n_auxvar
+    theta = rng.standard_normal(p) * (0.3 / np.sqrt(max(hidden)))
+    x0 = np.zeros((B, 13))
+    x0[:, :3] = rng.uniform(-2, 2, (B, 3))
+    x0[:, 6] = 1.0
+    loss, grad = cp.step_batch(x0, T, theta)
+    L, G = npy(loss), npy(grad)
+    x, u, cost = cp.integrateSys_batch(x0, T, theta)
+    tag = "generic MLP %s p=%d" % (hidden, p)
+    for i in range(B):
+        l, g = orc.step(x0[i], T, theta)
+        sol = orc.integrateSys(x0[i], T, theta)
+        margins.check("%s sample %d vs oracle: loss (relative)" % (tag, i), abs(L[i] - l) / abs(l), 1e-11)
+        margins.check("%s sample %d vs oracle: gradient (relative to its largest entry)" % (tag, i), np.abs(G[i] - g).max() / np.abs(g).max(), 1e-10)
+        margins.check("%s sample %d vs oracle: state trajectory" % (tag, i), rel(npy(x)[i], sol["state_traj"]), 1e-10)
+        margins.check("%s sample %d vs oracle: control trajectory" % (tag, i), rel(npy(u)[i], sol["control_traj"]), 1e-10)
+        assert abs(float(cost[i]) - sol["cost"]) <= 1e-11 * abs(sol["cost"])
+    # the reference's single-trajectory signature on top of it
+    l1, g1 = cp.step(x0[0], T, theta)
+    assert l1 == L[0] and np.array_equal(g1, G[0])
+
+
+def test_table_policy_equals_the_lagrange_policy():
+    """PDP_POLICY_TABLE with the Lagrange basis values of the pivots at every step IS the polynomial policy: the size-generic adjoint kernel against the tile kernels
+    (forward sensitivities, the reference's formulation) - loss, gradient and trajectories to 1e-12"""
+    from pdp_amd import runtime as rt, zoo
+    mdl = zoo.get("quadrotor", "oc")
+    rng = np.random.default_rng(4)
+    B, T = 7, 50
+    piv = np.linspace(0, T, 6)
+    basis = np.ones((T, 6))
+    for i in range(6):
+        for j in range(6):
+            if j != i:
+                basis[:, i] = basis[:, i] * (np.arange(T) - piv[j]) / (piv[i] - piv[j])
+    theta = rng.standard_normal(24)
+    x0 = np.zeros((B, 13))
+    x0[:, :3] = rng.uniform(-5, 5, (B, 3))
+    x0[:, 6] = 1.0
+    a = mdl.cp_step(rt.make_policy("poly", pivots=piv), 24, x0, theta, T, want_traj=True)
+    b = mdl.cp_step(rt.make_policy("table", table=basis), 24, x0, theta, T, want_traj=True)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert rel(npy(v), npy(u)) <= 1e-12, k
+    # per-sample parameters and no trajectory outputs (the workspace then holds the trajectory)
+    th_b = rng.standard_normal((B, 24))
+    a2 = mdl.cp_step(rt.make_policy("poly", pivots=piv), 24, x0, th_b, T)
+    b2 = mdl.cp_step(rt.make_policy("table", table=basis), 24, x0, th_b, T)
+    assert rel(npy(b2[0]), npy(a2[0])) <= 1e-12 and rel(npy(b2[1]), npy(a2[1])) <= 1e-12
+
+
+def test_recovery_matrix_step_is_one_launch_and_long_horizons_work(golden_dir):
+    """recmat_step at a horizon whose parameter count (T m = 800) exceeds every tuned kernel: against central finite differences of recmat_unwarp's cost, and the
+    device-resident loop (GDLoop around warped_step_fn) against the host-driven loop of the reference's driver (rocket_PDP_Recmat.py:56-64)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "examples"))
+    import oc_recmat_pdp as ex
+    from pdp_amd.irl import GDLoop
+    cp, _, dt = ex.build("quadrotor")
+    T = 200
+    x0 = np.array(ex.SETUP["quadrotor"]["x0"])
+    cp.recmat_init_step(T, -1)
+    assert cp.n_auxvar == 800
+    rng = np.random.default_rng(0)
+    theta = 2.5 + 0.1 * rng.standard_normal(800)
+    loss, g = cp.recmat_step(x0, T, theta)
+    assert abs(loss - float(cp.recmat_unwarp(x0, T, theta)["cost"][0])) <= 1e-12 * abs(loss)
+    for j in (0, 399, 799):
+        e = np.zeros(800); e[j] = 1e-5
+        fd = (float(cp.recmat_unwarp(x0, T, theta + e)["cost"][0]) - float(cp.recmat_unwarp(x0, T, theta - e)["cost"][0])) / 2e-5
+        assert abs(g[j] - fd) <= 1e-6 * max(1.0, abs(fd)), (j, g[j], fd)
+    lr, n_it = 1e-6, 12
+    th, losses = theta.copy(), []
+    for _ in range(n_it):
+        l, dp = cp.recmat_step(x0, T, th)
+        th = th - lr * dp
+        losses.append(l)
+    for graphed in (False, True):
+        loop = GDLoop(cp.warped_step_fn(x0), theta, lr, max_steps=n_it)
+        loop.run(n_it, graphed=graphed)
+        r = loop.results()
+        assert np.allclose(r["loss_trace"], losses, rtol=1e-13, atol=0) and np.abs(r["parameter_trace"][-1] - th).max() <= 1e-13 * np.abs(th).max()
+    assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("n,m,p,T,B", [(40, 10, 3, 9, 3), (20, 5, 40, 6, 2), (90, 3, 4, 5, 2)])
+def test_lqr_solver_of_any_size_against_the_oracle(margins, n, m, p, T, B):
+    """LQR.lqrSolver (PDP.py:446-615) beyond n = 32 / m = 8 through the class surface: a 40-state, 10-control problem (working set in LDS), p beyond one launch's
+    column block, and n = 90 (working set in the workspace: the GLOBAL instantiation of the size-generic kernel) - X, U, Lambda against oracle.lqr_solver, the
+    line-for-line restatement of the reference"""
+    from oracle import pdp_oracle as po
+    from pdp_amd import PDP
+    rng = np.random.default_rng(n + m)
+    for b in range(B):
+        F = [np.eye(n) + 0.3 / np.sqrt(n) * rng.standard_normal((n, n)) for _ in range(T)]
+        G = [rng.standard_normal((n, m)) / np.sqrt(n) for _ in range(T)]
+        E = [0.1 * rng.standard_normal((n, p)) for _ in range(T)]
+
+        def spd(k):
+            a = rng.standard_normal((k, k))
+            return a @ a.T / k + np.eye(k)
+        Hxx, Huu = [spd(n) for _ in range(T)], [spd(m) for _ in range(T)]
+        Hxu = [0.1 * rng.standard_normal((n, m)) for _ in range(T)]
+        Hxe = [0.1 * rng.standard_normal((n, p)) for _ in range(T)]
+        Hue = [0.1 * rng.standard_normal((m, p)) for _ in range(T)]
+        hxx, hxe = spd(n), 0.1 * rng.standard_normal((n, p))
+        X0 = rng.standard_normal((n, p))
+        lqr = PDP.LQR()
+        lqr.setDyn(dynF=F, dynG=G, dynE=E)
+        lqr.setPathCost(Hxx=Hxx, Huu=Huu, Hxu=Hxu, Hux=[h.T for h in Hxu], Hxe=Hxe, Hue=Hue)
+        lqr.setFinalCost(hxx=[hxx], hxe=[hxe])
+        sol = lqr.lqrSolver(X0, T)
+        ref = po.lqr_solver(F, G, E, Hxx, Huu, Hxu, Hxe, Hue, hxx, hxe, X0, T)
+        tag = "size-generic lqrSolver n=%d m=%d p=%d sample %d" % (n, m, p, b)
+        margins.check(tag + ": state_traj_opt", rel(np.stack(sol["state_traj_opt"]), np.stack(ref["state_traj_opt"])), 1e-10)
+        margins.check(tag + ": control_traj_opt", rel(np.stack(sol["control_traj_opt"]), np.stack(ref["control_traj_opt"])), 1e-10)
+        margins.check(tag + ": costate_traj_opt", rel(np.stack(sol["costate_traj_opt"]), np.stack(ref["costate_traj_opt"])), 1e-10)
+
+
+def _chain(nm, m, dt, lib, w):
+    """a chain of nm masses with m actuators (cubic springs), numeric weights w[0..5]: (states, controls, discrete dynamics, path cost, final cost) in pdp_amd.sx or sympy"""
+    if lib == "sx":
+        from pdp_amd.sx import SX
+        q, v, U = SX.sym("q", nm), SX.sym("v", nm), SX.sym("u", m)
+        qs, vs, us = [q[i] for i in range(nm)], [v[i] for i in range(nm)], [U[i] for i in range(m)]
+    else:
+        import sympy as sp
+        qs, vs, us = (list(sp.symbols("%s0:%d" % (nme, k), real=True)) for nme, k in (("q", nm), ("v", nm), ("u", m)))
+    acc = []
+    for i in range(nm):
+        left = qs[i - 1] if i > 0 else 0.0
+        right = qs[i + 1] if i + 1 < nm else 0.0
+        a = float(w[0]) * (left - 2 * qs[i] + right) - float(w[1]) * vs[i] - 0.3 * qs[i] * qs[i] * qs[i]
+        if i % 2 == 0 and i // 2 < m:
+            a = a + us[i // 2]
+        acc.append(a)
+    sq = lambda xs: sum((z * z for z in xs[1:]), xs[0] * xs[0])
+    path, final = float(w[2]) * sq(qs) + float(w[3]) * sq(vs) + float(w[4]) * sq(us), float(w[5]) * sq(qs)
+    f = [qs[i] + dt * vs[i] for i in range(nm)] + [vs[i] + dt * acc[i] for i in range(nm)]
+    return qs + vs, us, f, path, final
+
+
+def test_control_planning_with_forty_states_runs_the_whole_class_surface(margins):
+    """a 40-state, 10-control mass chain (beyond every tile kernel) through ControlPlanning: integrateSys, getAuxSys, integrateAuxSys, step - Lagrange and tanh-MLP policy -
+    against the oracle built from the same equations in sympy"""
+    from oracle import pdp_oracle as po
+    from pdp_amd import PDP
+    from pdp_amd.sx import vertcat
+    nm, m, dt, T = 20, 10, 0.05, 8
+    rng = np.random.default_rng(9)
+    wv = np.abs(rng.standard_normal(6)) + 0.5
+    X, U, f, path, final = _chain(nm, m, dt, "sx", wv)
+    Xs, Us, fs, paths, finals = _chain(nm, m, dt, "sympy", wv)
+    orc = po.ControlPlanningOracle(Xs, Us, fs, paths, finals)
+    x0 = 0.3 * rng.standard_normal(2 * nm)
+    for kind in ("poly", "mlp"):
+        cp = PDP.ControlPlanning("mass chain cp 40")
+        cp.setStateVariable(vertcat(*X))
+        cp.setControlVariable(vertcat(*U))
+        cp.setDyn(vertcat(*f))
+        cp.setPathCost(path)
+        cp.setFinalCost(final)
+        if kind == "poly":
+            cp.init_step(T, n_poly=3)
+            orc.init_step(T, n_poly=3)
+        else:
+            cp.init_step_neural_policy([12])
+            orc.init_step_neural_policy([12])
+        theta = 0.1 * rng.standard_normal(cp.n_auxvar)
+        assert cp.n_auxvar == orc.n_auxvar
+        loss, grad = cp.step(x0, T, theta)
+        l, g = orc.step(x0, T, theta)
+        sol, ref = cp.integrateSys(x0, T, theta), orc.integrateSys(x0, T, theta)
+        tag = "40-state mass chain ControlPlanning (%s policy, p = %d)" % (kind, cp.n_auxvar)
+        margins.check(tag + ": loss (relative)", abs(loss - l) / abs(l), 1e-11)
+        margins.check(tag + ": gradient", np.abs(grad - g).max() / np.abs(g).max(), 1e-10)
+        margins.check(tag + ": state trajectory", rel(sol["state_traj"], ref["state_traj"]), 1e-10)
+        aux = cp.getAuxSys(sol["state_traj"], sol["control_traj"], theta)
+        raux = orc.getAuxSys(ref["state_traj"], ref["control_traj"], theta)
+        for k in ("dynF", "dynG", "dUx", "dUe"):
+            margins.check(tag + ": getAuxSys " + k, rel(np.stack(aux[k]), np.stack(raux[k])), 1e-10)
+        s = cp.integrateAuxSys(aux["dynF"], aux["dynG"], aux["dUx"], aux["dUe"], np.zeros((2 * nm, cp.n_auxvar)))
+        rs = orc.integrateAuxSys(raux["dynF"], raux["dynG"], raux["dUx"], raux["dUe"], np.zeros((2 * nm, cp.n_auxvar)))
+        margins.check(tag + ": integrateAuxSys state", rel(np.stack(s["state_traj"]), np.stack(rs["state_traj"])), 1e-10)
