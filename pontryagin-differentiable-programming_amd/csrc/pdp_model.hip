@@ -481,7 +481,11 @@ int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
         if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;
         if constexpr (Mdl::NX > 16 || Mdl::NU > 4) return 0; else {
         int64_t need = 0;
-        if (cp_mlp16_ok<Mdl>(*pol)) need = (int64_t)B * T * 64 * (int64_t)sizeof(double);       // one double per lane and time step
+        if (cp_mlp16_ok<Mdl>(*pol)) {
+            need = (int64_t)B * T * 64 * (int64_t)sizeof(double);                                // register kernel: one double per lane and time step
+            const int64_t n4 = cp_mlp4t_ws_doubles<Mdl>(B, T) * (int64_t)sizeof(double);          // four-trajectory kernel: activations in D layout + the trajectories
+            need = n4 > need ? n4 : need;
+        }
         bool offload; int rows;
         cp_adjoint_plan<Mdl>(*pol, p, T, B, device_cu_count(), true, offload, rows);
         if (offload) {
@@ -511,7 +515,25 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 for (int k = 0; k < pol->n_layers; ++k) { if (pol->sizes[k] > MLP_MAX_WIDTH || pol->sizes[k] < 1) return PDP_E_SIZE; cnt += pol->sizes[k] * cols + pol->sizes[k]; cols = pol->sizes[k]; }
                 if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
             } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
-            if (pol->kind == PDP_POLICY_MLP && cp_mlp_variant() == 2 && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
+            // shared parameters (the reference's case: one policy for every initial state): four trajectories per wavefront on the 4-block MFMA (cp_step_mlp4t_kernel)
+            if (pol->kind == PDP_POLICY_MLP && cp_mlp_variant() == 2 && tb == 0 && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr &&
+                wsb >= cp_mlp4t_ws_doubles<Mdl>(B, T) * (int64_t)sizeof(double)) {
+                const size_t lds4 = sizeof(double) * (size_t)cp_mlp4t_layout<Mdl>().total;
+                PDP_CLEAR();
+                auto go4 = [&](auto kern) {
+                    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                    hipLaunchKernelGGL(kern, dim3((B + 3) / 4), dim3(64), lds4, S(st), B, T, *pol, p, x0, th, loss, grad, x, u, (double*)ws);
+                };
+                switch (pol->n_layers) {
+                    case 1: go4(cp_step_mlp4t_kernel<Mdl, 1>); break;
+                    case 2: go4(cp_step_mlp4t_kernel<Mdl, 2>); break;
+                    case 3: go4(cp_step_mlp4t_kernel<Mdl, 3>); break;
+                    default: go4(cp_step_mlp4t_kernel<Mdl, 4>); break;
+                }
+                return launched();
+            }
+            // PDP_CP_MLP_VARIANT=3: the one-trajectory register kernel for shared parameters as well (what round 4 ran; per-sample parameters always take it)
+            if (pol->kind == PDP_POLICY_MLP && (cp_mlp_variant() == 2 || cp_mlp_variant() == 3) && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
                 // batches beyond one trajectory per SIMD: rows sized for eight workgroups per CU, i.e. two wavefronts per SIMD that fill each other's gaps (PDP_CP_MLP_LDS_KB overrides)
                 static const int kb_env = [] { const char* e = std::getenv("PDP_CP_MLP_LDS_KB"); return e ? std::atoi(e) : 0; }();
                 const int rows16 = cp_mlp16_rows<Mdl>(T, kb_env > 0 ? kb_env : (B > 4 * device_cu_count() ? 20 : 40));

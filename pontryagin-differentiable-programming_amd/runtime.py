@@ -739,6 +739,8 @@ class ModelLib:
         return F, E
 
     def sysid_step(self, u, xobs, theta):
+        """SysID.step per trajectory (pdp_sysid_step_ws_batched).  Models beyond the fused kernels' tiles (n > 16 or p > 64) take the reference's own route kernel by kernel -
+        integrateDyn -> getAuxSys -> integrateAuxSys (size-generic kernels) -> the chain rule of PDP.py:1285-1291 as two tensor contractions: no size is refused."""
         torch = torch_cuda()
         u, xobs = dev(u), dev(xobs)
         B, T = u.shape[0], u.shape[1]
@@ -746,10 +748,22 @@ class ModelLib:
         loss = torch.empty((B,), dtype=torch.float64, device="cuda")
         grad = torch.empty((B, self.p), dtype=torch.float64, device="cuda")
         nbytes = int(self.lib.pdp_sysid_step_workspace_bytes(B, T))              # > 0: large batch, the trajectories are rolled out beforehand, one lane each
-        ws = getattr(self, "_sysid_ws", None) if nbytes > 0 else None
-        if nbytes > 0 and (ws is None or ws.numel() * 8 < nbytes):
-            ws = self._sysid_ws = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda")      # kept: an SGD loop calls this every step
-        check(self.lib.pdp_sysid_step_ws_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), ptr(ws), nbytes, current_stream_ptr()), "pdp_sysid_step_ws_batched")
+        ws = None
+        if nbytes > 0:
+            # kept per (B, T) and never replaced: an SGD loop calls this every step, and a captured hipGraph (irl.GDLoop) holds the raw pointer - a buffer that a later,
+            # larger call freed would leave the graph writing through a dangling pointer (round-4 advice)
+            cache = self.__dict__.setdefault("_sysid_ws", {})
+            ws = cache.get((B, T))
+            if ws is None:
+                ws = cache[(B, T)] = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda")
+        rc = self.lib.pdp_sysid_step_ws_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), ptr(ws), nbytes, current_stream_ptr())
+        if rc == -2:
+            x = self.sysid_integrate(xobs[:, 0].contiguous(), u, th)
+            F, E = self.sysid_auxsys(x, u, th)
+            X = sysid_aux_integrate(F, E)                                           # [B, T+1, n, p]
+            d = x - xobs
+            return (d * d).sum(dim=(1, 2)), torch.einsum("bti,btip->bp", d, X)
+        check(rc, "pdp_sysid_step_ws_batched")
         return loss, grad
 
 
