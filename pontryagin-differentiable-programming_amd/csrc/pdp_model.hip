@@ -434,7 +434,9 @@ int cp_step2_launch(int B, int gy, int T, const pdp_policy* pol, int p, const do
     return launched();
 }
 // MLP kernel variants (environment PDP_CP_MLP_VARIANT overrides): 2 = network in registers (pdp_cp_mlp_kernels.h), the default for networks of at
-// most 4 layers of width <= 16; 1 = the general adjoint kernel (any policy up to 8 layers x 32 units)
+// most 4 layers of width <= 16 - four trajectories per wavefront on the 4-block MFMA for shared parameters from two trajectories per CU on, one trajectory per
+// wavefront otherwise; 3 = one trajectory per wavefront for every batch (round 4's route); 4 = four per wavefront for every batch; 1 = the general adjoint kernel
+// (any policy up to 8 layers x 32 units)
 inline int cp_mlp_variant() { static const int v = [] { const char* e = std::getenv("PDP_CP_MLP_VARIANT"); return e ? std::atoi(e) : 2; }(); return v; }
 // ---- the size-generic route of ControlPlanning.step (csrc/pdp_cp_generic_kernels.h): whatever the tuned kernels below do not take
 template <class Mdl>
@@ -516,8 +518,10 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 if (cnt != p || cols != Mdl::NU) return PDP_E_ARG;
             } else if (p != pol->n_pivots * Mdl::NU || pol->n_pivots > 16) return PDP_E_ARG;
             // shared parameters (the reference's case: one policy for every initial state): four trajectories per wavefront on the 4-block MFMA (cp_step_mlp4t_kernel)
-            if (pol->kind == PDP_POLICY_MLP && cp_mlp_variant() == 2 && tb == 0 && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr &&
-                wsb >= cp_mlp4t_ws_doubles<Mdl>(B, T) * (int64_t)sizeof(double)) {
+            // - from two trajectories per CU on (below that a wavefront per trajectory has a SIMD to itself and the same latency per step: measured 0.252 / 0.257 / 0.267 ms
+            // against 0.272 for B = 64 / 256 / 512, probes/mlp4t_timing.py); PDP_CP_MLP_VARIANT=4 takes it for every batch (tests)
+            if (pol->kind == PDP_POLICY_MLP && ((cp_mlp_variant() == 2 && B > 2 * device_cu_count()) || cp_mlp_variant() == 4) && tb == 0 && cp_mlp16_ok<Mdl>(*pol) &&
+                ws != nullptr && wsb >= cp_mlp4t_ws_doubles<Mdl>(B, T) * (int64_t)sizeof(double)) {
                 const size_t lds4 = sizeof(double) * (size_t)cp_mlp4t_layout<Mdl>().total;
                 PDP_CLEAR();
                 auto go4 = [&](auto kern) {
@@ -533,7 +537,7 @@ int cp_step(int B, int T, const pdp_policy* pol, int p, const double* x0, const 
                 return launched();
             }
             // PDP_CP_MLP_VARIANT=3: the one-trajectory register kernel for shared parameters as well (what round 4 ran; per-sample parameters always take it)
-            if (pol->kind == PDP_POLICY_MLP && (cp_mlp_variant() == 2 || cp_mlp_variant() == 3) && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
+            if (pol->kind == PDP_POLICY_MLP && (cp_mlp_variant() >= 2) && cp_mlp16_ok<Mdl>(*pol) && ws != nullptr && wsb >= (int64_t)B * T * 64 * (int64_t)sizeof(double)) {
                 // batches beyond one trajectory per SIMD: rows sized for eight workgroups per CU, i.e. two wavefronts per SIMD that fill each other's gaps (PDP_CP_MLP_LDS_KB overrides)
                 static const int kb_env = [] { const char* e = std::getenv("PDP_CP_MLP_LDS_KB"); return e ? std::atoi(e) : 0; }();
                 const int rows16 = cp_mlp16_rows<Mdl>(T, kb_env > 0 ? kb_env : (B > 4 * device_cu_count() ? 20 : 40));

@@ -66,17 +66,18 @@ def test_register_kernels_equal_the_general_kernel(tmp_path):
     """default route (round 5: shared parameters -> cp_step_mlp4t_kernel, four trajectories per wavefront on the 4-block MFMA; per-sample parameters -> the one-trajectory
     register kernel) == PDP_CP_MLP_VARIANT=3 (the one-trajectory register kernel for everything: round 4's route) == PDP_CP_MLP_VARIANT=1 (the general kernel):
     loss, states and controls bit for bit, gradient to 1e-15 of its largest entry"""
-    new = _run_all()
+    new = _variant(tmp_path, 4)            # (four per wavefront for every batch size: the default takes it from two trajectories per CU on)
     one = _variant(tmp_path, 3)
     gen = _variant(tmp_path, 1)
     _compare(one, gen, "register kernel (one trajectory per wavefront) differs from the general kernel")
     _compare(new, one, "four-trajectory MFMA kernel differs from the one-trajectory register kernel")
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 5, 1024, 1027])
+@pytest.mark.parametrize("B", [513, 514, 515, 517, 1024, 1027])
 def test_four_trajectory_kernel_on_batches_that_do_not_fill_its_wavefronts(B):
     """cp_step_mlp4t_kernel packs trajectories 4 w .. 4 w + 3 into wavefront w: a batch that is no multiple of four (padding lanes repeat the last trajectory, their
-    stores are dropped), with and without the trajectory outputs - every trajectory equals the same trajectory run in a batch of one"""
+    stores are dropped), with and without the trajectory outputs - every trajectory equals the same trajectory run in a batch of one (which takes the one-trajectory
+    register kernel: the two kernels agree bit for bit in loss and trajectories, to the last bits in the gradient)"""
     sys.path.insert(0, ROOT)
     from pdp_amd import runtime as rt, zoo
     mdl = zoo.get("quadrotor", "oc")
@@ -92,4 +93,5 @@ def test_four_trajectory_kernel_on_batches_that_do_not_fill_its_wavefronts(B):
     assert np.array_equal(l2, loss) and np.array_equal(g2, grad)
     for i in sorted(set([0, B // 2, B - 1])):
         l1, g1, x1, u1 = (a.cpu().numpy() for a in mdl.cp_step(pol, p, x0[i:i + 1], th, T, want_traj=True))
-        assert np.array_equal(l1[0], loss[i]) and np.array_equal(g1[0], grad[i]) and np.array_equal(x1[0], x[i]) and np.array_equal(u1[0], u[i]), i
+        assert np.array_equal(l1[0], loss[i]) and np.array_equal(x1[0], x[i]) and np.array_equal(u1[0], u[i]), i
+        assert np.abs(g1[0] - grad[i]).max() <= 1e-15 * np.abs(grad[i]).max(), i
