@@ -231,8 +231,8 @@ def test_C5_quadrotor_neural_policy_T100_p420():
 
 
 def test_C5_neural_policy_full_shard_equals_small_batch():
-    """C5b at one GPU's shard (B = 1024) through the register-resident MLP kernel (cp_step_mlp16_kernel: every lane keeps its hidden
-    activation of every time step in the HBM workspace, 64 doubles per step): the arithmetic per trajectory does not depend on the batch -
+    """C5b at one GPU's shard (B = 1024: four trajectories per wavefront, cp_step_mlp4t_kernel) against a batch of 16 (one per wavefront, cp_step_mlp16_kernel;
+    hidden activations of every time step in the HBM workspace): the arithmetic per trajectory does not depend on the batch or the kernel -
     loss and gradient of the first 16 trajectories agree to rounding with the 16-trajectory run."""
     from pdp_amd import runtime as rt, zoo
     mdl = zoo.get("quadrotor", "oc")
@@ -243,8 +243,10 @@ def test_C5_neural_policy_full_shard_equals_small_batch():
     x0[:, :3] = rng.uniform(-2, 2, (B, 3))
     x0[:, 6] = 1.0
     pol = rt.make_policy("mlp", layers=[13, 13, 4])
-    assert mdl.lib.pdp_cp_step_workspace_bytes(B, T, rt.C.byref(pol), p) == B * T * 64 * 8          # one double per lane and time step
-    assert mdl.lib.pdp_cp_step_workspace_bytes(16, T, rt.C.byref(pol), p) == 16 * T * 64 * 8
+    # the larger of: one double per lane and time step (one trajectory per wavefront) | activations of four trajectories per wavefront in D layout + the trajectories
+    wsb = lambda b: 8 * max(b * T * 64, ((b + 3) // 4) * T * 3 * 64 + b * ((T + 1) * 13 + T * 4))
+    assert mdl.lib.pdp_cp_step_workspace_bytes(B, T, rt.C.byref(pol), p) == wsb(B)
+    assert mdl.lib.pdp_cp_step_workspace_bytes(16, T, rt.C.byref(pol), p) == wsb(16)
     L, G = mdl.cp_step(pol, p, x0, theta, T)
     l, g = mdl.cp_step(pol, p, x0[:16], theta, T)
     L, G, l, g = npy(L), npy(G), npy(l), npy(g)

@@ -87,7 +87,7 @@ def test_nonfinite_input_raises_status_flag_only_for_that_sample():
 
 def test_lqr_maximum_sizes_and_limits():
     """n = 16, m = 4, p = 60 (= 64 - m) is the largest problem of ONE launch of pdp_lqr_solve_batched; more parameter columns are solved in
-    column blocks by the class surface; 16 < n <= 32 / 4 < m <= 8 take the generic kernel (test below), beyond that PDP_E_SIZE"""
+    column blocks by the class surface; n > 16 or m > 4 take the size-generic kernel (test below and tests/test_gpu_generic_sizes.py): no size is refused"""
     from oracle import pdp_oracle as po
     from pdp_amd import runtime as rt
     rng = np.random.default_rng(2)
@@ -119,10 +119,11 @@ def test_lqr_maximum_sizes_and_limits():
     pr = rt.PdpLqrProblem()
     pr.B, pr.T, pr.n, pr.m, pr.p = 1, 2, 4, 1, 64
     assert core.pdp_lqr_solve_batched(__import__("ctypes").byref(pr), None, None, None, None, None, 0, None) in (-1, -2)
-    with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
-        rt.lqr_solve(np.zeros((1, 2, 33, 33)), np.zeros((1, 2, 33, 1)), np.zeros((1, 2, 33, 33)), np.ones((1, 2, 1, 1)), np.zeros((1, 33, 33)), np.zeros((1, 33, 1)))
-    with pytest.raises(RuntimeError, match="PDP_E_SIZE"):
-        rt.lqr_solve(np.zeros((1, 2, 12, 12)), np.zeros((1, 2, 12, 9)), np.zeros((1, 2, 12, 12)), np.ones((1, 2, 9, 9)), np.zeros((1, 12, 12)), np.zeros((1, 12, 1)))
+    # since round 5 no state or control dimension is refused (n = 33, m = 9 used to be PDP_E_SIZE; parity at such sizes: tests/test_gpu_generic_sizes.py)
+    X3, U3, _, st3 = rt.lqr_solve(np.tile(np.eye(33), (1, 2, 1, 1)), np.zeros((1, 2, 33, 1)), np.tile(np.eye(33), (1, 2, 1, 1)), np.ones((1, 2, 1, 1)), np.eye(33)[None], np.zeros((1, 33, 1)))
+    assert int(st3.sum()) == 0 and X3.shape == (1, 3, 33, 1) and float(X3.abs().max()) == 0.0
+    X4, U4, _, st4 = rt.lqr_solve(np.tile(np.eye(12), (1, 2, 1, 1)), np.zeros((1, 2, 12, 9)), np.tile(np.eye(12), (1, 2, 1, 1)), np.tile(np.eye(9), (1, 2, 1, 1)), np.eye(12)[None], np.zeros((1, 12, 1)))
+    assert int(st4.sum()) == 0 and U4.shape == (1, 2, 9, 1)
 
 
 @pytest.mark.parametrize("n,m,p", [(20, 3, 11), (17, 1, 5), (12, 6, 45), (32, 8, 32), (9, 5, 70)])
