@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
                 double a = 0.0;
                 for (int c = 0; c < cols; ++c) a += thb[loff[k] + r + c * rows] * zk[c];        // column-major A_k (PDP.py:739), c ascending as policy_eval
                 a += thb[loff[k] + rows * cols + r];
-                if (k + 1 < nl) { const double z = tanh(a); zs[zoff[k + 1] + r] = z; acts[(int64_t)t * L.actw + aoff[k] + r] = z; }
+                if (k + 1 < nl) { const double z = pdp_tanh(a); zs[zoff[k + 1] + r] = z; acts[(int64_t)t * L.actw + aoff[k] + r] = z; }
                 else vv[r] = a;
             }
             sync();
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(64) cp_policy_jac_generic_kernel(int B, int T,
         for (int r = lane; r < rows; r += 64) {
             double a = 0.0;
             for (int c = 0; c < cols; ++c) a += thb[loff[k] + r + c * rows] * zs[zoff[k] + c];
-            zs[zoff[k + 1] + r] = tanh(a + thb[loff[k] + rows * cols + r]);
+            zs[zoff[k + 1] + r] = pdp_tanh(a + thb[loff[k] + rows * cols + r]);
         }
         wave_lds_sync();
     }

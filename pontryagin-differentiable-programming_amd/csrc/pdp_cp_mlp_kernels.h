@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
                         a = fma(Wrow[c], zc, a);               // a += A[r][c] z[c], c ascending (as policy_eval)
                     }
                     if (k + 1 < nl) {
-                        const double zk = tanh(a);
+                        const double zk = pdp_tanh(a);
                         zprev = zk;
                         zkeep = grp == k ? zk : zkeep;
                     } else {
@@ -281,22 +281,23 @@ __global__ void __launch_bounds__(64) cp_step_mlp16_kernel(int B, int T, pdp_pol
 //     give the whole 16-wide layer for four trajectories: A_q[lane] = W[4 b + i][4 q + k], B_q[lane] = z[4 q + k][trajectory j] (the same for every b),
 //     D[lane (j, b, i)] = a[4 b + i][trajectory j].  The accumulator starts at the bias and the inner index ascends: the same fma chain as the register kernel, bit for bit;
 //   * a layer's output - one double per lane: row 4 b + i of trajectory j - goes through ONE tanh for all four trajectories and becomes the next layer's B operands by a
-//     broadcast of quad q inside each row of 16 lanes (B_q[lane] = D[(lane & 0x33) | 4 q]: ds_bpermute);
+//     broadcast of quad q inside each row of 16 lanes (B_q[lane] = D[(lane & 0x33) | 4 q]) - done through LDS, transposed on the way in (one write, two 128-bit reads);
 //   * the adjoint products A_k' delta_k are the same instruction with the transposed weights as A operands; the deltas and activations never leave that layout;
 //   * the rollout evaluates the dynamics for trajectory j on all 16 lanes of its group (redundant, free), so the states are in registers where layer 0 needs them
-//     (B_q = x[4 q + k]: a select on k = lane >> 4) and the controls come back from the output layer by four shuffles;
+//     (B_q = x[4 q + k]: a select on k = lane >> 4) and the controls come back from the output layer through the same LDS hop;
 //   * the parameter gradient of a trajectory is the sum over time of the outer products delta_k z_k': lane (j, row r) accumulates row r of every layer (16 doubles per
 //     layer), the z_k of the step staged in LDS and read back by the 16 lanes of the trajectory as 128-bit broadcasts.
 // Trajectories and controls live in global memory (the API outputs or the workspace), the activations in the workspace in D layout (one coalesced 512-byte store per
 // hidden layer and step for four trajectories), the Jacobian pool in LDS: 16 time steps x 4 trajectories per evaluation pass.
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------------
-struct Mlp4tLayout { int zst, mus, pool, total; };
+struct Mlp4tLayout { int zst, mus, zt, pool, total; };
 template <class Mdl>
 __host__ __device__ inline Mlp4tLayout cp_mlp4t_layout() {
     Mlp4tLayout L;
     int o = 0;
     L.zst = o; o += 4 * MLP16_MAXL * MLP16_W;            // layer inputs of the current step, [trajectory][layer][16]
     L.mus = o; o += 4 * MLP16_W;                         // mu of the four trajectories
+    L.zt = o; o += 3 * 64;                               // D layout -> B operands (forward | backward) and the controls: one row of 16 per trajectory
     L.pool = o; o += 64 * ((Mdl::PATH_NVAR + 1 + Mdl::PATH_NCONST) | 1);
     L.total = o + 8;
     return L;
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(64) cp_step_mlp4t_kernel(int B, int T, pdp_pol
     static_assert(NX <= W && NU <= 4, "states in one 16-wide layer input, controls in the rows of one block");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Mlp4tLayout L = cp_mlp4t_layout<Mdl>();
-    double *zst = lds + L.zst, *mus = lds + L.mus, *pool = lds + L.pool;
+    double *zst = lds + L.zst, *mus = lds + L.mus, *ztf = lds + L.zt, *ztb = ztf + 64, *ztu = ztf + 128, *pool = lds + L.pool;
     const int lane = threadIdx.x, j = lane & 3, bq = (lane >> 2) & 3, kq = lane >> 4, rowid = 4 * bq + kq;      // D layout: this lane holds row `rowid` of trajectory j
     const int wv = blockIdx.x, b = 4 * wv + j;
     const bool live = b < B;
@@ -353,7 +354,16 @@ __global__ void __launch_bounds__(64) cp_step_mlp4t_kernel(int B, int T, pdp_pol
             bias[k] = (k < nl && rowid < lrows[k]) ? theta[loff[k] + lrows[k] * lcols[k] + rowid] : 0.0;
         }
     }
-    auto bcast = [&](double d, int q) { return __shfl(d, (lane & 0x33) | (q << 2), 64); };              // D layout -> B operand of inner block q
+    // D layout -> the four B operands of the next product: B_q[lane (j, b, k)] = d[row 4 q + k][trajectory j], whatever b.  Through LDS, transposed on the way in: the lane
+    // that holds row 4 b + i writes slot [j][i][b], a reader finds its four values side by side at [j][k][0..3] (one 64-bit write, two 128-bit reads; as eight
+    // ds_bpermute - two per operand - this was 17 % of the kernel, probes/mlp4t_timing.py)
+    typedef double pdp_d2 __attribute__((ext_vector_type(2)));
+    auto to_b = [&](double d, double* zt, double (&Bq)[4]) {
+        zt[j * 16 + kq * 4 + bq] = d;
+        wave_lds_sync();
+        const pdp_d2 lo = *(const pdp_d2*)(zt + j * 16 + kq * 4), hi = *(const pdp_d2*)(zt + j * 16 + kq * 4 + 2);
+        Bq[0] = lo.x; Bq[1] = lo.y; Bq[2] = hi.x; Bq[3] = hi.y;
+    };
 
     // ---------------- forward rollout: x_{t+1} = f(x_t, pi(x_t)) for trajectory j on the 16 lanes of its group
     double J = 0.0;
@@ -370,25 +380,27 @@ __global__ void __launch_bounds__(64) cp_step_mlp4t_kernel(int B, int T, pdp_pol
 #pragma unroll
             for (int k = 0; k < ML; ++k) {
                 if (k < nl) {
-                    double a = bias[k];
+                    double a = bias[k], Bq[4];
+                    if (k == 0) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (4 * q < lcols[k]) {
-                            double bop;
-                            if (k == 0) {
-                                const double c0 = 4 * q + 0 < NX ? xc[4 * q + 0 < NX ? 4 * q + 0 : 0] : 0.0, c1 = 4 * q + 1 < NX ? xc[4 * q + 1 < NX ? 4 * q + 1 : 0] : 0.0,
-                                             c2 = 4 * q + 2 < NX ? xc[4 * q + 2 < NX ? 4 * q + 2 : 0] : 0.0, c3 = 4 * q + 3 < NX ? xc[4 * q + 3 < NX ? 4 * q + 3 : 0] : 0.0;
-                                bop = kq == 0 ? c0 : (kq == 1 ? c1 : (kq == 2 ? c2 : c3));
-                            } else bop = bcast(zD, q);
-                            a = mma4_blk(AF[k][q], bop, a);
+                        for (int q = 0; q < 4; ++q) {
+                            const double c0 = 4 * q + 0 < NX ? xc[4 * q + 0 < NX ? 4 * q + 0 : 0] : 0.0, c1 = 4 * q + 1 < NX ? xc[4 * q + 1 < NX ? 4 * q + 1 : 0] : 0.0,
+                                         c2 = 4 * q + 2 < NX ? xc[4 * q + 2 < NX ? 4 * q + 2 : 0] : 0.0, c3 = 4 * q + 3 < NX ? xc[4 * q + 3 < NX ? 4 * q + 3 : 0] : 0.0;
+                            Bq[q] = kq == 0 ? c0 : (kq == 1 ? c1 : (kq == 2 ? c2 : c3));
                         }
-                    }
-                    if (k + 1 < nl) {
-                        zD = tanh(a);
-                        actg[((int64_t)t * AS + k) * 64 + lane] = zD;
-                    } else {
+                    } else to_b(zD, ztf, Bq);
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) uc[i] = __shfl(a, j + 16 * i, 64);                 // row i of the output layer: block 0, lane j + 16 i
+                    for (int q = 0; q < 4; ++q) if (4 * q < lcols[k]) a = mma4_blk(AF[k][q], Bq[q], a);
+                    if (k + 1 < nl) {
+                        zD = pdp_tanh(a);
+                        actg[((int64_t)t * AS + k) * 64 + lane] = zD;
+                    } else {                              // the controls: rows 0 .. NU - 1 of the output layer, to every lane of the trajectory
+                        ztu[j * 16 + rowid] = a;
+                        wave_lds_sync();
+                        const pdp_d2 lo = *(const pdp_d2*)(ztu + j * 16), hi = *(const pdp_d2*)(ztu + j * 16 + 2);
+                        const double uu[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) uc[i] = uu[i];
                     }
                 }
             }
@@ -492,9 +504,10 @@ __global__ void __launch_bounds__(64) cp_step_mlp4t_kernel(int B, int T, pdp_pol
                 dk[k] = 0.0;
                 if (k < nl) {
                     dk[k] = delta;
-                    double back = 0.0;                    // (A_k' delta_k)[row], inner index ascending
+                    double back = 0.0, Dq[4];             // (A_k' delta_k)[row], inner index ascending
+                    to_b(delta, ztb, Dq);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (4 * q < lrows[k]) back = mma4_blk(AT[k][q], bcast(delta, q), back);
+                    for (int q = 0; q < 4; ++q) if (4 * q < lrows[k]) back = mma4_blk(AT[k][q], Dq[q], back);
                     if (k > 0) delta = back * (1.0 - zin[k] * zin[k]);
                     else back0 = back;
                 }

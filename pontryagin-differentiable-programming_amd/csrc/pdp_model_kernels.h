@@ -1588,7 +1588,7 @@ __global__ void __launch_bounds__(64) cp_step_adjoint_kernel(int B, int T, pdp_p
                 for (int c = 0; c < cols; ++c) a += ths[loff[k] + lane + c * rows] * zs[k * W + c];
             }
             if (k + 1 < nl) {
-                double zk = tanh(a);
+                double zk = pdp_tanh(a);
                 if (lane < rows) { zs[(k + 1) * W + lane] = zk; if (store_acts) { if (offload) actg[t * L.actw + aoff[k] + lane] = zk; else acts[t * L.actw + aoff[k] + lane] = zk; } }
             } else if (lane < NU) vv[lane] = a;
             wave_lds_sync();

@@ -46,7 +46,7 @@ PDP_DEV void policy_eval(const pdp_policy& pol, int t, const double* x, const do
         }
         if (act) for (int r = 0; r < rows; ++r) act[k * MLP_MAX_WIDTH + r] = a[r];
         off += rows * cols + rows;
-        if (k + 1 < pol.n_layers) for (int r = 0; r < rows; ++r) z[r] = tanh(a[r]);
+        if (k + 1 < pol.n_layers) for (int r = 0; r < rows; ++r) z[r] = pdp_tanh(a[r]);
         cols = rows;
     }
     for (int j = 0; j < NU; ++j) u[j] = a[j];
@@ -83,7 +83,7 @@ PDP_DEV void policy_jacobians(const pdp_policy& pol, int p, int t, const double*
         // input of layer k: z = x (k = 0) or tanh(a_{k-1})
         for (int j = 0; j < NU; ++j) {
             for (int c = 0; c < cols; ++c) {
-                double zc = (k == 0) ? x[c] : tanh(act[(k - 1) * MLP_MAX_WIDTH + c]);
+                double zc = (k == 0) ? x[c] : pdp_tanh(act[(k - 1) * MLP_MAX_WIDTH + c]);
                 for (int r = 0; r < rows; ++r) dUe[j * p + off + r + c * rows] = J[j * WM + r] * zc;
             }
             for (int r = 0; r < rows; ++r) dUe[j * p + off + rows * cols + r] = J[j * WM + r];
@@ -96,7 +96,7 @@ PDP_DEV void policy_jacobians(const pdp_policy& pol, int p, int t, const double*
             }
         if (k > 0) {
             for (int j = 0; j < NU; ++j)
-                for (int c = 0; c < cols; ++c) { double th_ = tanh(act[(k - 1) * MLP_MAX_WIDTH + c]); J[j * WM + c] = Jz[j * WM + c] * (1.0 - th_ * th_); }
+                for (int c = 0; c < cols; ++c) { double th_ = pdp_tanh(act[(k - 1) * MLP_MAX_WIDTH + c]); J[j * WM + c] = Jz[j * WM + c] * (1.0 - th_ * th_); }
         } else {
             for (int j = 0; j < NU; ++j) for (int c = 0; c < NX; ++c) dUx[j * NX + c] = Jz[j * WM + c];
         }

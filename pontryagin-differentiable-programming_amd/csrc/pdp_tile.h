@@ -194,6 +194,21 @@ PDP_DEV bool tile_finite(const d4 v) {
 // waited for.  No s_barrier, and - unlike __syncthreads() - no vmcnt(0): pending global stores keep draining.
 PDP_DEV void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// tanh for the policy networks (PDP.py:733-751): sign(x) (1 - 2 / (exp(2 |x|) + 1)), the reciprocal by v_rcp_f64 + two Newton steps.  ABSOLUTE error <= 2e-16 (the
+// subtraction from 1 loses relative accuracy for |x| << 1, where the value itself is that small) - far inside the 1e-10 parity tolerance, and what the activations, their
+// derivatives 1 - z^2 and every product they enter need.  The library tanh (double-double exp, (e - 1/e) / (e + 1/e)) costs ~680 cycles per call on gfx950
+// (probes/mlp4t_timing.py with the call stubbed out: 23 % of the C5b step kernel); this one ~1/3 of that.  EVERY kernel that evaluates a policy uses this function, so the
+// kernels stay bit-identical among themselves (tests/test_gpu_cp_mlp.py); against numpy's tanh the activations differ by <= 2 ulp of 1.
+PDP_DEV double pdp_tanh(double x) {
+    const double ax = fmin(fabs(x), 20.0);              // tanh(20) = 1 - 8e-18 = 1.0 in fp64; keeps exp finite
+    const double d = exp(2.0 * ax) + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double t = fma(-2.0, r, 1.0);
+    return x != x ? x : copysign(t, x);                 // (a NaN stays a NaN: the status words report it)
+}
+
 // broadcast lane `src`'s value to the whole wave (2 x v_readlane_b32, no LDS)
 PDP_DEV double readlane_f64(double v, int src) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
