@@ -9,6 +9,7 @@ Sources (all under /root/reference/Examples, see SURVEY.md section 4 / Appendix 
   SysID/<sys>/data/<name>_iodata.mat         -> iodata_<sys>.npz
   OC/quadrotor/data/PDP_OC_results_trial_0   -> oc_quadrotor.npz  (solved_solution / true_solution)
   OC/cartpole/data/PDP_Neural_trial_0        -> oc_cartpole_neural.npz (final MLP params + rollout)
+  OC/{quadrotor,cartpole,robotarm}/data/PDP_{OC,Recmat,Neural}_*trial_0 -> undo_<name>.npz (final parameter / controls, last losses, settings: undo_fixtures)
 """
 import os
 import sys
@@ -94,6 +95,43 @@ def oc_cartpole_neural():
     print("oc_cartpole_neural", P.shape, ss["state_traj"].shape, keys)
 
 
+def undo_fixtures():
+    """The tails of the reference's stored CONTROL / PLANNING runs (Examples/OC/*/data): final parameter (or the final controls, from which the Lagrange parameter follows by
+    a least-squares fit), learning rate, the last losses, and the settings the run was made with.  The drivers update `current_parameter -= lr * dp` in place and append the
+    same array to parameter_trace every iteration, so only the FINAL parameter survives in the files - but the loop can be run BACKWARDS from it: P_{k} solves
+    P_k - lr * grad(P_k) = P_{k+1}, and loss(P_k) must be the stored loss_trace[k].  That pins ControlPlanning.step / recmat_step GRADIENTS on outputs of real CasADi runs
+    (tests/test_undo_stored_runs.py, tests/test_gpu_undo_stored_runs.py); SURVEY.md section 8c knew of no reference-held vector for them."""
+    NL = 12
+
+    def st(s):
+        s = s[0, 0]
+        return {k: np.asarray(s[k], dtype=float).squeeze() if s[k].dtype != object else np.asarray(s[k][0, 0], dtype=float) for k in s.dtype.names}
+
+    def common(r):
+        L = np.asarray(r["loss_trace"], float).flatten()
+        ss = st(r["solved_solution"])
+        return dict(lr=float(r["learning_rate"].squeeze()), K=L.size, loss_tail=L[-NL:], dt=float(r["dt"].squeeze()), horizon=int(r["horizon"].squeeze()),
+                    x0=ss["state_traj"][0], solved_state=ss["state_traj"], solved_control=ss["control_traj"].reshape(ss["state_traj"].shape[0] - 1, -1),
+                    solved_cost=float(ss["cost"]))
+
+    def final_param(r):
+        P = np.asarray(r["parameter_trace"], float)
+        return P.reshape(P.shape[0], -1)[-1]
+    jobs = [("quadrotor_recmat", "OC/quadrotor/data/PDP_Recmat_results_trial_0.mat", None, False), ("quadrotor_poly", "OC/quadrotor/data/PDP_OC_results_trial_0.mat", None, False),
+            ("cartpole_neural", "OC/cartpole/data/PDP_Neural_trial_0.mat", "cartpole", True), ("robotarm_neural", "OC/robotarm/data/PDP_Neural_trial_0.mat", "robotarm", True),
+            ("robotarm_recmat", "OC/robotarm/data/PDP_Recmat_results_trial_0.mat", "robotarm", False)]
+    for name, rel, envkey, has_param in jobs:
+        r = sio.loadmat(os.path.join(EX, rel))["results"][0, 0]
+        d = common(r)
+        if envkey:
+            e = r[envkey][0, 0]
+            d.update({"env_" + k: float(np.asarray(e[k]).squeeze()) for k in e.dtype.names})
+        if has_param:
+            d["final_parameter"] = final_param(r)
+        np.savez_compressed(os.path.join(OUT, "undo_%s.npz" % name), **d)
+        print("undo", name, "K", d["K"], "lr", d["lr"], "T", d["horizon"], "tail", d["loss_tail"][-2:], "cost", d["solved_cost"])
+
+
 if __name__ == "__main__":
     if not os.path.isdir(EX):
         sys.exit("reference not found at %s (fixtures are generated in the build container only)" % REF)
@@ -103,3 +141,4 @@ if __name__ == "__main__":
         iodata(s, istem)
     oc_quadrotor()
     oc_cartpole_neural()
+    undo_fixtures()
