@@ -274,6 +274,9 @@ def other_configs(torch):
         solve_ms = kinds[record_kind]["oc_solve_ms"]
         sol = predicted_solve(pred=pred_in)
         # the same stopped where the reference's IPOPT stops (its default tol = 1e-8; the figures above use the 1e-10 the parity tests need)
+        # PDP_MS_PREDICT_GUARD (round 5, the default of every loop: the previous solution is evaluated beside its prediction, one more residual pass): what it costs here
+        unguarded_ms = _event_ms(torch, lambda: predicted_solve(pred=dict(pred_in, guard=False)), reps=5, warm=1)
+        rejected = int(((sol["status"] & 512) != 0).sum())
         solve8_ms = _event_ms(torch, lambda: predicted_solve(1e-8, pred_in), reps=5, warm=1)
         sol8 = predicted_solve(1e-8, pred_in)
         it8 = sol8["iterations"].double()
@@ -330,7 +333,8 @@ def other_configs(torch):
                    "sensitivities (PDP_MS_PREDICT: applied inside the solver launch from the packed fp32 prediction record - the kind named in prediction_record_kind) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / "
                    "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit "
                    "(it has none for the solve)",
-              extra={"oc_solve_ms": solve_ms, "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
+              extra={"oc_solve_ms": solve_ms, "oc_solve_ms_without_the_prediction_guard": unguarded_ms, "predictions_rejected_by_the_guard": rejected,
+                     "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
                      "irl_loop_wall_clock": loop_res, "prediction_record_kind": record_kind, "prediction_includes_multipliers": record_kind == "full", "pipelines_by_record_kind": kinds,
                      "prediction_record_bytes": int(sens0["predict_record"].numel() * 4) if record_kind == "full" else int(B * T * (mdl.n + mdl.m) * mdl.p * 4), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),

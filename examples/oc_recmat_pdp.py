@@ -36,7 +36,7 @@ def build(system):
     """(ControlPlanning object, OCSys object of the same problem, dt)"""
     env, dt = zoo.make_env(system, "oc")
     dyn = env.X + dt * env.f
-    cp = PDP.ControlPlanning(system + " recmat")
+    cp = PDP.ControlPlanning(system)                  # (same label and equations as the pre-built zoo model: no compilation at run time)
     cp.setStateVariable(env.X)
     cp.setControlVariable(env.U)
     cp.setDyn(dyn)

@@ -42,10 +42,14 @@ class OCSys:
         self._bar_model = None
 
     # ---- models stated with real casadi.SX (as every script of the reference does, PDP.py:23): the symbols are mirrored by this package's own, the
-    # expressions converted through the Function's instruction tape (casadi_adapter.py); from there on CasADi is not used
+    # expressions converted through the Function's instruction tape (casadi_adapter.py); from there on CasADi is not used.  Scope: OCSys only (SysID and
+    # ControlPlanning take this package's sx objects); operations: what sx.py expresses (+ - * / neg, sq, sqrt, sin, cos, tan, tanh, exp, log, pow with a
+    # constant exponent, inv, twice) - OP_FABS / OP_SIGN / OP_ATAN2 / OP_ASIN / OP_ACOS / OP_ATAN / OP_FMIN / OP_FMAX raise NotImplementedError at setDyn time.
     def _own(self, key, var):
         from . import casadi_adapter as ca
         if not ca.is_casadi(var):
+            if hasattr(self, "_casadi_vars"):
+                self._casadi_vars.pop(key, None)          # (a variable re-set with an own SX after a CasADi one: no stale mapping)
             return var
         if not hasattr(self, "_casadi_vars"):
             self._casadi_vars = {}

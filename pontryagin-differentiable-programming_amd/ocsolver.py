@@ -84,6 +84,10 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     big = mdl.n > 16 or mdl.m > 4                         # beyond the multiple-shooting kernel's tiles
     generic = big and method != "single" and u_init is None and warm_start is None
     if not generic and (method == "single" or big or (method == "auto" and u_init is not None) or (warm_start is not None and "costate" not in warm_start)):
+        if predict is not None:
+            import warnings
+            warnings.warn("ocsolver.solve_batch: `predict` is used by the multiple-shooting kernel only; this call takes single shooting (method / u_init / a warm start "
+                          "without multipliers) and starts from the warm start as it is", RuntimeWarning)
         return solve_batch_single_shooting(oc, ini_state, horizon, auxvar_value, u_init=u_init, tol=tol, max_iter=max_iter, print_level=print_level,
                                            neighbor_retries=neighbor_retries, warm_start=warm_start, want_gains=want_gains)
     x0 = runtime.dev(ini_state).reshape(-1, mdl.n)
@@ -91,6 +95,9 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     th = oc._theta(auxvar_value, B)
     if generic:
         # the same NLP and iteration, kernel by kernel (solve_batch_ms_generic)
+        if predict is not None:
+            import warnings
+            warnings.warn("ocsolver.solve_batch: `predict` is not used on the kernel-by-kernel route (models beyond n = 16 / m = 4)", RuntimeWarning)
         ms = solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=min(tol, 1e-9) * 0.1, max_iter=max_iter, print_level=print_level)
     else:
         warm = None if warm_start is None else (warm_start["state"], warm_start["control"], warm_start["costate"])

@@ -71,9 +71,14 @@ def test_workspace_size_entry_points_are_host_side_and_consistent(built):
     cp = runtime.load_model(codegen.build_problem(zoo.make_problem("quadrotor", "oc"))[0])
     mlp = runtime.make_policy("mlp", layers=[13, 13, 4])
     poly = runtime.make_policy("poly", pivots=np.linspace(0, 100, 6))
-    # MLP [13,13] runs on the register-resident kernel: one stored activation per lane and time step, whatever the batch
-    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(mlp), 420) == 16 * 100 * 64 * 8
-    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(mlp), 420) == 1024 * 100 * 64 * 8
+    # MLP [13,13] runs on the register-resident kernels: the larger of one stored activation per lane and time step (one trajectory per wavefront) and the
+    # four-trajectory kernel's activations in D layout + the trajectories (cp_mlp4t_ws_doubles)
+    wsb = lambda b, t: 8 * max(b * t * 64, ((b + 3) // 4) * t * 3 * 64 + b * ((t + 1) * 13 + t * 4))
+    assert cp.lib.pdp_cp_step_workspace_bytes(16, 100, ctypes.byref(mlp), 420) == wsb(16, 100)
+    assert cp.lib.pdp_cp_step_workspace_bytes(1024, 100, ctypes.byref(mlp), 420) == wsb(1024, 100)
+    # policies beyond every tuned kernel take the size-generic one: trajectory + controls + the hidden activations of every step, per trajectory
+    huge = runtime.make_policy("mlp", layers=[64, 64, 4])
+    assert cp.lib.pdp_cp_step_workspace_bytes(8, 100, ctypes.byref(huge), 64 * 13 + 64 + 64 * 64 + 64 + 4 * 64 + 4) == 8 * (101 * 13 + 100 * 4 + 100 * 128) * 8
     # a network beyond that kernel (width > 16): the general adjoint kernel, 20 stored activations per step, offloaded only when the batch does not
     # fit the CUs at once (256 CUs assumed without a GPU)
     wide = runtime.make_policy("mlp", layers=[20, 4])
