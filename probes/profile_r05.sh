@@ -17,6 +17,10 @@ grep '^{' $O/stats.log | tail -1 > $O/bench_line_under_rocprof.json
 python probes/rocprof_match.py $O/stats $O/windows.json $O/bench_line_unprofiled.json > $O/rocprof_match.txt 2>&1
 echo "rocprof_match exit $?" >> $O/rocprof_match.txt
 for f in $(find $O/stats -name 'p_kernel_stats.csv'); do cp $f $O/bench_full_kernel_stats.csv; done
+# ---- the headline alone (the command whose one kernel `roofline.achieved` prices: its average duration in this summary must agree with roofline.kernel_ms)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-scaling-configs > $O/stats_headline.log 2>&1
+for f in $(find $O/stats_headline -name 'p_kernel_stats.csv'); do cp $f $O/bench_kernel_stats.csv; done
+grep '^{' $O/stats_headline.log | tail -1 > $O/bench_line_headline_under_rocprof.json
 # ---- calibration
 hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate probes/pmc_calibrate.hip > $O/calib_build.log 2>&1
 /tmp/pmc_calibrate 1024 4 > $O/calib_truth.txt 2>&1
