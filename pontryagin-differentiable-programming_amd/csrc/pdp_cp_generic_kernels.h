@@ -27,8 +27,8 @@ constexpr int GEN_MAXL = 16;       // = the length of pdp_policy.sizes
 struct CpGenLayout {
     int64_t ws_per_traj;           // doubles of workspace per trajectory
     int64_t x_g, u_g, act_g, zs_g, ds_g, vs_g;
-    int zs_l, ds_l, mu_l, v_l, ul_l, pool_l, lds_total;
-    int sum_in, sum_w, actw, rows, wide, ul;     // sum_in: NX + hidden widths (+ 2 constants); sum_w: all widths; wide: zs / ds in the workspace; ul: u_t / v_t of an open-loop policy staged in LDS
+    int zs_l, ds_l, mu_l, v_l, ul_l, tab_l, th_l, pool_l, lds_total;
+    int sum_in, sum_w, actw, rows, wide, ul, tab, thl;     // sum_in: NX + hidden widths (+ 2 constants); sum_w: all widths; wide: zs / ds in the workspace; ul: u_t / v_t of an open-loop policy staged in LDS
 };
 
 template <class Mdl>
@@ -53,6 +53,13 @@ __host__ __device__ inline CpGenLayout cp_generic_layout(const pdp_policy& pol, 
     // trip per step); the same area then holds v_t = c_u + G_t' mu_{t+1} of every step, from which the gradient is formed after the sweep
     L.ul = pol.kind != PDP_POLICY_MLP && (int64_t)T * Mdl::NU <= 4096;
     L.ul_l = o; o += L.ul ? T * Mdl::NU : 0;
+    // a table policy's basis values [T][n_basis] in LDS while they fit 48 KB: the control pre-pass and the final gradient contraction walk the table with dependent
+    // accumulations - from global memory every trip waits for its load (measured on the recmat drivers: 60 of 74 us per launch)
+    L.tab = pol.kind == PDP_POLICY_TABLE && (int64_t)T * pol.n_basis <= 6144;
+    L.tab_l = o; o += L.tab ? T * pol.n_basis : 0;
+    const int p_open = (pol.kind == PDP_POLICY_POLY ? pol.n_pivots : pol.n_basis) * Mdl::NU;
+    L.thl = pol.kind != PDP_POLICY_MLP && p_open <= 2048;      // ... and the parameters of an open-loop policy beside it
+    L.th_l = o; o += L.thl ? p_open : 0;
     L.pool_l = o;
     int rows = (int)((150 * 1024 / 8 - o - 8) / STRIDE);
     rows = rows > 64 ? 64 : rows;
@@ -114,14 +121,19 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
     sync();
 
     // open-loop policies: u_t = sum_i b_i(t) theta_i for ALL t at once (lane = step), into the trajectory's control array and the LDS staging
-    auto basis = [&](int t, int i) { return table ? pol.table[(int64_t)t * nb + i] : lagrange_basis(pol, i, (double)t); };
+    const double* tab = L.tab ? lds + L.tab_l : pol.table;
+    const double* tho = L.thl ? lds + L.th_l : thb;                                   // parameters as the control pre-pass reads them
+    if (L.tab) for (int q = lane; q < T * nb; q += 64) lds[L.tab_l + q] = pol.table[q];
+    if (L.thl) for (int q = lane; q < p; q += 64) lds[L.th_l + q] = thb[q];
+    if (L.tab || L.thl) sync();
+    auto basis = [&](int t, int i) { return table ? tab[(int64_t)t * nb + i] : lagrange_basis(pol, i, (double)t); };
     double* ul = L.ul ? lds + L.ul_l : us;                                             // u_t inside the rollout, v_t inside the sweep
     double* vs = L.ul ? lds + L.ul_l : wsb + L.vs_g;
     if (!mlp) {
         for (int t = lane; t < T; t += 64) {
             for (int j = 0; j < NU; ++j) {
                 double u = 0.0;
-                for (int i = 0; i < nb; ++i) u += basis(t, i) * thb[i * NU + j];       // i ascending, as policy_eval
+                for (int i = 0; i < nb; ++i) u += basis(t, i) * tho[i * NU + j];       // i ascending, as policy_eval
                 us[(int64_t)t * NU + j] = u;
                 if (L.ul) ul[t * NU + j] = u;
             }
