@@ -33,3 +33,35 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -
 python probes/pmc_traffic_r05.py $O > $O/traffic_summary.txt 2>&1
 cat $O/rocprof_match.txt | tail -60
 cat $O/traffic_summary.txt | tail -60
+# ---- instruction counts of the tanh-MLP step at C5's total batch (8192 trajectories, [13, 13], T = 100): four trajectories per wavefront (default) against one (PDP_CP_MLP_VARIANT=3)
+cat > /tmp/mlp_once.py <<'PY'
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+import torch
+from pdp_amd import runtime as rt, zoo
+mdl = zoo.get("quadrotor", "oc")
+rng = np.random.default_rng(0)
+B, T, p = 8192, 100, 420
+x0 = np.zeros((B, 13)); x0[:, :3] = rng.uniform(-2, 2, (B, 3)); x0[:, 6] = 1
+x0d, thp, pol = rt.dev(x0), rt.dev(0.1 * rng.standard_normal(p)), rt.make_policy("mlp", layers=[13, 13, 4])
+for _ in range(4):
+    mdl.cp_step(pol, p, x0d, thp, T)
+torch.cuda.synchronize()
+PY
+for v in 2 3; do
+  PDP_CP_MLP_VARIANT=$v rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/mlp_pmc_$v -o p -- python /tmp/mlp_once.py > $O/mlp_pmc_$v.log 2>&1
+done
+python - <<'PY'
+import csv, glob, json, collections
+out = {}
+for v, tag in ((2, "cp_step_mlp4t_kernel (four trajectories per wavefront, round 5 default)"), (3, "cp_step_mlp16_kernel (one trajectory per wavefront, PDP_CP_MLP_VARIANT=3)")):
+    vals = collections.defaultdict(list)
+    for f in glob.glob("gpurun_out/prof5/mlp_pmc_%d/**/*counter_collection.csv" % v, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "cp_step_mlp" in r["Kernel_Name"]:
+                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[tag] = {k: sum(x[-3:]) / len(x[-3:]) for k, x in vals.items()}
+out["note"] = "rocprofv3 --pmc, mean of the last three of four dispatches; C5 total batch: 8192 quadrotor trajectories, tanh MLP [13, 13] (p = 420), T = 100"
+json.dump(out, open("gpurun_out/prof5/pmc_mlp_kernels.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY

@@ -7,8 +7,8 @@ started at the stored P[0] with the stored learning rate - cold multiple-shootin
 and as a hipGraph - and must write the stored rows: entry k of its traces is what the reference stored as L[k+1], P[k+1].
 
 Stated tolerances (margins recorded): rows 1..3: loss 1e-9 relative, parameter 1e-7 (the gradient tolerance against IPOPT's traces) x lr x the
-largest gradient entry x rows; all 100 rows: loss 2e-8 relative (IPOPT's termination noise in the stored rows; the oracle's own replay, tests/test_oracle_gd_replay.py,
-is at 3e-9), parameter 1e-9 absolute at every row, i.e. the loop lands on the stored P[100]."""
+largest gradient entry x rows; all 200 rows: loss 2e-8 relative (IPOPT's termination noise in the stored rows; the oracle's own replay, tests/test_oracle_gd_replay.py,
+is at 3e-9), parameter 1e-9 absolute at every row, i.e. the loop lands on the stored P[200]."""
 import os
 import subprocess
 import sys
@@ -18,7 +18,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ITERS = 100
+ITERS = 200          # (the fixtures hold rows 0 .. 201)
 
 
 def _check(margins, label, L, P, h, lr):
