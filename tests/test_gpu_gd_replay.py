@@ -7,8 +7,8 @@ started at the stored P[0] with the stored learning rate - cold multiple-shootin
 and as a hipGraph - and must write the stored rows: entry k of its traces is what the reference stored as L[k+1], P[k+1].
 
 Stated tolerances (margins recorded): rows 1..3: loss 1e-9 relative, parameter 1e-7 (the gradient tolerance against IPOPT's traces) x lr x the
-largest gradient entry x rows; all 200 rows: loss 2e-8 relative (IPOPT's termination noise in the stored rows; the oracle's own replay, tests/test_oracle_gd_replay.py,
-is at 3e-9), parameter 1e-9 absolute at every row, i.e. the loop lands on the stored P[200]."""
+largest gradient entry x rows; all 200 rows: loss 2e-8 relative or 5e-9 absolute (IPOPT's termination noise in the stored rows; the oracle's own replay, tests/test_oracle_gd_replay.py,
+is at 3e-9 over its 100), parameter 1e-9 absolute at every row, i.e. the loop lands on the stored P[200]."""
 import os
 import subprocess
 import sys
@@ -30,7 +30,9 @@ def _check(margins, label, L, P, h, lr):
     margins.check("%s: loss_trace rows 1..3 (relative)" % label, rel[:3].max(), 1e-9)
     margins.check("%s: parameter_trace rows 1..3 (in units of 1e-7 x lr x largest gradient entry x rows)" % label,
                   (err[:3] / (1e-7 * lr * np.maximum.accumulate(g[:3]) * np.arange(1, 4))).max(), 1.0)
-    margins.check("%s: loss_trace all %d rows (relative)" % (label, n), rel.max(), 2e-8)
+    # every row: 2e-8 relative, or 5e-9 absolute where the loss itself has become small (quadrotor rows 170 .. 200: loss 0.04 - the stored values carry the error of
+    # IPOPT's own termination, tol = 1e-8 on the states, which enters the loss as 2 |x - x_demo| 1e-8 whatever the loss)
+    margins.check("%s: loss_trace all %d rows (in units of max(2e-8 relative, 5e-9 absolute))" % (label, n), (np.abs(L - Ls) / np.maximum(2e-8 * np.abs(Ls), 5e-9)).max(), 1.0)
     margins.check("%s: parameter_trace all %d rows (absolute)" % (label, n), err.max(), 1e-9)
     margins.check("%s: lands on the stored P[%d] (absolute)" % (label, n), err[-1], 1e-9)
 
