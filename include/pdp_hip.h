@@ -237,6 +237,7 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                                      quantities of the convergence test - is finite and not larger; otherwise the solve starts from the previous solution and status gets
                                      PDP_MS_PREDICT_REJECTED.  One more residual pass per solve.  Needed where parameter steps are large against the curvature: on the
                                      reference's stored rocket IRL run the unguarded prediction of row 1 sends Newton's method to another stationary point */
+#define PDP_MS_GUARD_TRUST 0.02     /* PDP_MS_PREDICT_GUARD: a prediction that changes no state or control by more than this fraction of max(1, |its value|) is kept without the check */
 #define PDP_MS_PREDICT_REJECTED 512 /* status, informational: PDP_MS_PREDICT_GUARD preferred the previous solution to its prediction */
 typedef struct pdp_oc_ms_opts {
     double tol;

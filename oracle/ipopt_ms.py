@@ -258,6 +258,9 @@ def predict_start(oc, state, control, costate, auxvar_value, dtheta, with_costat
     return state + X @ d, control + U @ d, (costate + L @ d) if with_costate else np.array(costate, dtype=float)
 
 
+GUARD_TRUST = 0.02          # = PDP_MS_GUARD_TRUST of include/pdp_hip.h
+
+
 def scaled_kkt_error(oc, xs, us, lam, auxvar_value, primal_only=False):
     """max(inf_pr / (1 + max|x|,|u|), inf_du / (1 + max|lam|)) - the two quantities of solve()'s convergence test, each over the scale it is tested against;
     primal_only: the first of them alone"""
@@ -279,6 +282,10 @@ def guarded_start(oc, ini_state, state, control, costate, auxvar_prev, dtheta, w
     plain[0][0] = _vec(ini_state)
     pred = [np.array(a, dtype=float) for a in predict_start(oc, state, control, costate, auxvar_prev, dtheta, with_costate=with_costate)]
     pred[0][0] = _vec(ini_state)
+    # (PDP_MS_GUARD_TRUST: a correction below 2 % of max(1, |value|) in every state and control is trusted without the comparison)
+    corr = max(np.abs((pred[0] - plain[0])[1:] / np.maximum(1.0, np.abs(plain[0][1:]))).max(), np.abs((pred[1] - plain[1]) / np.maximum(1.0, np.abs(plain[1]))).max())
+    if corr <= GUARD_TRUST:
+        return tuple(pred), False
     e_plain = scaled_kkt_error(oc, *plain, th1, primal_only=not with_costate)
     with np.errstate(all="ignore"):
         e_pred = scaled_kkt_error(oc, *pred, th1, primal_only=not with_costate) if all(np.all(np.isfinite(a)) for a in pred) else np.inf

@@ -383,6 +383,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         const bool recp = rec && (op.flags & PDP_MS_PREDICT_PRIMAL) != 0;
         const bool pred = !rec && warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
         const bool predl = pred && op.riccati != nullptr;
+        double corr_l = 0.0;           // largest predicted change of a state or control against max(1, |its value|): the guard below trusts small corrections unseen
+        auto corr_upd = [&](double d, double v) { corr_l = fabs(d) <= 1.7e308 ? fmax(corr_l, fabs(d) / fmax(1.0, fabs(v))) : 1e300; };      // (a non-finite correction is never trusted)
         {
             double* s0 = Pt(0);
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
@@ -432,7 +434,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #pragma unroll
                         for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
                         dxb[sg * NX + i] = dx;
-                        s0[i * TS + t + 1] = xb[(t + 1) * NX + i] + dx;
+                        const double xv = xb[(t + 1) * NX + i];
+                        corr_upd(dx, xv);
+                        s0[i * TS + t + 1] = xv + dx;
                         // control rows: lane (stage, i) takes rows i, i + NX, ... - one row per lane when NU <= NX, and every row is still written when a model has more
                         // controls than states (round-4 advice: rows >= NX used to be skipped)
 #pragma unroll
@@ -440,7 +444,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                             double du = 0.0;
 #pragma unroll
                             for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + iu * NP + j], dth[j], du);
-                            s0[OU + iu * TS + t] = ub[t * NU + iu] + du;
+                            const double uv = ub[t * NU + iu];
+                            corr_upd(du, uv);
+                            s0[OU + iu * TS + t] = uv + du;
                         }
                     }
                     wave_lds_sync();
@@ -496,6 +502,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 rows_dot(op.dxdp + (int64_t)b * (T + 1) * NX * NP, (T + 1) * NX, [&](int q, double d) {
                     const int t = q / NX, i = q - t * NX;
                     double v = xb[q];
+                    if (t > 0) corr_upd(d, v);
                     v += d;
                     s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : v;
                     dxs[q] = d;
@@ -503,6 +510,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 rows_dot(op.dudp + (int64_t)b * T * NU * NP, T * NU, [&](int q, double d) {
                     const int t = q / NU, i = q - t * NU;
                     double v = ub[q];
+                    corr_upd(d, v);
                     v += d;
                     s0[OU + i * TS + t] = v;
                 });
@@ -880,7 +888,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // A prediction of states and controls only (PDP_MS_PREDICT_PRIMAL, or no Riccati record) is judged by the primal part alone: both candidates carry the SAME
         // multipliers, so the dual residual says nothing about the quality of the prediction (at a 2 % step it is a coin flip that would throw away predictions which
         // save an iteration - oracle: cart-pole and quadrotor demos, primal infeasibility 1e-4 against 3e-2, dual 5.3 against 5.1).
-        const bool guard = ph1 && (rec || pred) && (op.flags & PDP_MS_PREDICT_GUARD) != 0;
+        // A correction that moves no state or control by more than PDP_MS_GUARD_TRUST (2 %) of max(1, |its value|) is trusted without the extra pass: the error of a
+        // first-order prediction is of the order of the square of that.  (The steps of a running gradient-descent loop are ~1e-4: the guard then costs nothing; the
+        // rocket's rejected predictions move the trajectory by 150 %.)
+        const double corr = wave_max(corr_l);
+        const bool guard = ph1 && (rec || pred) && (op.flags & PDP_MS_PREDICT_GUARD) != 0 && !(corr <= PDP_MS_GUARD_TRUST);
         const bool g_primal = rec ? recp : !predl;
         double g_f = 0.0, g_th = 0.0, g_pr = 0.0, g_du = 0.0, g_z = 0.0, g_l = 0.0, g_lc = 0.0, g_err = 0.0;
         bool g_fin = false;
