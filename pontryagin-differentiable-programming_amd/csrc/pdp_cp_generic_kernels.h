@@ -92,14 +92,19 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
     double* xs = xo ? xo + (int64_t)b * (T + 1) * NX : wsb + L.x_g;                   // the API outputs double as the staging of the trajectory
     double* us = uo ? uo + (int64_t)b * T * NU : wsb + L.u_g;
     double* acts = wsb + L.act_g;                                                     // [T][actw]: tanh outputs of the hidden layers
-    double* zs = L.wide ? wsb + L.zs_g : lds + L.zs_l;                                // layer inputs of the current step: z_0 = x | z_1 | ... | 1.0 | 0.0   (basis values for POLY / TABLE)
-    double* ds = L.wide ? wsb + L.ds_g : lds + L.ds_l;                                // layer deltas of the current step (v for POLY / TABLE)
+    // Arrays that live in LDS or - when they do not fit - in the workspace are reached through accessors that branch (uniformly) on the flag: a pointer that may be either
+    // is a GENERIC pointer to the compiler, every access a flat_load / flat_store through the texture path - in the serial chains of the rollout and the sweep that was
+    // most of a recmat step.  Zr / Zw: layer inputs of the current step (z_0 = x | z_1 | ... | 1.0 | 0.0); Dr / Dw: layer deltas.
+    auto Zr = [&](int i) -> double { return L.wide ? wsb[L.zs_g + i] : lds[L.zs_l + i]; };
+    auto Zw = [&](int i, double v) { if (L.wide) wsb[L.zs_g + i] = v; else lds[L.zs_l + i] = v; };
+    auto Dr = [&](int i) -> double { return L.wide ? wsb[L.ds_g + i] : lds[L.ds_l + i]; };
+    auto Dw = [&](int i, double v) { if (L.wide) wsb[L.ds_g + i] = v; else lds[L.ds_l + i] = v; };
     double *mu = lds + L.mu_l, *vv = lds + L.v_l, *pool = lds + L.pool_l;
     const double* thb = theta + (int64_t)b * tb;
     double* gb = grad + (int64_t)b * p;
     const bool mlp = pol.kind == PDP_POLICY_MLP, table = pol.kind == PDP_POLICY_TABLE;
     const int nl = mlp ? pol.n_layers : 0, nb = mlp ? 0 : (table ? pol.n_basis : pol.n_pivots);
-    const int one = L.sum_in - 2;                                                     // zs[one] = 1.0 (bias factor), zs[one + 1] = 0.0
+    const int one = L.sum_in - 2;                                                     // layer-input slots `one`, `one + 1` hold 1.0 (bias factor) and 0.0
     auto sync = [&]() {       // everything the lanes exchange goes through LDS or (wide networks, trajectory, activations, gradient) global memory of this wavefront's own slice
         // (workgroup scope: the wavefront is its own workgroup and a CU's vector cache is coherent for its own stores - the fence is the wait for them)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -117,41 +122,41 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
         }
     }
     for (int j = lane; j < p; j += 64) gb[j] = 0.0;
-    if (lane == 0) { zs[one] = 1.0; zs[one + 1] = 0.0; }
+    if (lane == 0) { Zw(one, 1.0); Zw(one + 1, 0.0); }
     sync();
 
     // open-loop policies: u_t = sum_i b_i(t) theta_i for ALL t at once (lane = step), into the trajectory's control array and the LDS staging
-    const double* tab = L.tab ? lds + L.tab_l : pol.table;
-    const double* tho = L.thl ? lds + L.th_l : thb;                                   // parameters as the control pre-pass reads them
+    auto TAB = [&](int64_t i) -> double { return L.tab ? lds[L.tab_l + i] : pol.table[i]; };
+    auto THO = [&](int i) -> double { return L.thl ? lds[L.th_l + i] : thb[i]; };      // parameters as the control pre-pass reads them
     if (L.tab) for (int q = lane; q < T * nb; q += 64) lds[L.tab_l + q] = pol.table[q];
     if (L.thl) for (int q = lane; q < p; q += 64) lds[L.th_l + q] = thb[q];
     if (L.tab || L.thl) sync();
-    auto basis = [&](int t, int i) { return table ? tab[(int64_t)t * nb + i] : lagrange_basis(pol, i, (double)t); };
-    double* ul = L.ul ? lds + L.ul_l : us;                                             // u_t inside the rollout, v_t inside the sweep
-    double* vs = L.ul ? lds + L.ul_l : wsb + L.vs_g;
+    auto basis = [&](int t, int i) { return table ? TAB((int64_t)t * nb + i) : lagrange_basis(pol, i, (double)t); };
+    auto ULr = [&](int i) -> double { return L.ul ? lds[L.ul_l + i] : us[i]; };          // u_t inside the rollout ...
+    auto VSr = [&](int i) -> double { return L.ul ? lds[L.ul_l + i] : wsb[L.vs_g + i]; };  // ... v_t inside the sweep (the same LDS area)
+    auto VSw = [&](int i, double v) { if (L.ul) lds[L.ul_l + i] = v; else wsb[L.vs_g + i] = v; };
     if (!mlp) {
         for (int t = lane; t < T; t += 64) {
             for (int j = 0; j < NU; ++j) {
                 double u = 0.0;
-                for (int i = 0; i < nb; ++i) u += basis(t, i) * tho[i * NU + j];       // i ascending, as policy_eval
+                for (int i = 0; i < nb; ++i) u += basis(t, i) * THO(i * NU + j);       // i ascending, as policy_eval
                 us[(int64_t)t * NU + j] = u;
-                if (L.ul) ul[t * NU + j] = u;
+                if (L.ul) lds[L.ul_l + t * NU + j] = u;
             }
         }
         sync();
     }
     // MLP: u_t = pi(x_t, theta) into vv[0 .. NU); layer inputs stay in zs, hidden activations go to acts[t]
     auto policy_forward = [&](int t) {
-        for (int i = lane; i < NX; i += 64) zs[i] = xs[(int64_t)t * NX + i];
+        for (int i = lane; i < NX; i += 64) Zw(i, xs[(int64_t)t * NX + i]);
         sync();
         for (int k = 0; k < nl; ++k) {
-            const int rows = lrows[k], cols = lcols[k];
-            const double* zk = zs + zoff[k];
+            const int rows = lrows[k], cols = lcols[k], zo = zoff[k];
             for (int r = lane; r < rows; r += 64) {
                 double a = 0.0;
-                for (int c = 0; c < cols; ++c) a += thb[loff[k] + r + c * rows] * zk[c];        // column-major A_k (PDP.py:739), c ascending as policy_eval
+                for (int c = 0; c < cols; ++c) a += thb[loff[k] + r + c * rows] * Zr(zo + c);    // column-major A_k (PDP.py:739), c ascending as policy_eval
                 a += thb[loff[k] + rows * cols + r];
-                if (k + 1 < nl) { const double z = pdp_tanh(a); zs[zoff[k + 1] + r] = z; acts[(int64_t)t * L.actw + aoff[k] + r] = z; }
+                if (k + 1 < nl) { const double z = pdp_tanh(a); Zw(zoff[k + 1] + r, z); acts[(int64_t)t * L.actw + aoff[k] + r] = z; }
                 else vv[r] = a;
             }
             sync();
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
                 for (int j = lane; j < NU; j += 64) us[(int64_t)t * NU + j] = vv[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < NU; ++j) uc[j] = ul[t * NU + j];
+                for (int j = 0; j < NU; ++j) uc[j] = ULr(t * NU + j);
             }
             Mdl::dyn(xc, uc, nullptr, pc, xn);
             J += Mdl::path_cost(xc, uc, nullptr, pc);
@@ -241,32 +246,32 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
             for (int i = lane; i < NX; i += 64) vv[NU + i] = 0.0;          // (d pi/dx)' v: stays 0 for the open-loop policies
             sync();
             if (!mlp) {
-                for (int j = lane; j < NU; j += 64) vs[t * NU + j] = vv[j];           // the gradient of an open-loop policy is formed after the sweep
+                for (int j = lane; j < NU; j += 64) VSw(t * NU + j, vv[j]);           // the gradient of an open-loop policy is formed after the sweep
             } else {
-                for (int i = lane; i < NX; i += 64) zs[i] = xs[(int64_t)t * NX + i];
-                for (int k = 1; k < nl; ++k) for (int r = lane; r < lrows[k - 1]; r += 64) zs[zoff[k] + r] = acts[(int64_t)t * L.actw + aoff[k - 1] + r];
-                for (int j = lane; j < NU; j += 64) ds[doff[nl - 1] + j] = vv[j];
+                for (int i = lane; i < NX; i += 64) Zw(i, xs[(int64_t)t * NX + i]);
+                for (int k = 1; k < nl; ++k) for (int r = lane; r < lrows[k - 1]; r += 64) Zw(zoff[k] + r, acts[(int64_t)t * L.actw + aoff[k - 1] + r]);
+                for (int j = lane; j < NU; j += 64) Dw(doff[nl - 1] + j, vv[j]);
                 sync();
                 for (int k = nl - 1; k >= 0; --k) {
                     const int rows = lrows[k], cols = lcols[k];
-                    const double* dk = ds + doff[k];
+                    const int dko = doff[k];
                     // parameters of layer k: vec_F(A_k)[r + c rows] gets delta_k[r] z_k[c], the bias delta_k[r]
                     {
                         const int nw = rows * cols;
                         int e = lane, r = lane % rows, cc = lane / rows;                 // e = r + cc rows, advanced by 64 per trip without divisions
                         const int dr = 64 % rows, dc = 64 / rows;
                         for (; e < nw; e += 64) {
-                            gb[loff[k] + e] += dk[r] * zs[zoff[k] + cc];
+                            gb[loff[k] + e] += Dr(dko + r) * Zr(zoff[k] + cc);
                             r += dr; cc += dc;
                             if (r >= rows) { r -= rows; ++cc; }
                         }
-                        for (int r2 = lane; r2 < rows; r2 += 64) gb[loff[k] + nw + r2] += dk[r2];
+                        for (int r2 = lane; r2 < rows; r2 += 64) gb[loff[k] + nw + r2] += Dr(dko + r2);
                     }
                     // back through the layer: (A_k' delta_k)[c], times tanh' of the layer below, or (d pi/dx)' v at the input
                     for (int cidx = lane; cidx < cols; cidx += 64) {
                         double a = 0.0;
-                        for (int r = 0; r < rows; ++r) a += thb[loff[k] + r + cidx * rows] * dk[r];
-                        if (k > 0) { const double zk = zs[zoff[k] + cidx]; ds[doff[k - 1] + cidx] = a * (1.0 - zk * zk); }
+                        for (int r = 0; r < rows; ++r) a += thb[loff[k] + r + cidx * rows] * Dr(dko + r);
+                        if (k > 0) { const double zk = Zr(zoff[k] + cidx); Dw(doff[k - 1] + cidx, a * (1.0 - zk * zk)); }
                         else vv[NU + cidx] = a;
                     }
                     sync();
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
         for (int q = lane; q < p; q += 64) {
             const int i = q / NU, j = q - i * NU;
             double g = 0.0;
-            for (int t = 0; t < T; ++t) g += basis(t, i) * vs[t * NU + j];
+            for (int t = 0; t < T; ++t) g += basis(t, i) * VSr(t * NU + j);
             gb[q] = g;
         }
     }
