@@ -79,7 +79,9 @@ __host__ __device__ inline CpGenLayout cp_generic_layout(const pdp_policy& pol, 
     return L;
 }
 
-template <class Mdl>
+// MLPK: the policy kind as a template constant - the open-loop instantiation (Lagrange, table: what recmat / warp run) carries none of the layer tables, whose 96 scalar
+// registers spilled into VGPR lanes and cost the recmat drivers' single-trajectory step a third of its time
+template <class Mdl, bool MLPK>
 __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_policy pol, int p, const double* __restrict__ x0, const double* __restrict__ theta, int tb,
                                                               double* __restrict__ loss, double* __restrict__ grad, double* __restrict__ xo, double* __restrict__ uo,
                                                               double* __restrict__ ws, CpGenLayout L) {
@@ -102,7 +104,8 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
     double *mu = lds + L.mu_l, *vv = lds + L.v_l, *pool = lds + L.pool_l;
     const double* thb = theta + (int64_t)b * tb;
     double* gb = grad + (int64_t)b * p;
-    const bool mlp = pol.kind == PDP_POLICY_MLP, table = pol.kind == PDP_POLICY_TABLE;
+    constexpr bool mlp = MLPK;
+    const bool table = pol.kind == PDP_POLICY_TABLE;
     const int nl = mlp ? pol.n_layers : 0, nb = mlp ? 0 : (table ? pol.n_basis : pol.n_pivots);
     const int one = L.sum_in - 2;                                                     // layer-input slots `one`, `one + 1` hold 1.0 (bias factor) and 0.0
     auto sync = [&]() {       // everything the lanes exchange goes through LDS or (wide networks, trajectory, activations, gradient) global memory of this wavefront's own slice
@@ -113,10 +116,11 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
     double pc[Mdl::NPC];
     Mdl::precompute(nullptr, pc);
     // layer tables (uniform): parameter offset, rows, cols, offset of the layer's input in zs, of its delta in ds, of its stored activation
-    int loff[GEN_MAXL], lrows[GEN_MAXL], lcols[GEN_MAXL], zoff[GEN_MAXL], doff[GEN_MAXL], aoff[GEN_MAXL];
+    constexpr int NLT = MLPK ? GEN_MAXL : 1;
+    int loff[NLT], lrows[NLT], lcols[NLT], zoff[NLT], doff[NLT], aoff[NLT];
     {
         int cols = NX, off = 0, zo = 0, dof = 0, ao = 0;
-        for (int k = 0; k < GEN_MAXL; ++k) {
+        for (int k = 0; k < NLT; ++k) {
             loff[k] = off; lcols[k] = cols; lrows[k] = (k < nl) ? pol.sizes[k] : 0; zoff[k] = zo; doff[k] = dof; aoff[k] = ao;
             if (k < nl) { off += lrows[k] * cols + lrows[k]; zo += cols; dof += lrows[k]; if (k + 1 < nl) ao += lrows[k]; cols = lrows[k]; }
         }

@@ -467,9 +467,14 @@ int cp_step_generic(int B, int T, const pdp_policy* pol, int p, const double* x0
     if (L.rows < 1 || (size_t)L.lds_total * sizeof(double) > 160 * 1024) return PDP_E_SIZE;       // (a model whose single Jacobian row exceeds the LDS: not a policy size)
     if (L.ws_per_traj > 0 && (!ws || wsb < (int64_t)B * L.ws_per_traj * (int64_t)sizeof(double))) return PDP_E_ARG;
     const size_t lds = sizeof(double) * (size_t)L.lds_total;
-    (void)hipFuncSetAttribute((const void*)cp_step_generic_kernel<Mdl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     PDP_CLEAR();
-    hipLaunchKernelGGL((cp_step_generic_kernel<Mdl>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, L);
+    if (pol->kind == PDP_POLICY_MLP) {
+        (void)hipFuncSetAttribute((const void*)cp_step_generic_kernel<Mdl, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cp_step_generic_kernel<Mdl, true>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, L);
+    } else {
+        (void)hipFuncSetAttribute((const void*)cp_step_generic_kernel<Mdl, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((cp_step_generic_kernel<Mdl, false>), dim3(B), dim3(64), lds, S(st), B, T, *pol, p, x0, th, tb, loss, grad, x, u, (double*)ws, L);
+    }
     return launched();
 }
 template <class Mdl>
