@@ -195,8 +195,8 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
 /* OCSys.ocSolver (PDP.py:121-220) as the reference poses it: the multiple-shooting NLP
  *     min sum_t c(x_t,u_t) + h(x_T)  over x_1..x_T, u_0..u_{T-1}   s.t.  f(x_t,u_t) - x_{t+1} = 0,  x_0 = ini_state   (PDP.py:131-179)
  * solved from the reference's all-zero initial guess (PDP.py:155,166) by IPOPT's algorithm for the equality-constrained case
- * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search, least-squares initial multipliers;
- * CPU restatement: oracle/ipopt_ms.py).  A persistent pair of wavefronts per trajectory (runner: IPOPT's control flow and the Riccati /
+ * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search with second-order correction, least-squares
+ * initial multipliers; CPU restatement: oracle/ipopt_ms.py).  A persistent pair of wavefronts per trajectory (runner: IPOPT's control flow and the Riccati /
  * forward chains on the MFMA tiles; evaluator: KKT matrices, trial-point residuals, multiplier step with one lane per stage - csrc/pdp_ocsolve2_kernels.h;
  * the one-wavefront kernel of round 2, csrc/pdp_ocsolve_kernels.h, stays behind PDP_MS_VARIANT=1) runs ALL iterations inside one launch: the
  * Newton step is an LQ problem in homogeneous form on the Riccati tiles, trial points are evaluated with one lane per stage; no host round
@@ -215,7 +215,15 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
  * kernel adds the current point to the filter, keeps the controls and replaces the states by their rollout from x0 (constraint violation 0, acceptable to
  * every filter entry - what the filter method requires of a restoration phase; IPOPT's own restoration NLP is not restated), resets the multipliers to the
  * least-squares estimate as IPOPT does after a restoration, and continues; the iteration counts as one.  Not possible at a feasible point or when the rollout
- * overflows: PDP_MS_RESTORATION as before.  opts.flags & PDP_MS_NO_RESTORATION switches it off. */
+ * overflows: PDP_MS_RESTORATION as before.  opts.flags & PDP_MS_NO_RESTORATION switches it off.
+ * Second-order correction (round 5, runner / evaluator kernel only; opts.flags & PDP_MS_WITH_SOC; IPOPT's max_soc = 4, kappa_soc = 0.99).  When the first trial point of
+ * an iteration is rejected and its constraint violation is not below the iterate's, up to four corrected steps (same KKT matrix, constraint block
+ * alpha c(x_k) + c(x_k + alpha d), accumulated) are tried before the step is halved; status gets PDP_MS_SOC where one was taken, and such an iteration shows MINUS its
+ * test step length in the iteration log's alpha column.  Each correction costs a Newton sweep here (IPOPT: a back-substitution).  OFF by default: every stored optimum
+ * is reached either way (cart-pole demo 0 in 35 iterations instead of 45), but on the reference's own cart-pole IRL run (stored trace, first row, demonstration 4 - a
+ * non-convex solve with inertia corrections at most iterations) the iteration WITH the published correction ends in another stationary point (cost 1513.67 after 2490
+ * iterations) where the reference's IPOPT run and the iteration without it end in 623.79: as a model of what the reference's solver returned, the restatement is
+ * better without. */
 #define PDP_MS_WARM 1
 #define PDP_MS_NO_RESTORATION 2   /* opts.flags: return PDP_MS_RESTORATION instead of restoring (the behaviour before round 3) */
 #define PDP_MS_FROM_CONTROLS 8    /* opts.flags, with PDP_MS_WARM (runner / evaluator kernel): start from the controls in u only - x becomes their rollout from x0,
@@ -239,10 +247,12 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
                                      reference's stored rocket IRL run the unguarded prediction of row 1 sends Newton's method to another stationary point */
 #define PDP_MS_GUARD_TRUST 0.02     /* PDP_MS_PREDICT_GUARD: a prediction that changes no state or control by more than this fraction of max(1, |its value|) is kept without the check */
 #define PDP_MS_PREDICT_REJECTED 512 /* status, informational: PDP_MS_PREDICT_GUARD preferred the previous solution to its prediction */
+#define PDP_MS_WITH_SOC 128         /* opts.flags: second-order correction in the line search (see above; off by default) */
+#define PDP_MS_SOC 1024             /* status, informational: at least one iteration accepted a second-order-corrected step */
 typedef struct pdp_oc_ms_opts {
     double tol;
     int max_iter;
-    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT, PDP_MS_PREDICT_PRIMAL, PDP_MS_PREDICT_GUARD */
+    int flags;    /* PDP_MS_WARM, PDP_MS_NO_RESTORATION, PDP_MS_FROM_CONTROLS, PDP_MS_PREDICT, PDP_MS_PREDICT_PRIMAL, PDP_MS_PREDICT_GUARD, PDP_MS_WITH_SOC */
     int log_rows; /* rows per trajectory of the optional iteration log (0 = none) */
     int dtheta_bstride;        /* PDP_MS_PREDICT: dtheta [B][p] (stride p) or shared [p] (stride 0) ... */
     const double* dtheta;

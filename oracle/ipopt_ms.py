@@ -16,8 +16,18 @@ large-scale nonlinear programming", Math. Program. 106 (2006) - specialised to t
     theta_max = 1e-4 / 1e4 x max(1, theta(x0)), filter augmented after every non-f-type step, step halving     (Algorithm A)
   * equality multipliers move with the primal step length, lam+ = lam + alpha dlam; initial multipliers from the least-squares
     estimate, set to zero when its max-norm exceeds 1000                                                         (section 3.6)
-Not restated (never active on the reference's problems, checked on all stored demos and IRL traces): second-order correction,
-watchdog.  Restoration phase: IPOPT's own restoration algorithm is not restated; a step that would enter it (one stored demo: robot arm 3)
+  * OPTIONAL (solve(soc=True); round 5): second-order correction (section 2.4, steps A-5.5 .. A-5.10; max_soc = 4, kappa_soc = 0.99):
+    when the FIRST trial point of an iteration is rejected and its constraint violation is not below the iterate's, the step is
+    corrected by solving the same KKT matrix with the constraint block c_soc = alpha c(x_k) + c(x_k + alpha d) (accumulated over the
+    attempts); the corrected point is tested with the original alpha and directional derivative.  IPOPT has it on by default, and
+    cold solves do take corrected steps (cart-pole demo 0: 22 tried, 7 taken, 35 iterations instead of 45) - rounds 1-4 claimed the
+    opposite.  It is nevertheless OFF by default here, on the evidence of the reference's own data: every stored optimum is reached
+    either way, but cart-pole demonstration 4 at the first row of the stored IRL trace - a non-convex solve, inertia corrections at
+    most iterations - ends WITH the correction as published in another stationary point (cost 1513.67 after 2490 iterations) where
+    the reference's IPOPT run (stored loss_trace[1]) and this restatement without it end in 623.79 (tests/test_oracle_soc.py).  The
+    published algorithm is not all of IPOPT (watchdog, its restoration NLP): as a model of what the reference's solver RETURNED the
+    restatement is better without the correction.
+Not restated: watchdog.  Restoration phase: IPOPT's own restoration algorithm is not restated; a step that would enter it (one stored demo: robot arm 3)
 is answered by the structure-specific feasibility restoration described in `solve` (states <- rollout of the controls), which satisfies what the
 filter method asks of a restoration phase and lands in IPOPT's stored optimum on that demo; `restoration=False` raises there instead.
 
@@ -38,7 +48,7 @@ from .pdp_oracle import _vec
 OPT = dict(s_phi=2.3, s_theta=1.1, delta=1.0, eta_phi=1e-8, gamma_theta=1e-5, gamma_phi=1e-8, theta_min_fact=1e-4, theta_max_fact=1e4,
            first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20,
            perturb_inc_fact_first=100.0, perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0, constr_mult_init_max=1000.0,
-           alpha_red_factor=0.5, alpha_min_frac=0.05)
+           alpha_red_factor=0.5, alpha_min_frac=0.05, max_soc=4, kappa_soc=0.99)
 
 
 def evaluate(oc, xs, us, lam, e):
@@ -68,15 +78,21 @@ def evaluate(oc, xs, us, lam, e):
     return ev
 
 
-def objective_and_violation(oc, xs, us, e):
+def objective_and_violation(oc, xs, us, e, defects=False):
     T = us.shape[0]
     c = np.stack([_vec(oc.dyn_fn(xs[t], us[t], e)) - xs[t + 1] for t in range(T)])
+    if defects:
+        return oc.cost(xs, us, e), float(np.abs(c).sum()), c
     return oc.cost(xs, us, e), float(np.abs(c).sum())
 
 
-def kkt_step(ev, dw, n, m):
-    """Newton step of the KKT system by the stage-wise recursion.  Returns (dx [T+1,n], du [T,m], dlam [T,n], inertia_ok)."""
+def kkt_step(ev, dw, n, m, c=None):
+    """Newton step of the KKT system by the stage-wise recursion.  Returns (dx [T+1,n], du [T,m], dlam [T,n], inertia_ok).
+    c [T, n]: constraint block of the right-hand side instead of the defects of `ev` (the second-order correction)."""
     T = len(ev["F"])
+    if c is not None:
+        ev = dict(ev)
+        ev["c"] = c
     P = ev["hxx"] + dw * np.eye(n)
     W = ev["rdx"][T].copy()
     Ks, ks, Ps, Ws = [None] * T, [None] * T, [None] * (T + 1), [None] * (T + 1)
@@ -120,7 +136,7 @@ def least_squares_multipliers(ev, n, m):
     return dl
 
 
-def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None):
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None, soc=False):
     """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations` and `restorations`.
     log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type).
     restoration: what happens when the line search falls below alpha_min, where IPOPT switches to its feasibility restoration phase.  IPOPT's own
@@ -132,7 +148,9 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     u_init [T, m]: start from these controls and their rollout instead of the reference's all-zero guess (not something the reference does - it is
     the starting point PDP_MS_FROM_CONTROLS gives the kernel, restated here so that path has a checker).
     warm = (state [T+1, n], control [T, m], costate [T, n]): start the iteration AT that point (x_0 replaced by ini_state, no least-squares multiplier estimate) -
-    what PDP_MS_WARM does in the kernel; with the point predict_start below returns, the start of an IRL loop's next solve."""
+    what PDP_MS_WARM does in the kernel; with the point predict_start below returns, the start of an IRL loop's next solve.
+    soc: second-order correction (PDP_MS_WITH_SOC in the kernel; the header says why it is off by default); the log rows carry `soc` = the number of corrections tried in
+    the iteration and `soc_taken`; the result the total `soc_steps`."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
@@ -162,6 +180,7 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     dw_last = 0.0
     it = 0
     n_rest = 0
+    n_soc_total = 0
     for it in range(max_iter + 1):
         f, theta = ev["f"], ev["theta"]
         inf_pr_it, inf_du_it = ev["inf_pr"], ev["inf_du"]
@@ -196,21 +215,49 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
         else:
             amin = o["gamma_theta"]
         amin *= o["alpha_min_frac"]
+        def acceptable(ft, tht, a):
+            """(accepted, f-type) of a trial point with objective ft and violation tht, tested with the step length a (steps A-5.3, A-5.4)"""
+            if not (np.isfinite(ft) and np.isfinite(tht) and tht <= theta_max and all(not (tht >= th_f and ft >= f_f) for th_f, f_f in filt)):
+                return False, False
+            switching = gd < 0.0 and a * (-gd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
+            if theta <= theta_min and switching:
+                ok_ = ft <= f + o["eta_phi"] * a * gd + 10.0 * np.finfo(float).eps * abs(f)
+                return ok_, ok_
+            return (tht <= (1.0 - o["gamma_theta"]) * theta or ft <= f - o["gamma_phi"] * theta), False
+
+        n_soc, soc_taken = 0, False
+        dl_step = dl
         while alpha >= amin:
             xt, ut = xs + alpha * dx, us + alpha * du
-            ft, tht = objective_and_violation(oc, xt, ut, e)
-            in_filter_ok = np.isfinite(ft) and np.isfinite(tht) and tht <= theta_max and \
-                all(not (tht >= th_f and ft >= f_f) for th_f, f_f in filt)
-            if in_filter_ok:
-                switching = gd < 0.0 and alpha * (-gd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
-                if theta <= theta_min and switching:
-                    if ft <= f + o["eta_phi"] * alpha * gd + 10.0 * np.finfo(float).eps * abs(f):
-                        accepted, ftype = True, True
-                elif tht <= (1.0 - o["gamma_theta"]) * theta or ft <= f - o["gamma_phi"] * theta:
-                    accepted = True
+            ft, tht, ct = objective_and_violation(oc, xt, ut, e, defects=True)
+            accepted, ftype = acceptable(ft, tht, alpha)
             if accepted:
                 break
+            if soc and alpha == 1.0 and np.isfinite(ft) and np.isfinite(tht) and tht >= theta:
+                # second-order correction (A-5.5 .. A-5.10): same matrix (same dw), constraint block c_soc; no bounds -> the corrected step is taken in full
+                # (theta_old starts at the violation of the rejected full-step point, as IPOPT's implementation does - IpFilterLSAcceptor::TrySecondOrderCorrection;
+                #  the paper's step A-5.6 writes theta(x_k), which is not larger: the difference can only show in whether a SECOND correction is tried)
+                c_soc, a_soc, th_old = ev["c"].copy(), alpha, tht
+                while n_soc < o["max_soc"]:
+                    c_soc = a_soc * c_soc + ct
+                    dxs, dus, dls, ok = kkt_step(ev, dw, n, m, c=c_soc)
+                    if not ok or not (np.all(np.isfinite(dxs)) and np.all(np.isfinite(dus)) and np.all(np.isfinite(dls))):
+                        break
+                    n_soc += 1
+                    a_soc = 1.0
+                    xt2, ut2 = xs + a_soc * dxs, us + a_soc * dus
+                    ft2, tht2, ct2 = objective_and_violation(oc, xt2, ut2, e, defects=True)
+                    accepted, ftype = acceptable(ft2, tht2, alpha)
+                    if accepted:
+                        xt, ut, dl_step, soc_taken = xt2, ut2, dls, True
+                        break
+                    if not (np.isfinite(ft2) and np.isfinite(tht2)) or tht2 > o["kappa_soc"] * th_old:
+                        break
+                    th_old, ct = tht2, ct2
+                if accepted:
+                    break
             alpha *= o["alpha_red_factor"]
+        n_soc_total += n_soc
         if not accepted:
             if not restoration:
                 raise RuntimeError("ipopt_ms: line search would enter the restoration phase (not restated)")
@@ -229,16 +276,16 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
             ev = evaluate(oc, xs, us, lam, e)
             n_rest += 1
             if log is not None:
-                log.append(dict(it=it, f=f, inf_pr=inf_pr_it, inf_du=inf_du_it, dw=dw, alpha=0.0, ftype=False, gd=gd, theta=theta, restoration=True))
+                log.append(dict(it=it, f=f, inf_pr=inf_pr_it, inf_du=inf_du_it, dw=dw, alpha=0.0, ftype=False, gd=gd, theta=theta, restoration=True, soc=n_soc, soc_taken=False))
             continue
         if not ftype:
             filt.append(((1.0 - o["gamma_theta"]) * theta, f - o["gamma_phi"] * theta))
         if log is not None:
             log.append(dict(it=it, f=f, inf_pr=ev["inf_pr"], inf_du=ev["inf_du"], dw=dw, alpha=alpha, ftype=ftype, gd=gd, theta=theta,
-                            dx=dx, du=du, dlam=dl))
-        xs, us, lam = xt, ut, lam + alpha * dl
+                            dx=dx, du=du, dlam=dl, soc=n_soc, soc_taken=soc_taken))
+        xs, us, lam = xt, ut, lam + alpha * dl_step             # (a corrected step is a full one: alpha = 1 there)
         ev = evaluate(oc, xs, us, lam, e)
-    return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it, "restorations": n_rest,
+    return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it, "restorations": n_rest, "soc_steps": n_soc_total,
             "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"]}
 
 

@@ -100,7 +100,8 @@ struct Ms2Layout {
     // line: at B = 1024 (four trajectories per CU) the trial pass alone kept a CU's address unit busy for ~40 k cycles (profiles/r03_ms2_phase_timing_v1.txt).
     // One group = [x-like (NX rows) | u-like (NU rows) | lambda-like (NX rows)] = (2 NX + NU) * TS doubles:
     //     point set 0 | point set 1 (the iterate is in one, the trial point goes to the other) | step (dx | du | dlam) |
-    //     residual set 0 | residual set 1 (grad_x L | grad_u L | defect c)
+    //     residual set 0 | residual set 1 (grad_x L | grad_u L | defect c) |
+    //     second-order correction: its constraint block c_soc (the x-like rows) | the plain step, kept while corrected steps are tried
     // followed by the gains, (P, W) and the filter.  The API arrays are read once (warm start) and written once (the result).
     // PDP_MS_PREDICT inside the kernel: staging block of the sensitivity rows (64 rows of NP, or 64 / NX stages of the Riccati record) + dx of every node, in the pool
     // (third candidate: 64 / NX stages of the packed fp32 record X | U | tri(P) | W plus the block's dx - with many controls and few states, e.g. n = 2, m = 3, the U part
@@ -111,7 +112,7 @@ struct Ms2Layout {
     __host__ __device__ static constexpr bool predict_fits(int T) { return (int64_t)(T + 1) * NX + PRED_STG <= 2 * BUF; }
     __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
-        return 5 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
+        return 7 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
     }
 };
 
@@ -124,12 +125,15 @@ __host__ __device__ constexpr bool ms2_ok() {
 
 // mailbox slots (ints) and result slots (doubles behind them)
 enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9,
-       MS2_PDONE = 10 };       // PDONE: the runner's (primal) half of a line-search trial is in memory
+       MS2_PDONE = 10,         // PDONE: the runner's (primal) half of a line-search trial is in memory
+       MS2_CSRC = 11,          // SWEEP: 1 = the defect column of the LQ problem comes from the c_soc array (second-order correction) instead of the residual set
+       MS2_SOCM = 12, MS2_SOCN = 13 };      // the runner's own: a correction is under way / corrected points tried in this iteration (see the line search)
 // SWEEP: chunks of the iterate in set CUR.  TRIAL: residuals of CUR + alpha step -> set DST.  TRIAL_SWEEP: the same trial, then - speculating that the
 // runner accepts the point - straight on with the sweep of set DST (the runner aborts it otherwise)
 // RESTORE: the states of set CUR replaced by the rollout of its controls, its multipliers by zero, then the residuals of that point (as TRIAL with alpha = 0)
 enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_TRIAL_SWEEP = 3, MS2_CMD_RESTORE = 4 };
-enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, MS2_L = 6, MS2_LC = 7, MS2_FIN = 8 };
+enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, MS2_L = 6, MS2_LC = 7, MS2_FIN = 8,
+       MS2_S_GD = 9, MS2_S_AMIN = 10, MS2_S_THOLD = 11 };      // the line search's state while the sweep of a correction runs (slots 12 .. 19: timing builds)
 
 // Mailbox values come out of LDS in vector registers although every lane reads the same word: said explicitly (v_readfirstlane), or every pointer and
 // branch derived from them would be treated as divergent - 64-bit per-lane addresses for each of the trial pass's ~100 loads, masked branches in the
@@ -226,7 +230,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     auto Pt = [&](int k) { return w0 + k * GRP; };           // point sets 0 / 1: x (t, i) at [i TS + t], u at [OU + i TS + t], lambda at [OL + i TS + t]
     double* stp = w0 + 2 * GRP;                              // step: dx | du | dlam, same addressing
     auto Rs = [&](int k) { return w0 + (3 + k) * GRP; };     // residual sets 0 / 1: grad_x L (T + 1 stages) | grad_u L | defect c
-    double* gw = w0 + 5 * GRP;                               // gains, T x GSZ
+    double* csoc = w0 + 5 * GRP;                             // second-order correction: c_soc (t, i) at [i TS + t]
+    double* stpb = w0 + 6 * GRP;                             //                          the plain step while corrected ones are tried
+    double* gw = w0 + 7 * GRP;                               // gains, T x GSZ
     double* pw = gw + (int64_t)T * GSZ;                      // P_{t+1}, W_{t+1}, T x PWSZ
     double* fth = pw + (int64_t)T * PWSZ;                    // filter: theta entries (at most one per iteration) ...
     double* fph = fth + (op.max_iter + 1);                   //         ... and phi entries
@@ -559,8 +565,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #define MS2_T1(k)
 #endif
         // commands: parameters first, then the sequence number with release semantics (LDS writes and global stores above are visible to the evaluator)
+        int issue_csrc = 0;                      // (1 around the SWEEP of a second-order correction)
         auto issue = [&](int type, double alpha, int cur, int dst) {
-            if (lane == 0) { ctl[MS2_TYPE] = type; ctl[MS2_CUR] = cur; ctl[MS2_DST] = dst; res[MS2_ALPHA] = alpha; ctl[MS2_PROD] = 0; ctl[MS2_CONS] = 0; }
+            if (lane == 0) { ctl[MS2_TYPE] = type; ctl[MS2_CUR] = cur; ctl[MS2_DST] = dst; ctl[MS2_CSRC] = issue_csrc; res[MS2_ALPHA] = alpha; ctl[MS2_PROD] = 0; ctl[MS2_CONS] = 0; }
             ++seq;
             f3_signal(ctl + MS2_SEQ, seq);
         };
@@ -924,9 +931,22 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 st |= PDP_MS_PREDICT_REJECTED;
             }
         }
+        // Second-order correction (Waechter & Biegler 2006, section 2.4; IPOPT's defaults max_soc = 4, kappa_soc = 0.99): when the FIRST trial point of an iteration
+        // (alpha = 1: there are no bounds) is rejected and its constraint violation is not below the iterate's, the step is corrected by solving the SAME KKT matrix
+        // with the constraint block c_soc = alpha c(x_k) + c(x_k + alpha d), accumulated over up to four attempts while each reduces theta to 99 % of the attempt
+        // before; a corrected point is tested with the ORIGINAL alpha and directional derivative.  IPOPT re-uses its factorisation for that; here the matrices are
+        // not kept (the sweep stores gains and P only), so a correction is one more SWEEP of the iterate whose defect column the evaluator takes from `csoc`
+        // (MS2_CSRC) - a full Newton sweep for what is a back-substitution in IPOPT, on a path that only cold solves far from their optimum take.  The plain
+        // step waits in `stpb` and comes back when the corrections fail.  oracle/ipopt_ms.py: solve(soc=True) is the same algorithm.  Off unless PDP_MS_WITH_SOC
+        // (include/pdp_hip.h says why).
+        // What the line search must remember across the sweep of a correction (directional derivative, alpha_min, theta of the attempt before, the two counters) waits
+        // in the mailbox, not in registers: held live across the sweeps, those few values were exactly what the 256-register instantiation then spilled.
+        const bool soc_on = (op.flags & PDP_MS_WITH_SOC) != 0;
         for (;;) {
             if (dead) break;
-            if (phase == 1 && dw == 0.0) {              // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
+            const int soc_sweep = uni(ctl[MS2_SOCM]);   // this pass of the loop computes a correction of the step, not a step
+            bool soc_fail = false;
+            if (phase == 1 && dw == 0.0 && !soc_sweep) { // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
                 bool stop_ = false;
                 if (!finite) { st |= PDP_STATUS_NONFINITE; stop_ = true; }
                 else {
@@ -936,7 +956,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 }
                 if (stop_) { if (pending) abort_sweep(); break; }
             }
-            if (!pending) issue(MS2_CMD_SWEEP, 0.0, cur, cur);
+            if (!pending) { issue_csrc = soc_sweep ? 1 : 0; issue(MS2_CMD_SWEEP, 0.0, cur, cur); issue_csrc = 0; }
             pending = false;
             const bool pd = backward(hs, dw);
             if (dead) break;
@@ -951,6 +971,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if (pd) { abort_sweep(); if (dead) break; }
                     phase = 1; hs = 1.0; dw = 0.0; continue;
                 }
+            } else if (soc_sweep) {
+                soc_fail = !(pd && PWfinite);           // (the matrix of a step that has just been accepted by the inertia test: cannot happen short of a non-finite c_soc)
             } else {
                 if (!PWfinite) { st |= PDP_STATUS_NONFINITE; break; }
                 if (!pd) {                              // Algorithm IC (defaults: 1e-4 first, x100 / x8 up, /3 down, 1e20 max)
@@ -961,11 +983,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 }
                 if (dw > 0.0) dw_last = dw;
             }
-            const double gd = forward(hs);
-            MS2_T0();
-            wait_done();                                // the evaluator is through with the sweep (forms other than the homogeneous one: it has finished dlam)
-            MS2_T1(4);
-            if (dead) break;
+            double gd = 0.0;
+            if (!soc_fail) {
+                gd = forward(hs);
+                MS2_T0();
+                wait_done();                            // the evaluator is through with the sweep (forms other than the homogeneous one: it has finished dlam)
+                MS2_T1(4);
+                if (dead) break;
+            }
             if (phase == 0) {
                 double lm = 0.0;
                 bool fin = true;
@@ -984,18 +1009,34 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             }
             const double f = f_cur, theta = th_cur;
             // backtracking filter line search (Algorithm A): alpha_min below which IPOPT would enter the restoration phase
-            double amin = 1e-5;
-            if (gd < 0.0) {
-                amin = fmin(1e-5, 1e-8 * theta / (-gd));
-                if (theta <= theta_min) amin = fmin(amin, pow(theta, 1.1) / pow(-gd, 2.3));
+            int soc_mode = soc_sweep, soc_n = 0;
+            double alpha = 1.0, amin = 1e-5, soc_th_old = 0.0;
+            auto step_back = [&]() {                    // the corrections failed: the plain step again, halved
+                __threadfence_block();
+                for (int q = lane; q < (int)GRP; q += 64) stp[q] = stpb[q];
+                __threadfence_block();
+                soc_mode = 0;
+                if (lane == 0) ctl[MS2_SOCM] = 0;
+                alpha *= 0.5;
+            };
+            if (!soc_mode) {
+                if (gd < 0.0) {
+                    amin = fmin(1e-5, 1e-8 * theta / (-gd));
+                    if (theta <= theta_min) amin = fmin(amin, pow(theta, 1.1) / pow(-gd, 2.3));
+                }
+                amin *= 0.05;
+            } else {                                    // (a corrected step is judged with the directional derivative of the plain one; alpha = 1: corrections start there)
+                wave_lds_sync();
+                gd = uni(res[MS2_S_GD]); amin = uni(res[MS2_S_AMIN]); soc_th_old = uni(res[MS2_S_THOLD]); soc_n = uni(ctl[MS2_SOCN]);
+                if (soc_fail) step_back();
             }
-            amin *= 0.05;
-            double alpha = 1.0, ft = 0.0, tht = 0.0;
-            bool accepted = false, ftype = false, fin_p = true;
-            while (alpha >= amin && alpha > 1e-300) {      // (the second bound only guards against amin = 0)
-                issue(MS2_CMD_TRIAL_SWEEP, alpha, cur, cur ^ 1);
+            double ft = 0.0, tht = 0.0;
+            bool accepted = false, ftype = false, fin_p = true, to_soc = false;
+            while (soc_mode || (alpha >= amin && alpha > 1e-300)) {      // (the second bound only guards against amin = 0)
+                const double a_try = soc_mode ? 1.0 : alpha;           // (a corrected step is taken in full: no bounds, no fraction-to-the-boundary rule)
+                issue(MS2_CMD_TRIAL_SWEEP, a_try, cur, cur ^ 1);
                 if constexpr (SPLIT) {
-                    trial_pass(PartPrimal{}, alpha, cur, cur ^ 1); // this wave's half: (theta, phi) of the trial point - all the filter asks for
+                    trial_pass(PartPrimal{}, a_try, cur, cur ^ 1); // this wave's half: (theta, phi) of the trial point - all the filter asks for
                     fin_p = fin_all;
                     f3_signal(ctl + MS2_PDONE, seq);               // release: trial (x, u) and defects are in memory
                     ft = a_f; tht = a_th;
@@ -1020,15 +1061,44 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if (accepted) break;
                 abort_sweep();                          // (the evaluator went on with the sweep of the rejected point)
                 if (dead) break;
-                alpha *= 0.5;
+                const bool fin_t = fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308;
+                const double* __restrict__ ctr = Rs(cur ^ 1) + OL;      // defects of the rejected trial point
+                if (!soc_mode) {
+                    if (soc_on && alpha == 1.0 && fin_t && tht >= theta) {      // A-5.5: first trial point, no progress towards feasibility
+                        const double* __restrict__ cc_ = Rs(cur) + OL;
+                        __threadfence_block();
+                        for (int q = lane; q < (int)GRP; q += 64) stpb[q] = stp[q];
+                        for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) csoc[q] = fma(alpha, cc_[q], ctr[q]);
+                        __threadfence_block();
+                        if (lane == 0) { ctl[MS2_SOCM] = 1; ctl[MS2_SOCN] = 0; res[MS2_S_GD] = gd; res[MS2_S_AMIN] = amin; res[MS2_S_THOLD] = tht; }
+                        to_soc = true;
+                        break;
+                    }
+                    alpha *= 0.5;
+                } else {
+                    ++soc_n;
+                    if (soc_n < 4 && fin_t && tht <= 0.99 * soc_th_old) {      // A-5.9, A-5.10: the next correction accumulates on this one
+                        __threadfence_block();
+                        for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) csoc[q] = fma(1.0, csoc[q], ctr[q]);
+                        __threadfence_block();
+                        if (lane == 0) { ctl[MS2_SOCN] = soc_n; res[MS2_S_THOLD] = tht; }
+                        to_soc = true;
+                        break;
+                    }
+                    step_back();
+                }
             }
             if (dead) break;
+            if (to_soc) continue;                       // (nothing pending: the sweep of the correction is asked for at the top)
+            const bool soc_taken = accepted && soc_mode != 0;
+            if (soc_mode && lane == 0) ctl[MS2_SOCM] = 0;
+            if (soc_taken) st |= PDP_MS_SOC;
             pending = accepted;
             MS2_T1(5);
 #ifndef PDP_MS_TIMING
             if (iter_log && it < op.log_rows && lane == 0) {
                 double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
-                row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? alpha : 0.0; row[6] = gd; row[7] = theta;
+                row[0] = it; row[1] = f; row[2] = inf_pr; row[3] = inf_du; row[4] = dw; row[5] = accepted ? (soc_taken ? -alpha : alpha) : 0.0; row[6] = gd; row[7] = theta;      // (a corrected step: minus its test step length)
             }
 #endif
             if (!accepted) {                            // (every rejected trial's sweep has been aborted above)
@@ -1244,7 +1314,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             if (!ms2_wait_ge(ctl + MS2_SEQ, last + 1, ctl)) break;
             last = ms2_load(ctl + MS2_SEQ);
             wave_lds_sync();
-            const int type = uni(ctl[MS2_TYPE]), cur = uni(ctl[MS2_CUR]), dst = uni(ctl[MS2_DST]);
+            const int type = uni(ctl[MS2_TYPE]), cur = uni(ctl[MS2_CUR]), dst = uni(ctl[MS2_DST]), csrc = uni(ctl[MS2_CSRC]);
             const double alpha = uni(res[MS2_ALPHA]);
             if (type == MS2_CMD_EXIT) break;
             MS2_E0();
@@ -1266,6 +1336,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const int sw = type == MS2_CMD_SWEEP ? cur : dst;          // the set the sweep linearises at
                 const double* __restrict__ ps = Pt(sw);
                 const double* __restrict__ rd = Rs(sw);
+                const double* __restrict__ cdef = (type == MS2_CMD_SWEEP && csrc) ? csoc : rd + OL;       // defects of the point, or the constraint block of a second-order correction
                 bool aborted = false;
                 auto stop = [&]() { aborted = aborted || ms2_load(ctl + MS2_ABORT) == last; return aborted || dead; };
                 // terminal stage: hxx(x_T) entries and the terminal gradient
@@ -1300,7 +1371,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         // (every load of the stage first, then the LDS stores: interleaved, each store waits for its loads - a trip to memory per component)
                         double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); lc[i] = sm_ld(ps + OL + i * TS, o8); cc[i] = sm_ld(rd + OL + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8); }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); lc[i] = sm_ld(ps + OL + i * TS, o8); cc[i] = sm_ld(cdef + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8); }
 #pragma unroll
                         for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
                         asm volatile("" ::: "memory");
@@ -1338,7 +1409,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         double* row = pool + (g & 1) * L::BUF + lane * FS;
                         double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); cc[i] = sm_ld(rd + OL + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8 + 8u); }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); cc[i] = sm_ld(cdef + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8 + 8u); }
 #pragma unroll
                         for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
                         asm volatile("" ::: "memory");

@@ -139,13 +139,15 @@ def solve_batch(oc, ini_state, horizon, auxvar_value, u_init=None, tol=1e-9, max
     return sol
 
 
-def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, print_level=0, restoration=True, log_rows=0):
+def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, print_level=0, restoration=True, log_rows=0, soc=False):
     """The multiple-shooting NLP of OCSys.ocSolver (PDP.py:131-182) iterated the way IPOPT does - the algorithm of pdp_oc_solve_ms_batched and of its CPU restatement
     oracle/ipopt_ms.py - for problems BEYOND that kernel's tiles (16 < n <= 32 or 4 < m <= 8), kernel by kernel: residuals of the NLP (pdp_oc_ms_residuals_batched),
     KKT matrices (pdp_oc_auxsys_batched), the Newton step as an LQ problem with one affine column on the generic LQR kernel (pdp_lqr_solve_batched, whose status
     reports whether every Quu was positive definite = the inertia test), the restoration by rollout (pdp_oc_rollout_batched).  Only IPOPT's bookkeeping - inertia
     correction schedule, filter, step lengths, per sample - is tensor arithmetic here.  Several launches per iteration: a route for sizes the fast kernel does not
     take (before round 3 these problems were solved by single shooting, i.e. a different iterate path), not a fast path.
+    soc=True: IPOPT's second-order correction (include/pdp_hip.h, off by default as in the kernel; oracle/ipopt_ms.py) - per sample, up to four corrected steps when the first trial point is rejected
+    without progress towards feasibility; each is one more solve of the LQ problem with the accumulated constraint block.
     Returns the dict of ModelLib.oc_solve_ms (status bits PDP_MS_*; log [B, log_rows, 8] with log_rows > 0)."""
     torch = runtime.torch_cuda()
     mdl = oc.model()
@@ -195,7 +197,7 @@ def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_
     fth, fph, nf = torch.zeros((B, K), **f64), torch.zeros((B, K), **f64), torch.zeros((B,), dtype=torch.int64, device="cuda")
     kidx = torch.arange(K, device="cuda").view(1, K)
     conv, status = torch.zeros((B,), dtype=torch.bool, device="cuda"), torch.zeros((B,), dtype=torch.int32, device="cuda")
-    restored = torch.zeros_like(conv)
+    restored, corrected = torch.zeros_like(conv), torch.zeros_like(conv)
     iters, dw_last = torch.zeros((B,), dtype=torch.int32, device="cuda"), torch.zeros((B,), **f64)
     log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
     rkeys = ("c", "rx", "ru", "cost", "f", "theta", "inf_pr", "inf_du")
@@ -249,30 +251,63 @@ def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_
         amin = torch.where(neg, torch.minimum(torch.full_like(gd, G_TH), G_PH * theta / ngd), torch.full_like(gd, G_TH))
         amin = torch.where(neg & (theta <= theta_min), torch.minimum(amin, theta ** 1.1 / ngd ** 2.3), amin) * 0.05
         alpha, searching = torch.ones((B,), **f64), active.clone()
-        accepted, ftype = torch.zeros_like(conv), torch.zeros_like(conv)
+        accepted, ftype, soc_taken = torch.zeros_like(conv), torch.zeros_like(conv), torch.zeros_like(conv)
         xn, un, ln = x.clone(), u.clone(), lam.clone()
         rn = {k: r[k].clone() for k in rkeys}
-        while bool(searching.any()):
-            a3 = alpha.view(B, 1, 1)
-            xt, ut, lt = x + a3 * dx, u + a3 * du, lam + a3 * dl
-            rt = resid(xt, ut, lt)
+
+        def acceptable(rt, who):
+            """trial points rt of the samples `who`, tested with the step length alpha (steps A-5.3 / A-5.4): (accepted, f-type)"""
             ft, tht = rt["f"], rt["theta"]
             dominated = ((kidx < nf.view(B, 1)) & (tht.view(B, 1) >= fth) & (ft.view(B, 1) >= fph)).any(dim=1)
             okf = torch.isfinite(ft) & torch.isfinite(tht) & (tht <= theta_max) & ~dominated
             switching = neg & (alpha * ngd ** 2.3 > theta ** 1.1)
             c1 = (theta <= theta_min) & switching
-            acc = searching & okf & torch.where(c1, ft <= f + 1e-8 * alpha * gd + 10.0 * EPS * f.abs(), (tht <= (1.0 - G_TH) * theta) | (ft <= f - G_PH * theta))
+            acc = who & okf & torch.where(c1, ft <= f + 1e-8 * alpha * gd + 10.0 * EPS * f.abs(), (tht <= (1.0 - G_TH) * theta) | (ft <= f - G_PH * theta))
+            return acc, acc & c1
+
+        def take(xt, ut, lt, rt, acc):
             put(xn, xt, acc); put(un, ut, acc); put(ln, lt, acc)
             for k in rkeys:
                 put(rn[k], rt[k], acc)
-            ftype, accepted = ftype | (acc & c1), accepted | acc
+
+        first_trial = True
+        while bool(searching.any()):
+            a3 = alpha.view(B, 1, 1)
+            xt, ut, lt = x + a3 * dx, u + a3 * du, lam + a3 * dl
+            rt = resid(xt, ut, lt)
+            acc, ft_ = acceptable(rt, searching)
+            take(xt, ut, lt, rt, acc)
+            ftype, accepted = ftype | ft_, accepted | acc
             searching = searching & ~acc
+            if first_trial and soc:
+                # second-order correction: same matrix (same dw), constraint block c_soc = alpha c(x_k) + c(x_k + alpha d), accumulated; alpha = 1 here
+                live = searching & torch.isfinite(rt["f"]) & torch.isfinite(rt["theta"]) & (rt["theta"] >= theta)
+                c_soc, ct, th_old = r["c"].clone(), rt["c"], rt["theta"].clone()
+                for _ in range(4):
+                    if not bool(live.any()):
+                        break
+                    c_soc = torch.where(live.view(B, 1, 1), c_soc + ct, c_soc)
+                    rs = dict(r)
+                    rs["c"] = c_soc
+                    X, U, L, ok = kkt(A, rs, dw)
+                    live = live & ok & torch.isfinite(X).all(dim=(1, 2)) & torch.isfinite(U).all(dim=(1, 2)) & torch.isfinite(L).all(dim=(1, 2))
+                    xt2, ut2, lt2 = x + X, u + U, lam + L
+                    rt2 = resid(xt2, ut2, lt2)
+                    acc2, ft2_ = acceptable(rt2, live)
+                    take(xt2, ut2, lt2, rt2, acc2)
+                    ftype, accepted, soc_taken = ftype | ft2_, accepted | acc2, soc_taken | acc2
+                    searching = searching & ~acc2
+                    live = live & ~acc2 & torch.isfinite(rt2["f"]) & torch.isfinite(rt2["theta"]) & (rt2["theta"] <= 0.99 * th_old)
+                    th_old, ct = torch.where(live, rt2["theta"], th_old), rt2["c"]
+            first_trial = False
             alpha = torch.where(searching, alpha * 0.5, alpha)
             searching = searching & (alpha >= amin) & (alpha > 1e-300)
         if log is not None and it < log_rows:
-            row = torch.stack([torch.full_like(f, float(it)), f, r["inf_pr"], r["inf_du"], dw, torch.where(accepted, alpha, torch.zeros_like(alpha)), gd, theta], dim=1)
+            row = torch.stack([torch.full_like(f, float(it)), f, r["inf_pr"], r["inf_du"], dw,
+                               torch.where(accepted, torch.where(soc_taken, -alpha, alpha), torch.zeros_like(alpha)), gd, theta], dim=1)
             log[:, it] = torch.where(active.view(B, 1), row, log[:, it])
         failed = active & ~accepted
+        corrected = corrected | soc_taken
         filter_add(accepted & ~ftype, theta, f)
         x, u, lam, r = xn, un, ln, rn
         if bool(failed.any()):
@@ -297,6 +332,7 @@ def solve_batch_ms_generic(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_
         if print_level > 0:
             print("  ms-generic iteration %3d: %d / %d converged" % (it, int(conv.sum()), B))
     status = torch.where(restored, status | 128, status)                                                             # PDP_MS_RESTORED (informational)
+    status = torch.where(corrected, status | 1024, status)                                                           # PDP_MS_SOC (informational)
     out = {"state": x, "control": u, "costate": lam, "cost": r["f"], "resid": torch.stack([r["inf_pr"], r["inf_du"]], dim=1), "converged": conv,
            "iterations": iters, "status": status}
     if log is not None:

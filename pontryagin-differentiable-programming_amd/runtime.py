@@ -380,7 +380,8 @@ class ModelLib:
             out["gains"] = gains
         return out
 
-    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False, predict=None):
+    def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False, predict=None,
+                    soc=False):
         """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
         (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
         from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
@@ -391,6 +392,7 @@ class ModelLib:
         applied while the point is loaded - no extra launch; with consume_warm the previous solution's tensors are overwritten by the new one, as an IRL loop wants it).
         predict["guard"] (default True, PDP_MS_PREDICT_GUARD): the previous solution is evaluated beside its prediction and the solve starts from whichever has the smaller
         scaled KKT error (a first-order prediction across a large parameter step can be worse than no prediction: status & 512 marks the trajectories where it was dropped).
+        soc=True (PDP_MS_WITH_SOC): IPOPT's second-order correction in the line search (status & 1024: a corrected step was taken; include/pdp_hip.h says why it is off by default).
         Returns dict(state, control, costate, cost,
         resid [B,2], converged (bool), iterations [B], status [B][, gains])."""
         torch = torch_cuda()
@@ -419,7 +421,7 @@ class ModelLib:
         nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T, int(max_iter))
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
-        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0), int(log_rows))
+        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0) | (128 if soc else 0), int(log_rows))
         keep = None
         if predict is not None:
             assert warm is not None, "predict needs the previous solution as the warm point"
@@ -445,7 +447,7 @@ class ModelLib:
         if want_gains:
             out["gains"] = gains
         if log is not None:
-            out["log"] = log            # [B, log_rows, 8]: iteration, objective, inf_pr, inf_du, dw, alpha, grad(phi)'d, theta
+            out["log"] = log            # [B, log_rows, 8]: iteration, objective, inf_pr, inf_du, dw, alpha (minus alpha: a second-order-corrected step), grad(phi)'d, theta
         return out
 
     def oc_costate(self, x, u, theta):

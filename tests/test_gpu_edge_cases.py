@@ -384,19 +384,34 @@ def test_multiple_shooting_route_for_20_states_follows_the_oracle():
         rng = np.random.default_rng(5)
         x0 = (scale * rng.standard_normal((B, 2 * nm)))[:2 if scale == 5.0 else B]
         out = ocsolver.solve_batch_ms_generic(oc, x0, T, th, tol=1e-10, log_rows=40)
-        assert bool(out["converged"].all()) and int(out["status"].sum()) == 0
+        assert bool(out["converged"].all()) and int((out["status"] & ~1024).sum()) == 0            # (1024: PDP_MS_SOC, informational)
         for b in range(x0.shape[0]):
             log = []
             ref = ipopt_ms.solve(ref_oc, x0[b], T, th, tol=1e-10, log=log)
             assert int(out["iterations"][b]) == ref["iterations"] == len(log)
             kl = npy(out["log"])[b]
             for r_, l in zip(kl, log):
-                assert r_[5] == l["alpha"] and abs(r_[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (b, l["it"], r_[4], r_[5], l["dw"], l["alpha"])
+                assert r_[5] == (-l["alpha"] if l["soc_taken"] else l["alpha"]) and abs(r_[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (b, l["it"], r_[4], r_[5], l["dw"], l["alpha"])
                 assert abs(r_[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r_[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
                 seen_dw, seen_alpha = seen_dw or l["dw"] > 0.0, seen_alpha or l["alpha"] < 1.0
             for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
                 assert np.abs(npy(out[k])[b] - ref[kr]).max() <= 1e-8 * max(1.0, np.abs(ref[kr]).max())
     assert seen_dw and seen_alpha
+    # the second-order correction on this route (soc=True, off by default like PDP_MS_WITH_SOC in the solver kernel): per-sample masks - the two far initial states of (a)
+    # try 7 and 4 corrections and take one each, at different iterations - row by row the restatement's with the same switch; 9 and 8 iterations instead of 13 and 9
+    scale, T, th = 5.0, 30, np.array([2.0, 0.3, 1.0, 0.5, 0.2, 3.0])
+    x0 = (scale * np.random.default_rng(5).standard_normal((B, 2 * nm)))[:2]
+    out = ocsolver.solve_batch_ms_generic(oc, x0, T, th, tol=1e-10, log_rows=40, soc=True)
+    assert bool(out["converged"].all()) and (npy(out["status"]) == 1024).all() and (npy(out["iterations"]) == [9, 8]).all()
+    for b in range(2):
+        log = []
+        ref = ipopt_ms.solve(ref_oc, x0[b], T, th, tol=1e-10, log=log, soc=True)
+        assert int(out["iterations"][b]) == ref["iterations"] == len(log) and ref["soc_steps"] == (7, 4)[b] and sum(1 for l in log if l["soc_taken"]) == 1
+        for r_, l in zip(npy(out["log"])[b], log):
+            assert r_[5] == (-l["alpha"] if l["soc_taken"] else l["alpha"]) and abs(r_[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (b, l["it"], r_[4], r_[5], l["dw"], l["alpha"])
+            assert abs(r_[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r_[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
+        for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
+            assert np.abs(npy(out[k])[b] - ref[kr]).max() <= 1e-8 * max(1.0, np.abs(ref[kr]).max())
     # the class surface takes this route for such sizes (and reports it as the multiple-shooting method)
     sol = oc.ocSolver_batch(x0, T, th)
     assert bool(sol["converged"].all()) and bool(sol["method_ms"].all())

@@ -125,11 +125,14 @@ def test_oc_solve_entry_point_returns_a_kkt_point():
     assert bool((J_cl <= J_ol + 1e-12).all())
 
 
-@pytest.mark.parametrize("name", ["pendulum", "rocket", "quadrotor"])
-def test_ms_kernel_follows_the_oracle_iteration_by_iteration(golden_dir, name):
-    """pdp_oc_solve_ms_batched against oracle/ipopt_ms.py (the CPU restatement of IPOPT's algorithm on the reference's NLP) on the
-    first stored demo: same number of iterations, same inertia corrections and step lengths at every iteration, objective /
-    infeasibility columns of the iteration log equal to rounding, same solution."""
+def _alpha_col(l):
+    """the iteration log's alpha column: minus the test step length where a second-order-corrected step was taken (include/pdp_hip.h)"""
+    return -l["alpha"] if l.get("soc_taken") else l["alpha"]
+
+
+def _follows(golden_dir, name, demo, soc, rows=None):
+    """rows: compare only the first `rows` iterations (a non-convex solve amplifies rounding differences: the cart-pole cold solves part from the restatement's digits
+    after a dozen iterations - f agrees to 1e-10 at iteration 11, 1e-9 at 12, ... - and from its decisions later; both end in the stored optimum)"""
     from oracle import ipopt_ms, models, pdp_oracle as po
     from pdp_amd import zoo
     d = load(golden_dir, "demos_%s.npz" % name)
@@ -137,21 +140,74 @@ def test_ms_kernel_follows_the_oracle_iteration_by_iteration(golden_dir, name):
     oc = po.make_oc(models.REGISTRY[name](**st["kwargs"]), st["dt"])
     T = d["control"].shape[1]
     log = []
-    ref = ipopt_ms.solve(oc, d["state"][0, 0], T, d["true_parameter"], log=log)
+    ref = ipopt_ms.solve(oc, d["state"][demo, 0], T, d["true_parameter"], log=log, soc=soc)
     mdl = zoo.get(name, "irl")
-    sol = mdl.oc_solve_ms(d["state"][:1, 0], d["true_parameter"], T, tol=1e-10, log_rows=len(log) + 4)
-    assert bool(sol["converged"][0]) and int(sol["status"][0]) == 0
-    assert int(sol["iterations"][0]) == ref["iterations"] == len(log)
-    kl = sol["log"][0].cpu().numpy()
-    for r, l in zip(kl, log):
-        assert r[5] == l["alpha"], (name, l["it"], r[5], l["alpha"])
+    x0 = np.repeat(d["state"][demo:demo + 1, 0], 3, axis=0)                  # (a few copies: the last one is compared)
+    sol = mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10, log_rows=len(log) + 4, soc=soc)
+    taken = sum(1 for l in log if l["soc_taken"])
+    assert bool(sol["converged"].all()) and (sol["status"].cpu().numpy() == (1024 if taken else 0)).all()
+    assert ref["iterations"] == len(log) and (rows is not None or (sol["iterations"].cpu().numpy() == ref["iterations"]).all())
+    kl = sol["log"][2].cpu().numpy()
+    for r, l in list(zip(kl, log))[:rows]:
+        assert r[5] == _alpha_col(l), (name, l["it"], r[5], l["alpha"], l["soc_taken"])
         assert abs(r[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"])
         assert abs(r[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"]))
         assert abs(r[7] - l["theta"]) <= 1e-9 * max(1.0, l["theta"]) and abs(r[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
     sc = lambda a: max(1.0, np.abs(a).max())
-    assert np.abs(sol["state"][0].cpu().numpy() - ref["state_traj_opt"]).max() <= 1e-9 * sc(ref["state_traj_opt"])
-    assert np.abs(sol["control"][0].cpu().numpy() - ref["control_traj_opt"]).max() <= 1e-9 * sc(ref["control_traj_opt"])
-    assert np.abs(sol["costate"][0].cpu().numpy() - ref["costate_traj_opt"]).max() <= 1e-9 * sc(ref["costate_traj_opt"])
+    tol = 1e-9 if rows is None else 1e-7                                     # (two iterate paths into one optimum, each to the 1e-10 convergence test)
+    assert np.abs(sol["state"][2].cpu().numpy() - ref["state_traj_opt"]).max() <= tol * sc(ref["state_traj_opt"])
+    assert np.abs(sol["control"][2].cpu().numpy() - ref["control_traj_opt"]).max() <= tol * sc(ref["control_traj_opt"])
+    assert np.abs(sol["costate"][2].cpu().numpy() - ref["costate_traj_opt"]).max() <= tol * sc(ref["costate_traj_opt"])
+    assert abs(float(sol["cost"][2]) - d["cost"][demo]) <= 1e-9 * abs(d["cost"][demo])      # ... which is the one IPOPT stored
+    return ref, log, d
+
+
+@pytest.mark.parametrize("name", ["pendulum", "rocket", "quadrotor"])
+def test_ms_kernel_follows_the_oracle_iteration_by_iteration(golden_dir, name):
+    """pdp_oc_solve_ms_batched against oracle/ipopt_ms.py (the CPU restatement of IPOPT's algorithm on the reference's NLP) on the
+    first stored demo: same number of iterations, same inertia corrections and step lengths at every iteration, objective /
+    infeasibility columns of the iteration log equal to rounding, same solution."""
+    _follows(golden_dir, name, 0, False)
+
+
+@pytest.mark.parametrize("name,demo,tried,taken,iters,iters_plain,rows", [("cartpole", 0, 22, 7, 35, 45, 11), ("robotarm", 0, 1, 1, 3, 6, None), ("robotarm", 1, 4, 1, 5, 14, None),
+                                                                          ("quadrotor", 0, 1, 0, 11, 11, None), ("rocket", 0, 2, 0, 10, 10, None)])
+def test_ms_kernel_second_order_correction_follows_the_oracle(golden_dir, name, demo, tried, taken, iters, iters_plain, rows):
+    """PDP_MS_WITH_SOC: the kernel's line search with IPOPT's second-order correction against the restatement's (solve(soc=True)) row by row - cart-pole and robot-arm
+    demos TAKE corrected steps (minus alpha in the log, PDP_MS_SOC in the status), quadrotor and rocket try one or two, reject them and go on with the plain step halved,
+    exactly as without the switch.  Cart-pole demo 0 (the small-system form of the kernel: the line search's trial pass split between the two waves): the first 11 rows -
+    corrections taken at iterations 1, 3, 8, rejected at 5, 6, 9, 10 - then rounding takes the two non-convex solves apart (restatement 35 iterations, kernel 39; 45
+    without the switch).  Every one of these solves ends in the optimum IPOPT stored."""
+    ref, log, d = _follows(golden_dir, name, demo, True, rows=rows)
+    assert ref["soc_steps"] == tried and sum(1 for l in log if l["soc_taken"]) == taken and ref["iterations"] == iters
+    if rows is not None:
+        assert sum(1 for l in log[:rows] if l["soc_taken"]) >= 3 and sum(1 for l in log[:rows] if l["soc"] and not l["soc_taken"]) >= 3
+    assert abs(ref["cost"] - d["cost"][demo]) <= 1e-9 * abs(d["cost"][demo])
+    from pdp_amd import zoo
+    plain = zoo.get(name, "irl").oc_solve_ms(d["state"][demo:demo + 1, 0], d["true_parameter"], d["control"].shape[1], tol=1e-10)
+    assert int(plain["iterations"][0]) == iters_plain and int(plain["status"][0]) == 0
+    assert abs(float(plain["cost"][0]) - d["cost"][demo]) <= 1e-9 * abs(d["cost"][demo])
+
+
+def test_ms_kernel_second_order_correction_after_a_restoration(golden_dir):
+    """robot arm demo 3 with PDP_MS_WITH_SOC: 40 corrections tried around the restoration of iteration 8, two taken after it; 19 iterations instead of 21, the same stored optimum
+    (to the 1e-10 convergence test: the last iterate sits 1.2e-9 from the stored controls where the plain iteration, one step later, sits 3e-13)."""
+    from oracle import ipopt_ms, models, pdp_oracle as po
+    from pdp_amd import zoo
+    d = load(golden_dir, "demos_robotarm.npz")
+    st = models.IRL_SETUP["robotarm"]
+    oc = po.make_oc(models.REGISTRY["robotarm"](**st["kwargs"]), st["dt"])
+    T = d["control"].shape[1]
+    log = []
+    ref = ipopt_ms.solve(oc, d["state"][3, 0], T, d["true_parameter"], tol=1e-10, log=log, soc=True)
+    assert ref["iterations"] == 19 and ref["restorations"] == 1 and ref["soc_steps"] == 40
+    out = zoo.get("robotarm", "irl").oc_solve_ms(d["state"][3:4, 0], d["true_parameter"], T, tol=1e-10, log_rows=32, soc=True)
+    assert bool(out["converged"][0]) and int(out["status"][0]) == 128 + 1024 and int(out["iterations"][0]) == 19
+    kl = out["log"][0].cpu().numpy()
+    for r, l in enumerate(log):
+        assert kl[r, 0] == l["it"] and kl[r, 4] == l["dw"] and kl[r, 5] == _alpha_col(l), (r, kl[r], l["dw"], l["alpha"])
+        assert abs(kl[r, 1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(kl[r, 2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
+    assert np.abs(out["control"][0].cpu().numpy() - d["control"][3]).max() <= 5e-9 and abs(float(out["cost"][0]) - d["cost"][3]) <= 1e-9 * d["cost"][3]
 
 
 def test_ms_kernel_restoration_follows_the_oracle(golden_dir):
@@ -173,7 +229,7 @@ def test_ms_kernel_restoration_follows_the_oracle(golden_dir):
     assert (out["iterations"].cpu().numpy() == ref["iterations"]).all() and ref["restorations"] == 1
     kl = out["log"].cpu().numpy()[0]
     for r, l in enumerate(log):
-        assert kl[r, 0] == l["it"] and kl[r, 4] == l["dw"] and kl[r, 5] == l["alpha"], (r, kl[r], l["dw"], l["alpha"])
+        assert kl[r, 0] == l["it"] and kl[r, 4] == l["dw"] and kl[r, 5] == _alpha_col(l), (r, kl[r], l["dw"], l["alpha"])
         assert abs(kl[r, 1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(kl[r, 2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
         assert abs(kl[r, 3] - l["inf_du"]) <= 1e-8 * max(1.0, l["inf_du"])
     assert [l["alpha"] for l in log].index(0.0) == 8
@@ -204,7 +260,7 @@ def test_ms_kernel_from_controls_follows_the_oracle_at_a_long_horizon(golden_dir
     assert bool(sol["converged"].all()) and (sol["iterations"].cpu().numpy() == ref["iterations"]).all() and ref["iterations"] == len(log)
     kl = sol["log"][B - 1].cpu().numpy()
     for r, l in zip(kl, log):
-        assert r[5] == l["alpha"] and abs(r[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (l["it"], r[4], r[5], l["dw"], l["alpha"])
+        assert r[5] == _alpha_col(l) and abs(r[4] - l["dw"]) <= 1e-12 * max(1.0, l["dw"]), (l["it"], r[4], r[5], l["dw"], l["alpha"])
         assert abs(r[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r[2] - l["inf_pr"]) <= 1e-9 * max(1.0, l["inf_pr"])
     assert log[0]["inf_pr"] <= 1e-12                                           # the starting point is the rollout: feasible
     sc = lambda a: max(1.0, np.abs(a).max())

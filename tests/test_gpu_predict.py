@@ -101,7 +101,7 @@ def test_ms_kernel_from_the_predicted_start_follows_the_oracle(golden_dir, name,
     assert int(got["iterations"][0]) < int(plain["iterations"][0])
     kl = got["log"][0].cpu().numpy()
     for r, l in zip(kl, log):
-        assert r[5] == l["alpha"] and r[4] == l["dw"], (name, l["it"], r[4], r[5], l["dw"], l["alpha"])
+        assert r[5] == (-l["alpha"] if l["soc_taken"] else l["alpha"]) and r[4] == l["dw"], (name, l["it"], r[4], r[5], l["dw"], l["alpha"])
         assert abs(r[1] - l["f"]) <= 1e-9 * max(1.0, abs(l["f"])) and abs(r[2] - l["inf_pr"]) <= 1e-8 * max(1e-3, l["inf_pr"])
     sc = lambda a: max(1.0, np.abs(a).max())
     for k, kr in (("state", "state_traj_opt"), ("control", "control_traj_opt"), ("costate", "costate_traj_opt")):
