@@ -210,6 +210,27 @@ def test_ms_kernel_second_order_correction_after_a_restoration(golden_dir):
     assert np.abs(out["control"][0].cpu().numpy() - d["control"][3]).max() <= 5e-9 and abs(float(out["cost"][0]) - d["cost"][3]) <= 1e-9 * d["cost"][3]
 
 
+@pytest.mark.parametrize("name,demo,iters,status", [("robotarm", 1, 5, 1024), ("robotarm", 3, 19, 1152), ("quadrotor", 0, 11, 0)])
+def test_second_order_correction_in_every_workgroup_shape(golden_dir, name, demo, iters, status):
+    """the corrections' bookkeeping lives in the trajectory's LDS mailbox: one, two and four trajectories per workgroup (B = 3, 300, 1100 copies of a stored demo) give the same
+    iterations, status and - bit for bit - the same solution (robot arm: corrections taken, one case around a restoration; quadrotor: tried and rejected, the plain step restored)"""
+    from pdp_amd import zoo
+    d = load(golden_dir, "demos_%s.npz" % name)
+    mdl = zoo.get(name, "irl")
+    T = d["control"].shape[1]
+    ref = None
+    for B in (3, 300, 1100):
+        sol = mdl.oc_solve_ms(np.repeat(d["state"][demo:demo + 1, 0], B, axis=0), d["true_parameter"], T, tol=1e-10, soc=True)
+        assert bool(sol["converged"].all()) and (sol["iterations"].cpu().numpy() == iters).all() and (sol["status"].cpu().numpy() == status).all()
+        got = [sol[k].cpu().numpy() for k in ("state", "control", "costate")]
+        for g in got:
+            assert (g == g[:1]).all()                                        # every copy alike
+        if ref is None:
+            ref = got
+        else:
+            assert all(np.array_equal(a[0], b[0]) for a, b in zip(got, ref)), B
+
+
 def test_ms_kernel_restoration_follows_the_oracle(golden_dir):
     """robot arm demo 3 (the one stored demo whose line search falls below alpha_min): the kernel's iteration log equals the restatement's row by row -
     eight Newton iterations, the restoration (step length 0 in the log), the least-squares multiplier reset, twelve more iterations - and ends in the optimum
