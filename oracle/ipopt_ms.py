@@ -133,7 +133,7 @@ def least_squares_multipliers(ev, n, m):
     ls["hxx"] = np.eye(n)
     ls["c"] = np.zeros((T, n))
     _, _, dl, ok = kkt_step(ls, 0.0, n, m)
-    return dl
+    return dl if ok else np.full((T, n), np.nan)          # (a non-finite point: the callers then start from zero multipliers, as for an estimate above constr_mult_init_max)
 
 
 def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None, soc=False):
