@@ -195,7 +195,7 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
 /* OCSys.ocSolver (PDP.py:121-220) as the reference poses it: the multiple-shooting NLP
  *     min sum_t c(x_t,u_t) + h(x_T)  over x_1..x_T, u_0..u_{T-1}   s.t.  f(x_t,u_t) - x_{t+1} = 0,  x_0 = ini_state   (PDP.py:131-179)
  * solved from the reference's all-zero initial guess (PDP.py:155,166) by IPOPT's algorithm for the equality-constrained case
- * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search with second-order correction, least-squares
+ * (Waechter & Biegler 2006: primal-dual Newton step, inertia correction, filter line search (second-order correction: optional, see below), least-squares
  * initial multipliers; CPU restatement: oracle/ipopt_ms.py).  A persistent pair of wavefronts per trajectory (runner: IPOPT's control flow and the Riccati /
  * forward chains on the MFMA tiles; evaluator: KKT matrices, trial-point residuals, multiplier step with one lane per stage - csrc/pdp_ocsolve2_kernels.h;
  * the one-wavefront kernel of round 2, csrc/pdp_ocsolve_kernels.h, stays behind PDP_MS_VARIANT=1) runs ALL iterations inside one launch: the
