@@ -472,7 +472,7 @@ def scaling_configs(torch, dist, world, rank, steps, verify=False):
     exchange alone (exchange_us), the overlapped step time (max over ranks) and the aggregate trajectories/s = total batch / step time."""
     from pdp_amd import JinEnv, parallel, runtime as rt, zoo
     res = {}
-    distributed = world > 1
+    distributed = world > 1 or parallel.force_collective()
     steps = max(3, min(steps, 20))
 
     def run(name, B_total, p, make_unit, flop, note, T=None, latency_bound=False, executed_flop=None):
@@ -671,9 +671,12 @@ def main():
     backend = os.environ.get("PDP_DIST_BACKEND", "nccl")
     same_device = os.environ.get("PDP_DIST_SAME_DEVICE", "0") == "1"
     torch.cuda.set_device(0 if same_device else local)
-    distributed = world > 1
+    # PDP_DIST_FORCE_COLLECTIVE=1: a ONE-rank process group that still issues every collective - the nccl (= RCCL) backend executed on a one-GPU box through
+    # exactly the calls of an N-GPU run (communicator set-up, all_gather_into_tensor / all_reduce on device pointers, the side-stream exchange).
+    distributed = world > 1 or parallel.force_collective()
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, T = args.batch, HORIZON
@@ -786,7 +789,8 @@ def main():
                        "batch_per_gpu": B, "horizon": T,
                        "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the next step's kernel" %
                                     ("RCCL" if backend == "nccl" else backend + " (staged through host memory: test mode)")) if distributed else "none (1 GPU)",
-                       "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and distributed)},
+                       "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and world > 1),
+                       "collectives_forced_at_world_size_1": bool(distributed and world == 1)},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_calibration": traffic_cal, "kernel_resources": kres,
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "

@@ -452,6 +452,28 @@ def _build(out, deps, cmd_tail, force, flags=None):
     return out
 
 
+def source_closure(src):
+    """`src` and every file of this repository it includes, transitively (`#include "..."` resolved against the including file's directory, csrc/ and include/;
+    the generated model header comes in through a macro and is listed by the caller).  The content-hash stamp of a library is taken over exactly this list, so a
+    header added to a translation unit can never be missing from it (round-5 advice: pdp_cp_generic_kernels.h was, and edits to it left stale model libraries)."""
+    import re
+    roots = [CSRC, os.path.join(os.path.dirname(HERE), "include")]
+    seen, todo = [], [os.path.abspath(src)]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.append(f)
+        with open(f) as fh:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+                for d in [os.path.dirname(f)] + roots:
+                    c = os.path.abspath(os.path.join(d, inc))
+                    if os.path.exists(c):
+                        todo.append(c)
+                        break
+    return [seen[0]] + sorted(seen[1:])
+
+
 def tuned(name):
     env = os.environ.get("PDP_MFMA_VGPR_FORM")
     if env is not None:
@@ -462,8 +484,7 @@ def tuned(name):
 def compile_model(name, force=False, plain_twin=False):
     """hipcc csrc/pdp_model.hip with the generated header -> lib/libpdp_model_<name>.so (in-tree).  plain_twin: the same model built with
     CORE_FLAGS whatever tuned() says, as lib/libpdp_model_<name>__plain.so - the reference build tests/test_gpu_flag_fence.py compares with."""
-    deps = [header_path(name)] + [os.path.join(CSRC, f) for f in ("pdp_model.hip", "pdp_model_kernels.h", "pdp_ocsolve_kernels.h", "pdp_ocsolve2_kernels.h", "pdp_cp_mlp_kernels.h", "pdp_cp_pair_kernels.h", "pdp_fused3_kernels.h", "pdp_lqr_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h", "pdp_policy.h")]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h"))
+    deps = [header_path(name)] + source_closure(os.path.join(CSRC, "pdp_model.hip"))
     extra = OC_EXTRA_FLAGS if ("_%s_" % KIND_NAME[KIND_OC]) in name else []
     # -amdgpu-mfma-vgpr-form (hidden LLVM option, +4 % on the headline kernel, but see CORE_FLAGS above) only for the exact benchmark models
     # (TUNED_NAMES), whose kernels are parity-tested one by one on NaN-dirtied memory and compared with their plain -O3 twins; a user's model
@@ -477,7 +498,7 @@ CORE_LIB_PATH = os.path.join(LIB_DIR, "libpdp_hip.so")
 
 
 def compile_core(force=False):
-    deps = [os.path.join(CSRC, f) for f in ("pdp_lqr.hip", "pdp_lqr_kernels.h", "pdp_lqr_stream_kernels.h", "pdp_riccati.h", "pdp_riccati_small.h", "pdp_tile.h")] + [os.path.join(os.path.dirname(HERE), "include", "pdp_hip.h")]
+    deps = source_closure(os.path.join(CSRC, "pdp_lqr.hip"))
     return _build(os.path.join(LIB_DIR, "libpdp_hip.so"), deps, ["-I", CSRC, os.path.join(CSRC, "pdp_lqr.hip")], force, flags=CORE_FLAGS)
 
 

@@ -6,8 +6,22 @@ contiguous shards, every rank runs the same kernels on its shard with a replicat
     1024 x 10 x 8 B = 80 KB per rank - latency-bound over xGMI, so it is a single collective, never one per parameter;
   * all-reduce of the locally summed row `[p+1]` (allreduce_mean_packed, mode="allreduce") - what a driver that only needs the mean should use: 3.4 KB at
     C5b (p = 420) instead of 27.6 MB received per rank."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def force_collective():
+    """PDP_DIST_FORCE_COLLECTIVE=1: a process group of ONE rank still issues every collective (no world-size-1 short cut anywhere in this module or in bench.py).
+    That is how a one-GPU box executes the `nccl` (= RCCL) backend through exactly the calls an 8-GPU run makes: communicator set-up, all_gather_into_tensor /
+    all_reduce on device pointers, the side-stream ordering of OverlappedGather (tests/test_gpu_rccl_world1.py)."""
+    return os.environ.get("PDP_DIST_FORCE_COLLECTIVE", "0") == "1"
+
+
+def exchange_active():
+    """True when a collective has to be issued: a process group exists and it has more than one rank (or force_collective())"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective())
 
 
 def host_staged(t):
@@ -60,7 +74,7 @@ def shard(x, world=None, rank=None, dim=0):
 def gather_loss_grad(loss, grad, n_total=None):
     """all-gather per-sample (loss [b], grad [b,p]) of every rank -> (loss [B], grad [B,p]) on every rank.
     Shards may differ by one trajectory (ragged): they are padded to the largest shard for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchange_active():
         return loss, grad
     world, rank = dist.get_world_size(), dist.get_rank()
     b, p = grad.shape
@@ -88,7 +102,7 @@ def allreduce_mean_packed(packed, n_total=None):
     Ragged shards need no padding (a sum does not care).  Returns the mean row [p+1] (gradient mean | loss mean) on every rank.
     n_total: the number of trajectories over all ranks (None: it is all-reduced along, as one more entry of the same message)."""
     s = packed.sum(dim=0)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchange_active():
         return s / float(packed.shape[0] if n_total is None else n_total)
     if n_total is None:
         s = torch.cat([s, torch.tensor([float(packed.shape[0])], dtype=s.dtype, device=s.device)])
@@ -127,7 +141,7 @@ def gather_packed(packed, n_total=None, out=None):
     """all-gather of the [b, p+1] rows the fused kernel writes with PDP_OC_PACKED (gradient | loss): no packing copies on the way in.
     Equal shards (n_total divisible by the world size, or None): ONE collective straight into `out` [B, p+1]; ragged shards go
     through gather_loss_grad's padding.  Returns the [B, p+1] tensor."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not exchange_active():
         return packed
     world = dist.get_world_size()
     b, p1 = packed.shape
@@ -149,6 +163,7 @@ class OverlappedGather:
 
     def __init__(self, rows, cols, dtype=torch.float64, device="cuda"):
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.active = exchange_active()
         self.cuda = torch.device(device).type == "cuda"
         self.buffers = [torch.zeros((rows, cols), dtype=dtype, device=device) for _ in range(2)]
         self.gathered = [torch.zeros((self.world * rows, cols), dtype=dtype, device=device) for _ in range(2)]
@@ -167,7 +182,7 @@ class OverlappedGather:
         """enqueue the all-gather of the buffer handed out by the last next_buffer(); returns the index of the gathered tensor"""
         i = self.k % 2
         self.k += 1
-        if self.world == 1:
+        if not self.active:
             self.gathered[i] = self.buffers[i]
             return i
         if not self.cuda:

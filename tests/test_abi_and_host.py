@@ -318,3 +318,28 @@ def test_product_path_fails_loudly_without_a_gpu(built):
         IRLLoop(mdl, np.zeros((2, 6, 4)), np.zeros((2, 5, 1)), np.ones(7), 1e-4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mdl.oc_solve_ms(np.zeros((2, 4)), np.ones(7), 5)
+
+
+def test_library_stamps_cover_every_included_header(tmp_path):
+    """Round-5 advice: pdp_model.hip gained `#include "pdp_cp_generic_kernels.h"` while the hand-written dependency list behind the model libraries' content-hash
+    stamp did not - edits to that header left stale libraries.  The list is now the include closure of the translation unit: every local header either .hip file
+    names (directly or through another header) is in it, and touching any of them changes the stamp."""
+    from pdp_amd import codegen
+    for unit in ("pdp_model.hip", "pdp_lqr.hip"):
+        src = os.path.abspath(os.path.join(codegen.CSRC, unit))
+        deps = codegen.source_closure(src)
+        by_name = {os.path.basename(d): d for d in deps}
+        assert deps[0] == src and "pdp_hip.h" in by_name
+        for f in deps:                                           # every quoted include of every file of the list is itself in the list
+            for inc in re.findall(r'#\s*include\s+"([^"]+)"', open(f).read()):
+                assert os.path.basename(inc) in by_name, "%s includes %s, which the stamp of its library does not cover" % (os.path.basename(f), inc)
+    assert "pdp_cp_generic_kernels.h" in {os.path.basename(d) for d in codegen.source_closure(os.path.join(codegen.CSRC, "pdp_model.hip"))}
+    # the stamp is a content hash over that list: one byte more in any header is another stamp
+    a, b = tmp_path / "a.h", tmp_path / "b.h"
+    a.write_text('#include "b.h"\nint a;\n')
+    b.write_text("int b;\n")
+    d0 = codegen.source_closure(str(a))
+    assert [os.path.basename(x) for x in d0] == ["a.h", "b.h"]
+    s0 = codegen._stamp_of(d0, ["-O3"])
+    b.write_text("int b; \n")
+    assert codegen._stamp_of(codegen.source_closure(str(a)), ["-O3"]) != s0
