@@ -646,6 +646,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default = config C3)")
+    ap.add_argument("--eager", action="store_true",
+                    help="one ctypes launch per step from Python instead of one hipGraph replay per step (single-GPU default: replay; N > 1 always launches eagerly - "
+                         "the side-stream exchange is not captured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-scaling-configs", action="store_true", help="skip the sharded C4 / C5 measurements (BASELINE configs[3], configs[4])")
@@ -712,14 +715,46 @@ def main():
         pk = og.buffers[0]
         exch_us = 1e3 * _event_ms(torch, lambda: parallel.gather_packed(pk, out=og.gathered[0]), reps=10, warm=2)
 
+    # ---- single GPU: the step recorded once as a hipGraph (one kernel node, same arguments, same buffers) and replayed K times - what pdp_amd.irl.IRLLoop / GDLoop do
+    # for the loops of the reference's drivers: the host's per-step cost (Python wrapper, ctypes marshalling) leaves the timed region.  The eager form is timed beside
+    # it over the same K steps (`launch_modes`); --eager makes it the measured one.
+    graph, eager_ms_per_step = None, None
+    if not distributed:
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        eager_ms_per_step = (time.perf_counter() - te) / args.steps * 1e3
+        if not args.eager:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            ref_rows = bufs["packed"].clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            bufs["packed"].zero_()
+            for _ in range(max(2, args.warmup)):
+                graph.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(bufs["packed"], ref_rows):
+                raise SystemExit("the replayed graph does not reproduce the eager step bit for bit")
+
     # ---- the timed region: EXACTLY K steps between barrier + synchronize
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     c0 = _clocks()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        for _ in range(args.steps):
+            graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     if distributed:
         og.drain()                      # every exchange of the K steps has completed inside the timed region
     torch.cuda.synchronize()
@@ -789,6 +824,9 @@ def main():
                        "batch_per_gpu": B, "horizon": T,
                        "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the next step's kernel" %
                                     ("RCCL" if backend == "nccl" else backend + " (staged through host memory: test mode)")) if distributed else "none (1 GPU)",
+                       "launch": "hipGraph replay (one kernel node per step)" if graph is not None else "one C-ABI call per step from Python",
+                       "launch_modes": ({"eager_ms_per_step": eager_ms_per_step, "graph_replay_ms_per_step": dt / args.steps * 1e3 if graph is not None else None}
+                                        if not distributed else None),
                        "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and world > 1),
                        "collectives_forced_at_world_size_1": bool(distributed and world == 1)},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

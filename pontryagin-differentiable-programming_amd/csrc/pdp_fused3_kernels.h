@@ -27,10 +27,6 @@
 #ifndef PDP_F3_ROLLOUT_LANES
 #define PDP_F3_ROLLOUT_LANES 0      // 1: the rollout parks x_{t+1} in lane t and stores blocks of 64 steps (see the rollout loop)
 #endif
-#ifndef PDP_F3_SYM_EVERY
-#define PDP_F3_SYM_EVERY 1          // P <- (P + P')/2 every k-th backward step of a group of U.  ONLY 1 IS CORRECT: k = 2 / 4 exist to reproduce profiles/r03_fused3_sym_every.txt
-                                    // (2 - 4 % faster, gradient wrong in the 5th - 9th digit: one unsymmetrised step already lets the skew rounding error of P through)
-#endif
 
 namespace pdp {
 
@@ -379,8 +375,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                 // tiles are accumulator inputs of later MFMAs and are requested at the top of their own step.  Step 0 of a chunk requests
                 // nothing ahead (no LDS read outside the buffer).
                 d4 Fa = read3(rF, RB), Ya = read3(rY, RB), Fb = z, Yb = z;
-                auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn, auto sym_tag) {      // imm: distance of row tl from the runs
-                    constexpr bool SYM_ = decltype(sym_tag)::value;
+                auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {      // imm: distance of row tl from the runs
                     const int t = t0 + tl;
 #ifdef PDP_PHASE_TIMING_FINE
                     if (blockIdx.x == 0 && threadIdx.x == 0) g_rb_stamp[9] = __builtin_readcyclecounter();
@@ -393,7 +388,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
                         if (riccati) { f3_bstore(rsR, (unsigned)(t * RSZ) * 8u, mRP, P); f3_bstore(rsR, (unsigned)(t * RSZ + NX * NX) * 8u, mRW, W2); }
                         if (precPW) { pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P); pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.W, W2); }
                     }
-                    ok = riccati_backward<M, false, false, false, SYM_>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
+                    ok = riccati_backward<M, false>(P, W2, Fc, Yc, Grep, Hxx, HX2, HU2, Hux[0], scratch, lane, NP, gn, P_old) && ok;
                     store_all<1>(gw + t * GSZ, mK, gn.K);
                     store_all<1>(gw + t * GSZ + NX * NU, mIK, gn.IK);
 #ifdef PDP_PHASE_TIMING_FINE
@@ -401,19 +396,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_pdp_fused3_kernel(int B, int T, 
 #endif
                 };
                 // single steps until a whole number of groups of U remains (the register sets move up by copies there)
-                for (; (tl + 1) % U != 0; --tl) { bstep(tl, RB, Fa, Ya, Fb, Yb, std::true_type{}); Fa = Fb; Ya = Yb; move_all(-RB); }
+                for (; (tl + 1) % U != 0; --tl) { bstep(tl, RB, Fa, Ya, Fb, Yb); Fa = Fb; Ya = Yb; move_all(-RB); }
                 // groups of U steps: the runs sit on row tl - U, step tl - j reads at (U - j) rows - literal offsets, one address update per group
                 move_all(-(U - 1) * RB);
                 for (; tl >= U - 1; tl -= U) {
-                    static_assert(U == 4, "the group is written out: the symmetrisation schedule is a compile-time property of each step");
-                    using S0 = std::integral_constant<bool, (0 % PDP_F3_SYM_EVERY) == PDP_F3_SYM_EVERY - 1>;
-                    using S1 = std::integral_constant<bool, (1 % PDP_F3_SYM_EVERY) == PDP_F3_SYM_EVERY - 1>;
-                    using S2 = std::integral_constant<bool, (2 % PDP_F3_SYM_EVERY) == PDP_F3_SYM_EVERY - 1>;
-                    using S3 = std::integral_constant<bool, (3 % PDP_F3_SYM_EVERY) == PDP_F3_SYM_EVERY - 1>;
-                    bstep(tl, (unsigned)(4 * RB), Fa, Ya, Fb, Yb, S0{});
-                    bstep(tl - 1, (unsigned)(3 * RB), Fb, Yb, Fa, Ya, S1{});
-                    bstep(tl - 2, (unsigned)(2 * RB), Fa, Ya, Fb, Yb, S2{});
-                    bstep(tl - 3, (unsigned)(1 * RB), Fb, Yb, Fa, Ya, S3{});
+                    static_assert(U == 4, "the group is written out");
+                    bstep(tl, (unsigned)(4 * RB), Fa, Ya, Fb, Yb);
+                    bstep(tl - 1, (unsigned)(3 * RB), Fb, Yb, Fa, Ya);
+                    bstep(tl - 2, (unsigned)(2 * RB), Fa, Ya, Fb, Yb);
+                    bstep(tl - 3, (unsigned)(1 * RB), Fb, Yb, Fa, Ya);
                     move_all(-U * RB);
                 }
                 f3_signal(fl + 3, g + 1);

@@ -100,29 +100,17 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
     }
     // The matrices of step t-1 are requested from HBM before the Riccati step of t runs (one step = ~3k cycles of MFMA / VALU work,
     // an HBM round trip ~2k): two steps per trip, the operand tiles alternating between two register sets.
-    struct BwdTiles { d4 Ft, Y2, Grep, Hxx, HX2, HU2, Hux; };
+    struct BwdTiles { d4 Ft, Y2, Grep, Hxx, HX2, HU2; };
     const pdp_mat none = {nullptr, 0, 0};
     RunPtr rF = make_run(pr.F, mNN, none, mNN, b, T - 1), rY = make_run(pr.G, mNM, pr.E, mNP, b, T - 1), rHxx = make_run(pr.Hxx, mNN, none, mNN, b, T - 1),
            rHX = make_run(pr.Hxu, mNM, pr.Hxe, mNP, b, T - 1), rHU = make_run<1>(pr.Huu, mMM, pr.Hue, mMP, b, T - 1),
            rGr = make_run(pr.G, mNMrep, none, mNN, b, T - 1);
-    // experiment hooks of probes/lqr_oob_probe.py (root cause of the round-1 out-of-bounds reads): PDP_LQR_STREAM_HUX streams
-    // Hxu' as a seventh operand instead of transposing HX2 through LDS; PDP_LQR_UNGUARDED restores the round-1 prefetch after the last step
-#ifdef PDP_LQR_STREAM_HUX
-    RunPtr rHux = make_run<1>(pr.Hxu, make_dense_map<true>(n, M, M, 0, 0, lane), none, mNN, b, T - 1);
-#endif
     auto load_bwd = [&](BwdTiles& w) {     // (issued for steps t-1 >= 0 only: bstep guards the request of the last step)
         w.Ft = load_run(rF, -1); w.Y2 = load_run(rY, -1); w.Grep = load_run(rGr, -1); w.Hxx = load_run(rHxx, -1); w.HX2 = load_run(rHX, -1);
         w.HU2 = load_run<1>(rHU, -1);
-#ifdef PDP_LQR_STREAM_HUX
-        w.Hux = load_run<1>(rHux, -1);
-#endif
     };
     auto bstep = [&](int t, const BwdTiles& c, BwdTiles& nx) {
-#ifdef PDP_LQR_UNGUARDED
-        load_bwd(nx);
-#else
-        if (t > 0) load_bwd(nx);
-#endif
+        if (t > 0) load_bwd(nx);      // (never for t - 1 = -1: one time stride in front of the arrays - the round-1 out-of-bounds read, profiles/r02_lqr_oob_root_cause.txt)
         if (ws_pw) {   // P_{t+1}, W_{t+1} for the costate output (lambda_{t+1} = P x_{t+1} + W, PDP.py:604)
             double* pw = ws_pw + ((int64_t)b * T + t) * pwsz;
             lqs_store(rPW, sNN, (unsigned)(t * pwsz) * 8u, P);
@@ -132,11 +120,7 @@ __global__ void __launch_bounds__(64) lqr_solve_kernel(pdp_lqr_problem pr, doubl
         }
         RiccatiGains g;
         d4 P_old;
-#ifdef PDP_LQR_STREAM_HUX
-        ok = riccati_backward<M, true, false>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, c.Hux[0], scratch, lane, p0, g, P_old) && ok;
-#else
         ok = riccati_backward<M, true, true>(P, W[0], c.Ft, c.Y2, c.Grep, c.Hxx, c.HX2, c.HU2, 0.0, scratch, lane, p0, g, P_old) && ok;
-#endif
         double* gw = ws_gain + ((int64_t)b * T + t) * gsz;
         lqs_store(rG, sNM, (unsigned)(t * gsz) * 8u, g.KT);
         lqs_store<1>(rG, sMP, (unsigned)(t * gsz + n * M) * 8u, g.IK);

@@ -488,18 +488,6 @@ PDP_DEV d4 gather_tile(const double* lds, const Gather& g, int tl) {
 
 // feedback gains of one step in the workspace: K [NU x NX], k [NU x NP], and one slot that receives (and hands back) the zeros of
 // the tile elements outside those blocks
-// Closed-loop forward sweep - an EXPERIMENT, off by default (-DPDP_FUSED_CLOSED_LOOP enables it for n > 4): the backward step also leaves
-// Acl = F - G K and ecl = E - G k in the workspace, so that the forward recursion is X+ = Acl X + ecl - one 16x16x16 product per step on the
-// critical path instead of U = -K X - k followed by X+ = F X + G U + E, and no evaluation pass of F, G, E in the forward sweep.  Parity-green,
-// but slower (C3: 0.134 - 0.137 ms against 0.119 ms): the two rank-m MFMAs and 8 stores cost 350 cycles per backward step, and the forward
-// sweep then has to pull 114 KB per trajectory (117 MB per launch) through L2 / HBM in ~25 us - it runs AT the memory system's limit
-// (~4.5 TB/s) whatever the prefetch distance (profiles/r02_closed_loop_forward.txt).  The open-loop form recomputes F, G, E from 1.3 KB of
-// x, u per trajectory instead, which is why it wins.
-#ifdef PDP_FUSED_CLOSED_LOOP
-template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return Mdl::NX > 4; }
-#else
-template <class Mdl> __host__ __device__ constexpr bool fused_closed_loop() { return false; }
-#endif
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain0_doubles() { return Mdl::NX * Mdl::NU + Mdl::NU * Mdl::NP + 1; }      // K | k | zero sink
 // Riccati record of a stage (optional output of the fused gradient unit): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | one scratch word (zero sink of the tile stores)
@@ -546,7 +534,7 @@ struct PredMaps {
 };
 template <class Mdl>
 __host__ __device__ constexpr int fused_gain_doubles() {
-    return fused_gain0_doubles<Mdl>() + (fused_closed_loop<Mdl>() ? Mdl::NX * Mdl::NX + Mdl::NX * Mdl::NP + 1 : 0);              // + Acl | ecl | zero sink
+    return fused_gain0_doubles<Mdl>();
 }
 
 // experiment hooks (probes/occupancy_variant.py): -DPDP_FUSED_CHUNK=<steps per chunk> shrinks the LDS pool, -DPDP_FUSED_WAVES=<n> asks the
@@ -602,7 +590,6 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
     // left operands are gathered in "rep" form (the 4 x 4 block replicated in the four column blocks), only register 0 of a tile is live
     constexpr bool SMALL = NX <= 4;
     constexpr int NRT = SMALL ? 1 : 4;                  // live registers of an n-row tile
-    constexpr bool CLF = fused_closed_loop<Mdl>();      // closed-loop forward sweep (see fused_closed_loop)
     constexpr int GSZ0 = fused_gain0_doubles<Mdl>();
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* scratch = lds;                              // RICCATI_SCRATCH
@@ -757,8 +744,6 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             return r >= M ? -1 : (c < M ? codeB(3, r * NU + c) : (c < M + NP ? codeB(4, r * NP + (c - M)) : -1)); });
         // gains of a step in the workspace: K [NU x NX] (rows 0..3 of its tile: one register), k [NU x NP], zero sink
         const TileMapBytes mK = make_tile_map_sink(NU, NX, NX, 0, 0, lane, GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP);
-        // closed-loop matrices behind the gains: Acl [NX x NX] | ecl [NX x NP] | zero sink
-        const TileMapBytes mAcl = make_tile_map_sink(NX, NX, NX, 0, 0, lane, NX * NX + NX * NP), mEcl = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
         // Riccati record of a stage (RIC; see oc_pdp_fused3_kernel): P_{t+1} [NX x NX] | W_{t+1} [NX x NP] | zero sink
         constexpr int RSZ = oc_riccati_doubles<Mdl>();
         [[maybe_unused]] const TileMapBytes mRP = make_tile_map_sink(NX, NX, NX, 0, 0, lane, RSZ - 1), mRW = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
@@ -768,8 +753,6 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
         [[maybe_unused]] const bool precPW = RIC && prec && !(flags & PDP_OC_RECORD_PRIMAL);      // (PDP_OC_RECORD_PRIMAL: the P | W stores go to a resource of size 0)
         [[maybe_unused]] const auto rsPR = __builtin_amdgcn_make_buffer_rsrc((void*)(precPW ? (void*)(prec + (int64_t)b * T * PredRec<Mdl>::SIZE) : (void*)ws_gain), 0,
                                                                               precPW ? (int)((int64_t)T * PredRec<Mdl>::SIZE * 4) : 0, 0x00020000);
-        Gather gGTb;                                      // G' (m x n, rows 0..3): left operand of the rank-m products G K and G k
-        make_gather(gGTb, lane, L::NC, L::BSTRIDE, [&](int r, int c) { return (CLF && r < M && c < NX) ? codeA(1, c * NU + r) : -1; });
         const bool given = (flags & PDP_OC_GIVEN_TRAJ) != 0;
         // costate tile: column 0 holds lambda_{t+1}; terminal value lambda_T = h_x(x_T)
         d4 Lam = z;
@@ -858,8 +841,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
             PDP_ACC(2);
             // operands of step tl are gathered one step ahead (the pool is read-only inside the chunk); running LDS offsets
             GatherRun rF = gather_at(gF, cnt - 1, blk), rY = gather_at(gY, cnt - 1, blk), rHxx = gather_at(gHxx, cnt - 1, blk), rHX = gather_at(gHX, cnt - 1, blk),
-                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk),
-                      rGTb = gather_at(gGTb, cnt - 1, blk);
+                      rHU = gather_at(gHU, cnt - 1, blk), rGr = gather_at(gGr, cnt - 1, blk), rHux = gather_at(gHux, cnt - 1, blk);
             // F and [G|E] feed the first MFMAs of a step and are gathered one step ahead; the Hessian tiles are accumulator inputs
             // of later MFMAs: their reads are issued at the top of the step, straight into the accumulator registers.  The last step
             // of a chunk prefetches nothing (no LDS read outside the pool).  Two steps per trip with the prefetched tiles alternating
@@ -901,8 +883,6 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 } else {
                 RiccatiGains g;
                 d4 P_old;
-                [[maybe_unused]] d4 GTb = z;
-                if constexpr (CLF) GTb = gather_run<1>(rGTb, -1);
                 if constexpr (RIC) {
                     if (rw) { store_all(rw + t * RSZ, mRP, P); store_all(rw + t * RSZ + NX * NX, mRW, W2); }
                     pred_store(rsPR, (unsigned)(t * PredRec<Mdl>::SIZE) * 4u, pm.P, P);
@@ -912,12 +892,6 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
                 PDP_FINE(2, t == 20);
                 store_all<1>(gw + t * GSZ, mK, g.K);
                 store_all<1>(gw + t * GSZ + NX * NU, mIK, g.IK);
-                if constexpr (CLF) {                     // Acl = F - G K, ecl = E - G k for the forward sweep (off this step's critical path)
-                    const d4 Acl = mms_tn_r0(GTb, g.K, Fu);
-                    const d4 Ecl = keep_cols(mms_tn_r0(GTb, g.IK, Yu), M, M + NP, lane);
-                    store_all(gw + t * GSZ + GSZ0, mAcl, Acl);
-                    store_all(gw + t * GSZ + GSZ0 + NX * NX, mEcl, Ecl);
-                }
                 }
                 PDP_FINE(3, t == 20);
                 PDP_FINE(4, t == 19);
@@ -933,72 +907,7 @@ __global__ void __launch_bounds__(64) PDP_FUSED_OCCUPANCY oc_pdp_fused_kernel(in
 
     // ---------------- forward sweep: sensitivities X_t = dx_t/dtheta, U_t, loss and gradient -----------
     double acc = 0.0, lsum = 0.0;
-    if constexpr (CLF) {
-        // closed-loop form: X+ = Acl X + ecl with the matrices the backward sweep left in the workspace; the pool only carries
-        // x - x_demo, u - u_demo per step (one lane-per-step pass per 64 steps, no model evaluation)
-        wave_lds_sync();
-        if (lane == 0) blk[0] = 0.0;
-        constexpr int FS2 = (NX + NU) | 1;
-        Gather gDX, gDU;
-        make_gather(gDX, lane, L::NC, FS2, [](int r, int c) { return (r < NX) ? r : -1; });
-        make_gather(gDU, lane, L::NC, FS2, [](int r, int c) { return (r < M) ? NX + r : -1; });
-        const double* dxb = demo_x + (int64_t)b * (T + 1) * NX;
-        const double* dub = demo_u + (int64_t)b * T * NU;
-        const TileMapBytes mKT = to_bytes_sink(make_rep4_map_transposed(NX, NU, NX, lane), GSZ0 - 1), mIK = make_tile_map_sink(NU, NP, NP, 0, M, lane, NU * NP),
-                           mAT = to_bytes_sink(make_dense_map<true>(NX, NX, NX, 0, 0, lane), NX * NX + NX * NP), mEc = make_tile_map_sink(NX, NP, NP, 0, M, lane, NX * NP);
-        d4 X2 = z;
-        // a step is one product (~350 cycles) but its operands come from HBM / L2 (~1000 cycles away): they are requested THREE steps ahead,
-        // four register sets in rotation, four steps per trip
-        struct FSet { d4 KT, k, A, E; };
-        auto request = [&](int t) {
-            const int tc = t < T ? t : T - 1;
-            FSet f;
-            f.KT = -load_all<4>(gw + tc * GSZ, mKT);
-            f.k = -load_all<1>(gw + tc * GSZ + NX * NU, mIK);
-            f.A = load_all<4>(gw + tc * GSZ + GSZ0, mAT);
-            f.E = load_all<4>(gw + tc * GSZ + GSZ0 + NX * NX, mEc);
-            return f;
-        };
-        FSet s0 = request(0), s1 = request(1), s2 = request(2), s3 = s2;
-        const int cap = fused_pool_doubles<Mdl>(T) / FS2;
-        const int ch2 = cap < 64 ? cap : 64;
-        for (int t0 = 0; t0 < T; t0 += ch2) {
-            const int cnt = min(ch2, T - t0);
-            wave_lds_sync();
-            if (lane < cnt) {
-                const int t = t0 + lane;
-                double* row = pool + lane * FS2;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) { const double d = xb[t * NX + i] - dxb[t * NX + i]; row[i] = d; lsum += d * d; }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) { const double d = ub[t * NU + i] - dub[t * NU + i]; row[NX + i] = d; lsum += d * d; }
-            }
-            wave_lds_sync();
-            GatherRun rDX = gather_at(gDX, 0, blk), rDU = gather_at(gDU, 0, blk);
-            auto fstep = [&](int tl, const d4 Xc, d4& Xn, const FSet& f, FSet& far) {
-                const int t = t0 + tl;
-                far = request(t + 3);
-                const d4 DX = gather_run(rDX, 1), DU = gather_run<1>(rDU, 1);
-                Xn = mma_tn(f.A, Xc, f.E);                // X+ = Acl X + ecl: the only product on the chain
-                d4 U2 = z;
-                U2[0] = mma4_tn(f.KT, Xc, f.k[0]);        // U = -K X - k (for the gradient and the dudp output)
-                acc += DX[0] * Xc[0] + DX[1] * Xc[1] + DX[2] * Xc[2] + DX[3] * Xc[3] + DU[0] * U2[0];
-                if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + t) * NX * NP, NX, NP, NP, 0, M, lane, Xc);
-                if (dudp) store_dense(dudp + ((int64_t)b * T + t) * NU * NP, NU, NP, NP, 0, M, lane, U2);
-            };
-            d4 Xb;
-            int tl = 0;
-            for (; tl + 3 < cnt; tl += 4) { fstep(tl, X2, Xb, s0, s3); fstep(tl + 1, Xb, X2, s1, s0); fstep(tl + 2, X2, Xb, s2, s1); fstep(tl + 3, Xb, X2, s3, s2); }
-            for (; tl < cnt; ++tl) { fstep(tl, X2, Xb, s0, s3); X2 = Xb; s0 = s1; s1 = s2; s2 = s3; }      // (at most three steps: the sets move up by copies)
-        }
-        wave_lds_sync();
-        if (lane < NX) { double d = xb[T * NX + lane] - dxb[T * NX + lane]; dlT[lane] = d; lsum += d * d; }
-        wave_lds_sync();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { int row = tile_row(lane, r); if (row < NX) acc += dlT[row] * X2[r]; }
-        if (dxdp) store_dense(dxdp + ((int64_t)b * (T + 1) + T) * NX * NP, NX, NP, NP, 0, M, lane, X2);
-        finite = finite && tile_finite(X2);
-    } else {
+    {
         wave_lds_sync();
         for (int i_ = lane; i_ < Mdl::FWD_NCONST; i_ += 64) blk[1 + i_] = Mdl::fwd_const(i_);
         constexpr int DLX = Mdl::FWD_NVAR, DLU = Mdl::FWD_NVAR + NX;      // pool slots of x - x_demo, u - u_demo

@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         bool dead = false;
         int seq = 0;
 #ifdef PDP_MS_TIMING      // timing builds (probes/ms_phase_timing.py): cycles per phase and iteration in the iteration log instead of IPOPT's columns
-        long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0 = 0, tmi = __builtin_readcyclecounter();
+        long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmi = __builtin_readcyclecounter(), tm0 = tmi;
 #define MS2_T0() tm0 = __builtin_readcyclecounter()
 #define MS2_T1(k) do { const long long now_ = __builtin_readcyclecounter(); tm[k] += now_ - tm0; tm0 = now_; } while (0)
 #else
@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             bool pdall = true, ok = true;
             d4 P = z, W2 = z;
             constexpr int RB = 8 * BS;
+            MS2_T1(6);                                   // (timing builds: "sweep prologues" = loop top + the maps above)
             for (int g = 0; g < nchunk && pdall && !dead; ++g) {
                 int t0, cnt;
                 bchunk(g, t0, cnt);
@@ -810,6 +811,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             double acc = 0.0;
             const bool scaledE = hs != 1.0;
             constexpr int RF = 8 * FS;
+            MS2_T1(6);
             for (int c = 0; c < nchunkF && !dead; ++c) {
                 const int g = nchunk + c;
                 int t0, cnt;
@@ -1136,10 +1138,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 finite = fin_p && uni(res[MS2_FIN]) != 0.0;
             } else read_res();
             cur ^= 1;                                   // ... and the trial pass left the point itself in the other set
-            MS2_T1(6);
+            MS2_T1(5);
 #ifdef PDP_MS_TIMING
             if (iter_log && it < op.log_rows && lane == 0) {
-                // first-chunk wait | Riccati steps | later chunk waits | forward steps | dlam tail | line search | update; total of the iteration
+                // first-chunk wait | Riccati steps | later chunk waits | forward steps | dlam tail | line search + update | sweep prologues (loop top, gather / store maps); total of the iteration
                 double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
                 const long long now_ = __builtin_readcyclecounter();
                 for (int k_ = 0; k_ < 7; ++k_) { row[k_] = (double)tm[k_]; tm[k_] = 0; }

@@ -76,7 +76,7 @@ PDP_DEV bool posdef_small(const double* a) {
 #ifndef PDP_RB_T
 #define PDP_RB_T(i)      // timing builds (probes/phase_timing3.py) define it to take a cycle stamp
 #endif
-template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false, bool WANT_PD = false, bool SYM = true>
+template <int M, bool WANT_KT = true, bool HUX_FROM_HX2 = false, bool WANT_PD = false>
 PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 Grep, const d4 Hxx, const d4 HX2, const d4 HU2, double Hux0,
                               double* scratch, int lane, int p0, RiccatiGains& g, d4& P_old_out) {
     const d4 z = zero4();
@@ -174,18 +174,16 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
     g.Zrep = Zrep;
     g.Qux = Qux;
     P = mms_tn_r0(Qux, K, Pn);            // Hxx + F'PF - Qux'K
-    if constexpr (SYM) tile_to_lds17(scratch + 272, P, lane);
+    tile_to_lds17(scratch + 272, P, lane);
     PDP_RB_T(6);
     d4 Wn = mms_tn_r0(Qux, g.IK, FY);     // [Qux' - Qux' I | Wn - Qux' k]
     // columns < M of Wn are Qux' - Qux' (Z Quu): zero only up to the rounding of Z Quu ~ I.  Left in, they perturb P G of the next
     // step and the error compounds over the horizon (quadrotor T = 50: parity lost) - they are masked out.
     W0 = keep_cols(Wn, M, M + p0, lane);
     g.IK = keep_cols(g.IK, M, M + p0, lane);
-    if constexpr (SYM) {
-        wave_lds_sync();
-        PDP_RB_T(7);
-        P = 0.5 * (P + tile_from_lds17_transposed(scratch + 272, lane));
-    }
+    wave_lds_sync();
+    PDP_RB_T(7);
+    P = 0.5 * (P + tile_from_lds17_transposed(scratch + 272, lane));
     PDP_RB_T(8);
     return ok;
 }

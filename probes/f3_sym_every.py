@@ -1,6 +1,7 @@
 """Headline kernel with P <- (P + P')/2 every k-th backward step instead of every step (-DPDP_F3_SYM_EVERY=k, k = 1, 2, 4): time at C3 / C4 shapes and the
 deviation of loss / gradient from the k = 1 build and from the CPU oracle on a few samples.  Libraries: probes/_build/libf3_sym<k>_<system>.so, built by this
-script when missing (hipcc) - build them beforehand in the container and they travel with the snapshot."""
+script when missing (hipcc) - build them beforehand in the container and they travel with the snapshot.
+Since round 6 the switch is no longer in the product headers: apply probes/patches/retired_switches.patch to a scratch copy of the repository first."""
 import sys, os, subprocess, numpy as np
 sys.path.insert(0, os.getcwd())
 from pdp_amd import codegen, zoo

@@ -1,5 +1,5 @@
 """Root-cause experiment for the out-of-bounds reads of lqr_solve_kernel reported in round 1: run a build variant of
-libpdp_hip.so (argv[1]; see the PDP_LQR_* hooks in csrc/pdp_lqr_kernels.h) on GUARD-BANDED operands: every input, output and the
+libpdp_hip.so (argv[1]; the PDP_LQR_* hooks live in probes/patches/retired_switches.patch since round 6) on GUARD-BANDED operands: every input, output and the
 workspace is a view into one NaN-filled allocation, with NaN words directly before and after it.  A read outside an operand that
 reaches the result shows up as NaN / a mismatch against the numpy restatement; all 16 <M, NT> instantiations are exercised."""
 import os, sys

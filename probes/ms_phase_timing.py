@@ -8,7 +8,7 @@ import bench
 EXTRA = [a for a in os.environ.get('PDP_EXTRA', '').split() if a]
 VARIANT = os.environ.get("PDP_MS_VARIANT", "2")
 COLS = (["residuals", "bwd misc", "bwd eval", "riccati", "fwd eval", "fwd steps", "linesearch", "total"] if VARIANT == "1" else
-        ["first-chunk wait", "riccati", "chunk waits", "fwd steps", "dlam tail", "linesearch", "update", "total"])
+        ["first-chunk wait", "riccati", "chunk waits", "fwd steps", "dlam tail", "linesearch+update", "sweep prologues", "total"])
 rng = np.random.default_rng(0)
 for system, B, T in (("cartpole", 256, 50), ("quadrotor", 1024, 50), ("quadrotor", 256, 50)):
     pb = zoo.make_problem(system, 'irl'); _, info = codegen.write_header(pb)

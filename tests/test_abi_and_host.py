@@ -343,3 +343,18 @@ def test_library_stamps_cover_every_included_header(tmp_path):
     s0 = codegen._stamp_of(d0, ["-O3"])
     b.write_text("int b; \n")
     assert codegen._stamp_of(codegen.source_closure(str(a)), ["-O3"]) != s0
+
+
+def test_no_result_changing_macros_in_product_headers():
+    """Round-5 verdict, item 8: build-time switches that change what a kernel computes (or make it fault) live in probes/patches/, not in csrc/."""
+    from pdp_amd import codegen
+    retired = ("PDP_F3_SYM_EVERY", "PDP_LQR_UNGUARDED", "PDP_LQR_STREAM_HUX", "PDP_FUSED_CLOSED_LOOP", "PDP_F3_EXP_GAINS_STEP0", "PDP_F3_EXP_IDLE_EVALUATOR", "PDP_LQS_EXP_NOSTORE")
+    for f in sorted(os.listdir(codegen.CSRC)):
+        if f.endswith((".h", ".hip")):
+            src = open(os.path.join(codegen.CSRC, f)).read()
+            for name in retired:
+                assert name not in src, "%s still mentions %s" % (f, name)
+    patches = os.path.join(os.path.dirname(os.path.dirname(codegen.CSRC)), "probes", "patches")
+    text = "".join(open(os.path.join(patches, p)).read() for p in os.listdir(patches) if p.endswith(".patch"))
+    for name in retired:
+        assert name in text, name
