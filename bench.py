@@ -646,9 +646,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default = config C3)")
-    ap.add_argument("--eager", action="store_true",
-                    help="one ctypes launch per step from Python instead of one hipGraph replay per step (single-GPU default: replay; N > 1 always launches eagerly - "
-                         "the side-stream exchange is not captured)")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: replay the step as a hipGraph (one kernel node) instead of one C-ABI call per step from Python.  Measured in round 6 "
+                         "(profiles/r06_bench_launch_modes.txt): the replay is 3 - 5 us per step SLOWER than back-to-back launches, whose host cost hides under the "
+                         "97 us kernel - so the default stays eager; the option remains for the record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-scaling-configs", action="store_true", help="skip the sharded C4 / C5 measurements (BASELINE configs[3], configs[4])")
@@ -715,18 +716,18 @@ def main():
         pk = og.buffers[0]
         exch_us = 1e3 * _event_ms(torch, lambda: parallel.gather_packed(pk, out=og.gathered[0]), reps=10, warm=2)
 
-    # ---- single GPU: the step recorded once as a hipGraph (one kernel node, same arguments, same buffers) and replayed K times - what pdp_amd.irl.IRLLoop / GDLoop do
-    # for the loops of the reference's drivers: the host's per-step cost (Python wrapper, ctypes marshalling) leaves the timed region.  The eager form is timed beside
-    # it over the same K steps (`launch_modes`); --eager makes it the measured one.
+    # ---- --graph (single GPU): the step recorded once as a hipGraph (one kernel node, same arguments, same buffers) and replayed K times, as pdp_amd.irl.IRLLoop /
+    # GDLoop do for the loops of the reference's drivers.  Round-5 verdict, item 4, asked whether that recovers the gap between the driver's ms_per_step and the kernel
+    # time: it does not - a replay costs MORE than a launch the host issues while the previous kernel runs (see --graph's help) - so this is an option, not the default.
     graph, eager_ms_per_step = None, None
-    if not distributed:
+    if not distributed and args.graph:
         torch.cuda.synchronize()
         te = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         eager_ms_per_step = (time.perf_counter() - te) / args.steps * 1e3
-        if not args.eager:
+        if True:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -825,8 +826,7 @@ def main():
                        "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the next step's kernel" %
                                     ("RCCL" if backend == "nccl" else backend + " (staged through host memory: test mode)")) if distributed else "none (1 GPU)",
                        "launch": "hipGraph replay (one kernel node per step)" if graph is not None else "one C-ABI call per step from Python",
-                       "launch_modes": ({"eager_ms_per_step": eager_ms_per_step, "graph_replay_ms_per_step": dt / args.steps * 1e3 if graph is not None else None}
-                                        if not distributed else None),
+                       "launch_modes": ({"eager_ms_per_step": eager_ms_per_step, "graph_replay_ms_per_step": dt / args.steps * 1e3} if graph is not None else None),
                        "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and world > 1),
                        "collectives_forced_at_world_size_1": bool(distributed and world == 1)},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -28,23 +28,13 @@ def _vec(v):
 
 
 # =============================================================================================================
-class OCSys:
-    """Parametrised optimal control system (reference PDP/PDP.py:57-314)."""
+class _CasadiFrontEnd:
+    """Models stated with real casadi.SX (as every script of the reference does, PDP.py:23; JinEnv/JinEnv.py:19): the symbols handed to set*Variable are mirrored by
+    this package's own, the expressions handed to setDyn / setPathCost / setFinalCost are converted through the Function's instruction tape (casadi_adapter.py);
+    from there on CasADi is not used.  Shared by OCSys, ControlPlanning and SysID (round 6: rounds 4-5 had it on OCSys only).  Operations: what sx.py expresses
+    (+ - * / neg, sq, sqrt, sin, cos, tan, tanh, exp, log, pow with a constant exponent, inv, twice) - OP_FABS / OP_SIGN / OP_ATAN2 / OP_ASIN / OP_ACOS / OP_ATAN /
+    OP_FMIN / OP_FMAX raise NotImplementedError at set time.  Own sx objects pass through untouched."""
 
-    def __init__(self, project_name="my optimal control system"):
-        self.project_name = project_name
-        self._model = None
-        self._bar_model = None
-
-    def _invalidate(self):
-        """the compiled models (problem and log-barrier sub-problem) describe the previous set-up: drop them"""
-        self._model = None
-        self._bar_model = None
-
-    # ---- models stated with real casadi.SX (as every script of the reference does, PDP.py:23): the symbols are mirrored by this package's own, the
-    # expressions converted through the Function's instruction tape (casadi_adapter.py); from there on CasADi is not used.  Scope: OCSys only (SysID and
-    # ControlPlanning take this package's sx objects); operations: what sx.py expresses (+ - * / neg, sq, sqrt, sin, cos, tan, tanh, exp, log, pow with a
-    # constant exponent, inv, twice) - OP_FABS / OP_SIGN / OP_ATAN2 / OP_ASIN / OP_ACOS / OP_ATAN / OP_FMIN / OP_FMAX raise NotImplementedError at setDyn time.
     def _own(self, key, var):
         from . import casadi_adapter as ca
         if not ca.is_casadi(var):
@@ -64,6 +54,20 @@ class OCSys:
         keys = [k for k in keys if k in cv]
         assert keys, "the expression is a CasADi object but no variable was given as one (setStateVariable / setControlVariable / setAuxvarVariable)"
         return ca.convert_expression(expr, [cv[k] for k in keys], [getattr(self, k) for k in keys], name)
+
+
+class OCSys(_CasadiFrontEnd):
+    """Parametrised optimal control system (reference PDP/PDP.py:57-314)."""
+
+    def __init__(self, project_name="my optimal control system"):
+        self.project_name = project_name
+        self._model = None
+        self._bar_model = None
+
+    def _invalidate(self):
+        """the compiled models (problem and log-barrier sub-problem) describe the previous set-up: drop them"""
+        self._model = None
+        self._bar_model = None
 
     # ---- set-up (PDP.py:62-119) -------------------------------------------------------------------------
     def setAuxvarVariable(self, auxvar=None):
@@ -351,7 +355,7 @@ class LQR:
 
 
 # =============================================================================================================
-class ControlPlanning:
+class ControlPlanning(_CasadiFrontEnd):
     """Policy-parametrised optimal control (reference PDP/PDP.py:640-878)."""
 
     def __init__(self, project_name="planner"):
@@ -359,19 +363,19 @@ class ControlPlanning:
         self._model = None
 
     def setStateVariable(self, state, state_lb=[], state_ub=[]):
-        self.state = state
+        self.state = self._own("state", state)
         self.n_state = self.state.numel()
         self.state_lb = state_lb if len(state_lb) == self.n_state else self.n_state * [-1e20]
         self.state_ub = state_ub if len(state_ub) == self.n_state else self.n_state * [1e20]
 
     def setControlVariable(self, control, control_lb=[], control_ub=[]):
-        self.control = control
+        self.control = self._own("control", control)
         self.n_control = self.control.numel()
         self.control_lb = control_lb if len(control_lb) == self.n_control else self.n_control * [-1e20]
         self.control_ub = control_ub if len(control_ub) == self.n_control else self.n_control * [1e20]
 
     def setDyn(self, ode):                                                      # PDP.py:672-680
-        self.dyn = ode
+        self.dyn = self._own_expr(ode, "dynFun", keys=("state", "control"))
         self.dyn_fn = sx.Function("dynFun", [self.state, self.control], [self.dyn])
         self.dfx = jacobian(self.dyn, self.state)
         self.dfx_fn = sx.Function("dfx", [self.state, self.control], [self.dfx])
@@ -380,14 +384,14 @@ class ControlPlanning:
         self._model = None
 
     def setPathCost(self, path_cost):                                           # PDP.py:682-690
-        self.path_cost = path_cost
+        self.path_cost = self._own_expr(path_cost, "pathCost", keys=("state", "control"))
         self.path_cost_fn = sx.Function("pathCost", [self.state, self.control], [self.path_cost])
         self.dcx_fn = sx.Function("dcx", [self.state, self.control], [jacobian(self.path_cost, self.state)])
         self.dcu_fn = sx.Function("dcx", [self.state, self.control], [jacobian(self.path_cost, self.control)])
         self._model = None
 
     def setFinalCost(self, final_cost):                                         # PDP.py:692-697
-        self.final_cost = final_cost
+        self.final_cost = self._own_expr(final_cost, "finalCost", keys=("state",))
         self.final_cost_fn = sx.Function("finalCost", [self.state], [self.final_cost])
         self.dhx_fn = sx.Function("dhx", [self.state], [jacobian(self.final_cost, self.state)])
         self._model = None
@@ -662,7 +666,7 @@ class ControlPlanning:
 
 
 # =============================================================================================================
-class SysID:
+class SysID(_CasadiFrontEnd):
     """System identification (reference PDP/PDP.py:1157-1296)."""
 
     def __init__(self, project_name="my system identification"):
@@ -670,23 +674,23 @@ class SysID:
         self._model = None
 
     def setAuxvarVariable(self, auxvar):
-        self.auxvar = auxvar
+        self.auxvar = self._own("auxvar", auxvar)
         self.n_auxvar = self.auxvar.numel()
 
     def setStateVariable(self, state):
-        self.state = state
+        self.state = self._own("state", state)
         self.n_state = self.state.numel()
         self.state_lb = self.n_state * [-1e20]
         self.state_ub = self.n_state * [1e20]
 
     def setControlVariable(self, control):
-        self.control = control
+        self.control = self._own("control", control)
         self.n_control = self.control.numel()
         self.control_lb = self.n_control * [-1e20]
         self.control_ub = self.n_control * [1e20]
 
     def setDyn(self, ode):                                                      # PDP.py:1178-1188
-        self.dyn = ode
+        self.dyn = self._own_expr(ode, "dyn_fn")
         a = [self.state, self.control, self.auxvar]
         self.dyn_fn = sx.Function("dyn_fn", a, [self.dyn])
         self.dfx = jacobian(self.dyn, self.state)

@@ -261,9 +261,16 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     // PART 2, evaluator: the DUAL half - trial lambda, grad_x L, grad_u L and their measures (used once the point is accepted), then on with the sweep.
     double a_f = 0.0, a_th = 0.0, a_pr = 0.0, a_du = 0.0, a_z = 0.0, a_l = 0.0, a_lc = 0.0;
     bool fin_all = true;
-    auto trial_pass = [&](auto part_tag, double a, int cur, int dst) {
+    double* const xT_park = scratch;                         // x_T of a fused trial pass: the Riccati scratch is idle whenever a trial pass runs (no sweep is in flight)
+    // PART 3, runner: everything, like PART 0, but the sums stay in this wave's registers (a_f .. a_lc, fin_all) and the mailbox's result slots are left alone - the
+    //         prediction guard's pass over the previous solution, which runs BESIDE the evaluator's pass over the predicted point (see the guard).
+    // fuse_fin: the terminal node's lane leaves the terminal gradient h_x(x_T) - lambda_T in `dlT` and parks x_T in LDS - what the terminal stage of the sweep at the
+    //         trial point starts from.  The sweep used to fetch both again from memory with ONE lane: 26 loads and their latency in front of the first chunk
+    //         (6 k cycles per iteration at C3, profiles/r06_ms2_phase_timing.txt).  Same values, bit for bit.  (eval_fin itself runs behind the pass: inside it,
+    //         its temporaries pushed the four-trajectory instantiation over its 256 registers.)
+    auto trial_pass = [&](auto part_tag, double a, int cur, int dst, bool fuse_fin) {
         constexpr int PART = decltype(part_tag)::value;
-        constexpr bool PRIMAL = PART != 2, DUAL = PART != 1;
+        constexpr bool PRIMAL = PART != 2, DUAL = PART != 1, KEEP = PART == 3;
         PDP_MS2_PAR();
         const bool stepped = a != 0.0, put = dst != cur;
         const double* __restrict__ ps = Pt(cur);
@@ -339,6 +346,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
                     a_du = fmax(a_du, node ? fabs(g) : 0.0);
                     fin = fin && (!node || fabs(g) <= 1.7e308);
+                    hT[i] = g;
+                }
+                if (last && fuse_fin) {                                  // (one lane: the terminal gradient where the sweep wants it, x_T parked for eval_fin)
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) { dlT[i] = hT[i]; xT_park[i] = xc[i]; }
                 }
                 double hu[NU];
                 Mdl::dHu(xc, uc, lc, th, pc, hu);
@@ -349,7 +361,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         if constexpr (PRIMAL) { a_f = wave_sum(a_f); a_th = wave_sum(a_th); a_lc = wave_sum(a_lc); a_pr = wave_max(a_pr); a_z = wave_max(a_z); }
         if constexpr (DUAL) { a_du = wave_max(a_du); a_l = wave_max(a_l); }
         fin_all = __all(fin);
-        if constexpr (DUAL) {                                        // (the runner keeps its half in registers)
+        if constexpr (DUAL && !KEEP) {                               // (the runner keeps its half - PART 3: all of it - in registers)
             if (lane == 0) {
                 if constexpr (PRIMAL) { res[MS2_F] = a_f; res[MS2_TH] = a_th; res[MS2_PR] = a_pr; res[MS2_Z] = a_z; res[MS2_LC] = a_lc; }
                 res[MS2_DU] = a_du; res[MS2_L] = a_l;
@@ -364,6 +376,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     using PartAll = std::integral_constant<int, 0>;
     using PartPrimal = std::integral_constant<int, 1>;
     using PartDual = std::integral_constant<int, 2>;
+    using PartKeep = std::integral_constant<int, 3>;
 
     if (runner) {
         // ================================================ runner ================================================
@@ -905,24 +918,27 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         const bool g_primal = rec ? recp : !predl;
         double g_f = 0.0, g_th = 0.0, g_pr = 0.0, g_du = 0.0, g_z = 0.0, g_l = 0.0, g_lc = 0.0, g_err = 0.0;
         bool g_fin = false;
+        // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays).  Unless the point has to be built first
+        // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
+        // the trial half is done and finds chunk 0 of the sweep already under way instead of asking for it then
+        if (from_u) issue(MS2_CMD_RESTORE, 0.0, cur, cur);
+        else if constexpr (SPLIT) issue(MS2_CMD_TRIAL, 0.0, cur, cur);      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
+        else issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur);
         if (guard) {
+            // ... and while the evaluator is on the predicted point, THIS wave evaluates the previous solution (round 6; until then both passes ran on the evaluator,
+            // one behind the other, with the runner asleep: +11 us per solve at C3).  Two VALU-bound waves on one SIMD take ~1.4 x the time of one, not 2 x
+            // (profiles/r02_probe_two_waves_per_simd.txt).  The sums stay in registers (PART 3); the residual arrays of set 1 are written as by any other pass.
             double* s1 = Pt(1);
             for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : xb[q]; }
             for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s1[OU + i * TS + t] = ub[q]; }
             for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[OL + i * TS + t] = lb[q]; }
-            issue(MS2_CMD_TRIAL, 0.0, 1, 1);
-            if constexpr (SPLIT) { /* (a plain TRIAL is evaluated by the evaluator alone in both forms) */ }
-            wait_done();
-            read_res();
-            g_f = f_cur; g_th = th_cur; g_pr = inf_pr; g_du = inf_du; g_z = zmax; g_l = lmax; g_lc = lamc; g_fin = finite;
-            g_err = g_primal ? inf_pr / (1.0 + zmax) : fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
+            __threadfence_block();
+            trial_pass(PartKeep{}, 0.0, 1, 1, false);
+            g_f = a_f; g_th = a_th; g_pr = a_pr; g_du = a_du; g_z = a_z; g_l = a_l; g_lc = a_lc; g_fin = fin_all;
+            g_err = g_primal ? g_pr / (1.0 + g_z) : fmax(g_pr / (1.0 + g_z), g_du / (1.0 + g_l));
         }
-        // residuals of the starting point (both phases: the phase-0 sweep takes its right-hand sides from the same arrays).  Unless the point has to be built first
-        // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
-        // the trial half is done and finds chunk 0 of the sweep already under way instead of asking for it then
-        if (from_u) { issue(MS2_CMD_RESTORE, 0.0, cur, cur); wait_done(); }
-        else if constexpr (SPLIT) { issue(MS2_CMD_TRIAL, 0.0, cur, cur); wait_done(); }      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
-        else { issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur); wait_slot(MS2_TDONE); pending = true; }
+        if (from_u || SPLIT) wait_done();
+        else { wait_slot(MS2_TDONE); pending = true; }
         read_res();
         if (guard && !dead) {
             const double p_err = g_primal ? inf_pr / (1.0 + zmax) : fmax(inf_pr / (1.0 + zmax), inf_du / (1.0 + lmax));
@@ -1038,7 +1054,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const double a_try = soc_mode ? 1.0 : alpha;           // (a corrected step is taken in full: no bounds, no fraction-to-the-boundary rule)
                 issue(MS2_CMD_TRIAL_SWEEP, a_try, cur, cur ^ 1);
                 if constexpr (SPLIT) {
-                    trial_pass(PartPrimal{}, a_try, cur, cur ^ 1); // this wave's half: (theta, phi) of the trial point - all the filter asks for
+                    trial_pass(PartPrimal{}, a_try, cur, cur ^ 1, false); // this wave's half: (theta, phi) of the trial point - all the filter asks for
                     fin_p = fin_all;
                     f3_signal(ctl + MS2_PDONE, seq);               // release: trial (x, u) and defects are in memory
                     ft = a_f; tht = a_th;
@@ -1312,6 +1328,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         };
         using Cap1 = std::integral_constant<int, L::BUF>;
         using Cap2 = std::integral_constant<int, 2 * L::BUF>;
+        if (lane == 0) fin[0] = 0.0;                            // [0.0 | terminal constants | terminal entries]: the first two never change
+        for (int i = lane; i < Mdl::FIN_NCONST; i += 64) fin[1 + i] = Mdl::fin_const(i);
         for (;;) {
             if (!ms2_wait_ge(ctl + MS2_SEQ, last + 1, ctl)) break;
             last = ms2_load(ctl + MS2_SEQ);
@@ -1322,8 +1340,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             MS2_E0();
             if (type == MS2_CMD_RESTORE) restore(cur);
             if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP || type == MS2_CMD_RESTORE) {
-                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP) trial_pass(PartDual{}, alpha, cur, dst);       // (the line search: the runner does the primal half meanwhile)
-                else trial_pass(PartAll{}, alpha, cur, dst);
+                const bool fuse = type == MS2_CMD_TRIAL_SWEEP;           // the sweep that follows linearises at this very point: its terminal stage comes out of the pass
+                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP) trial_pass(PartDual{}, alpha, cur, dst, fuse);       // (the line search: the runner does the primal half meanwhile)
+                else trial_pass(PartAll{}, alpha, cur, dst, fuse);
                 __threadfence_block();
                 MS2_E1(0);
 #ifdef PDP_MS_TIMING
@@ -1341,14 +1360,17 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const double* __restrict__ cdef = (type == MS2_CMD_SWEEP && csrc) ? csoc : rd + OL;       // defects of the point, or the constraint block of a second-order correction
                 bool aborted = false;
                 auto stop = [&]() { aborted = aborted || ms2_load(ctl + MS2_ABORT) == last; return aborted || dead; };
-                // terminal stage: hxx(x_T) entries and the terminal gradient
-                if (lane == 0) fin[0] = 0.0;
-                for (int i = lane; i < Mdl::FIN_NCONST; i += 64) fin[1 + i] = Mdl::fin_const(i);
+                // terminal stage: hxx(x_T) entries and the terminal gradient (a TRIAL_SWEEP's trial pass has left the gradient in place and x_T in LDS: fuse_fin)
                 if (lane == 0) {
                     PDP_MS2_PAR();
                     double xT[NX];
+                    if (type == MS2_CMD_SWEEP) {
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
+                        for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) xT[i] = xT_park[i];
+                    }
                     PackedSink s{fin + L::NCFIN};
                     Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
                 }

@@ -63,6 +63,27 @@ def main():
     with open(os.path.join(HERE, "casadi_tape_handwritten.json"), "w") as fh:
         json.dump(hand, fh, indent=0)
     print("wrote", len(tape["instructions"]), "and", len(I), "instructions")
+    # round 6: one ControlPlanning and one SysID model, one tape PER EXPRESSION - what OCSys / ControlPlanning / SysID build when they are handed casadi.SX objects
+    # (casadi.Function(name, [the variables the expression may depend on], [expr]), PDP.py:672-697, 1178-1188): quadrotor, Examples/OC/quadrotor/uav_PDP.py:9-21 and
+    # Examples/SysID/quadrotor/uav_PDP.py
+    env, dt = zoo.make_env("quadrotor", "oc")
+    names = {"dyn": ("dynFun", [env.X, env.U], env.X + dt * env.f), "path_cost": ("pathCost", [env.X, env.U], env.path_cost),
+             "final_cost": ("finalCost", [env.X], env.final_cost)}
+    out = {}
+    for key, (nm, ins, ex) in names.items():
+        t = ca.tape_of(sx.Function(nm, ins, [ex]))
+        for d, n_ in zip(t["in"], ("state", "control")):
+            d["name"] = n_
+        out[key] = t
+    with open(os.path.join(HERE, "casadi_tape_quadrotor_cp.json"), "w") as fh:
+        json.dump(out, fh, separators=(",", ":"))
+    env, dt = zoo.make_env("quadrotor", "sysid")
+    t = ca.tape_of(sx.Function("dyn_fn", [env.X, env.U, env.dyn_auxvar], [env.X + dt * env.f]))
+    for d, n_ in zip(t["in"], ("state", "control", "auxvar")):
+        d["name"] = n_
+    with open(os.path.join(HERE, "casadi_tape_quadrotor_sysid.json"), "w") as fh:
+        json.dump({"dyn": t}, fh, separators=(",", ":"))
+    print("wrote the quadrotor ControlPlanning / SysID tapes:", {k: len(v["instructions"]) for k, v in out.items()}, len(t["instructions"]))
 
 
 if __name__ == "__main__":

@@ -104,3 +104,99 @@ def test_live_casadi_function():
     oc.setPathCost(cost)
     oc.setFinalCost(casadi.dot(x, x))
     assert np.allclose(oc.dyn_fn(xv, uv, pv).full().ravel(), np.asarray(fn(xv, uv, pv)[0].full()).ravel(), rtol=1e-14)
+
+
+# ---- round 6: CasADi objects at the ControlPlanning and SysID class surface (PDP/PDP.py:672-697, 1178-1188 take casadi.SX) ------------------------------------------
+class _ReplaySX:
+    """What the class surface sees of a casadi.SX: a type that lives in module `casadi`, numel(), and - for an expression - the recorded tape of the casadi.Function
+    the reference would wrap it in.  CasADi is absent from the build image: the stand-in answers `casadi.Function(name, vars, [expr])` with that tape, so that
+    _CasadiFrontEnd._own / _own_expr, the variable bookkeeping and casadi_adapter.convert_expression run exactly as with the real module."""
+    __module__ = "casadi"
+
+    def __init__(self, n, tape=None, deps=()):
+        self.n, self.tape, self.deps = n, tape, tuple(deps)
+
+    def numel(self):
+        return self.n
+
+
+def _replay_casadi(monkeypatch):
+    import sys
+    import types
+    from pdp_amd import casadi_adapter as ca
+    mod = types.ModuleType("casadi")
+
+    def Function(name, ins, outs):
+        (expr,) = outs
+        assert isinstance(expr, _ReplaySX) and expr.tape is not None
+        assert len(ins) == len(expr.deps) and all(a is b for a, b in zip(ins, expr.deps)), "the Function is built over the variables the expression was recorded in"
+        return ca.RecordedTape(dict(expr.tape, name=name))
+    mod.Function = Function
+    mod.SX = _ReplaySX
+    monkeypatch.setitem(sys.modules, "casadi", mod)
+    return mod
+
+
+def _same_model(info, native):
+    """The class surface mirrors the CasADi symbols by FRESH symbols of its own, and sx.py orders the operands of commutative operations by node id: the generated
+    source then lists `u[1] + u[0]` where the native model has `u[0] + u[1]` - another content hash, the same arithmetic bit for bit (the tests compare values and
+    Jacobians with array_equal).  What must agree is everything the code generator derives from the DAG: sizes, distinct non-zero entries and constants of every
+    matrix group, theta-only precomputed values, operation counts, LDS chunking.  (On the native symbols the hash itself agrees: the cart-pole test above.)"""
+    assert {k: v for k, v in info.items() if k != "name"} == {k: v for k, v in native.items() if k != "name"}
+
+
+def test_casadi_objects_at_the_controlplanning_surface(golden_dir, monkeypatch):
+    """ControlPlanning built from casadi.SX symbols and expressions (recorded tapes of the quadrotor model of Examples/OC/quadrotor/uav_PDP.py:9-21): the model that
+    arrives is the native one (_same_model; values and Jacobians bit for bit), policies and Jacobian Functions are built on the mirrored symbols."""
+    from pdp_amd import PDP, codegen, sx, zoo
+    _replay_casadi(monkeypatch)
+    tapes = json.load(open(os.path.join(golden_dir, "casadi_tape_quadrotor_cp.json")))
+    X, U = _ReplaySX(13), _ReplaySX(4)
+    cp = PDP.ControlPlanning("quadrotor")
+    cp.setStateVariable(X)
+    cp.setControlVariable(U)
+    assert isinstance(cp.state, sx.SX) and cp.n_state == 13 and cp.n_control == 4 and cp._casadi_vars == {"state": X, "control": U}
+    cp.setDyn(_ReplaySX(13, tapes["dyn"], (X, U)))
+    cp.setPathCost(_ReplaySX(1, tapes["path_cost"], (X, U)))
+    cp.setFinalCost(_ReplaySX(1, tapes["final_cost"], (X,)))
+    pb = codegen.Problem(codegen.KIND_CP, cp.state, cp.control, cp.dyn, None, cp.path_cost, cp.final_cost, label="quadrotor")
+    _same_model(codegen.generate(pb)[1], codegen.generate(zoo.make_problem("quadrotor", "oc"))[1])
+    env, dt = zoo.make_env("quadrotor", "oc")
+    native = sx.Function("n", [env.X, env.U], [env.X + dt * env.f, env.path_cost, sx.jacobian(env.X + dt * env.f, env.X), sx.jacobian(env.path_cost, env.U)])
+    rng = np.random.default_rng(3)
+    x, u = rng.standard_normal(13), rng.standard_normal(4)
+    for a, b in zip(native(x, u), (cp.dyn_fn(x, u), cp.path_cost_fn(x, u), cp.dfx_fn(x, u), cp.dcu_fn(x, u))):
+        assert np.array_equal(a.full(), b.full())
+    cp.init_step(50)                                               # the Lagrange policy is stated on the mirrored symbols
+    assert cp.n_auxvar == 24
+    # an own sx object after a CasADi one drops the stale mapping; a CasADi expression without CasADi variables is refused
+    cp.setControlVariable(sx.SX.sym("u", 4))
+    assert "control" not in cp._casadi_vars
+    cp2 = PDP.ControlPlanning("x")
+    cp2.setStateVariable(sx.SX.sym("x", 13))
+    cp2.setControlVariable(sx.SX.sym("u", 4))
+    with pytest.raises(AssertionError, match="no variable was given"):
+        cp2.setDyn(_ReplaySX(13, tapes["dyn"], (X, U)))
+
+
+def test_casadi_objects_at_the_sysid_surface(golden_dir, monkeypatch):
+    """SysID.setDyn with casadi.SX (PDP.py:1178-1188): the quadrotor model of Examples/SysID/quadrotor through its recorded tape = the native model (_same_model; f, f_x,
+    f_theta bit for bit)."""
+    from pdp_amd import PDP, codegen, sx, zoo
+    _replay_casadi(monkeypatch)
+    tape = json.load(open(os.path.join(golden_dir, "casadi_tape_quadrotor_sysid.json")))["dyn"]
+    X, U, P = _ReplaySX(13), _ReplaySX(4), _ReplaySX(5)
+    sid = PDP.SysID("quadrotor")
+    sid.setAuxvarVariable(P)
+    sid.setStateVariable(X)
+    sid.setControlVariable(U)
+    sid.setDyn(_ReplaySX(13, tape, (X, U, P)))
+    pb = codegen.Problem(codegen.KIND_SYSID, sid.state, sid.control, sid.dyn, sid.auxvar, label="quadrotor")
+    _same_model(codegen.generate(pb)[1], codegen.generate(zoo.make_problem("quadrotor", "sysid"))[1])
+    env, dt = zoo.make_env("quadrotor", "sysid")
+    dyn = env.X + dt * env.f
+    native = sx.Function("n", [env.X, env.U, env.dyn_auxvar], [dyn, sx.jacobian(dyn, env.X), sx.jacobian(dyn, env.dyn_auxvar)])
+    rng = np.random.default_rng(4)
+    x, u, th = rng.standard_normal(13), rng.standard_normal(4), np.array([1.0, 1.1, 0.9, 1.2, 0.4])
+    for a, b in zip(native(x, u, th), (sid.dyn_fn(x, u, th), sid.dfx_fn(x, u, th), sid.dfe_fn(x, u, th))):
+        assert np.array_equal(a.full(), b.full())
