@@ -403,8 +403,11 @@ class ModelLib:
         if warm is not None:
             assert u_init is None, "warm and u_init exclude each other"
             if consume_warm:        # in place: the caller's tensors ARE the outputs - a silent copy would leave an IRL loop re-solving from a stale point
-                for a in warm:
-                    assert torch.is_tensor(a) and a.is_cuda and a.dtype == torch.float64 and a.is_contiguous(), "consume_warm needs contiguous fp64 CUDA tensors"
+                for a in warm:          # (an exception, not an assert: under `python -O` the silent copy would come back)
+                    if not (torch.is_tensor(a) and a.is_cuda and a.dtype == torch.float64 and a.is_contiguous()):
+                        raise TypeError("oc_solve_ms(consume_warm=True) works IN PLACE on the warm start: state, control and costate must be contiguous fp64 CUDA tensors "
+                                        "(got %s); pass consume_warm=False to start from a copy of anything dev() converts" % (type(a).__name__ if not torch.is_tensor(a)
+                                        else "%s %s tensor, contiguous=%s" % (a.device.type, a.dtype, a.is_contiguous())))
                 x, u, lam = warm
             else:
                 x, u, lam = (dev(a).clone().contiguous() for a in warm)
