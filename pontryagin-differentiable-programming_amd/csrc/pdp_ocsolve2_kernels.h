@@ -261,14 +261,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     // PART 2, evaluator: the DUAL half - trial lambda, grad_x L, grad_u L and their measures (used once the point is accepted), then on with the sweep.
     double a_f = 0.0, a_th = 0.0, a_pr = 0.0, a_du = 0.0, a_z = 0.0, a_l = 0.0, a_lc = 0.0;
     bool fin_all = true;
-    double* const xT_park = scratch;                         // x_T of a fused trial pass: the Riccati scratch is idle whenever a trial pass runs (no sweep is in flight)
     // PART 3, runner: everything, like PART 0, but the sums stay in this wave's registers (a_f .. a_lc, fin_all) and the mailbox's result slots are left alone - the
     //         prediction guard's pass over the previous solution, which runs BESIDE the evaluator's pass over the predicted point (see the guard).
-    // fuse_fin: the terminal node's lane leaves the terminal gradient h_x(x_T) - lambda_T in `dlT` and parks x_T in LDS - what the terminal stage of the sweep at the
-    //         trial point starts from.  The sweep used to fetch both again from memory with ONE lane: 26 loads and their latency in front of the first chunk
-    //         (6 k cycles per iteration at C3, profiles/r06_ms2_phase_timing.txt).  Same values, bit for bit.  (eval_fin itself runs behind the pass: inside it,
-    //         its temporaries pushed the four-trajectory instantiation over its 256 registers.)
-    auto trial_pass = [&](auto part_tag, double a, int cur, int dst, bool fuse_fin) {
+    auto trial_pass = [&](auto part_tag, double a, int cur, int dst) {
         constexpr int PART = decltype(part_tag)::value;
         constexpr bool PRIMAL = PART != 2, DUAL = PART != 1, KEEP = PART == 3;
         PDP_MS2_PAR();
@@ -346,11 +341,6 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
                     a_du = fmax(a_du, node ? fabs(g) : 0.0);
                     fin = fin && (!node || fabs(g) <= 1.7e308);
-                    hT[i] = g;
-                }
-                if (last && fuse_fin) {                                  // (one lane: the terminal gradient where the sweep wants it, x_T parked for eval_fin)
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) { dlT[i] = hT[i]; xT_park[i] = xc[i]; }
                 }
                 double hu[NU];
                 Mdl::dHu(xc, uc, lc, th, pc, hu);
@@ -372,7 +362,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     // The split pays where the two halves are comparable and the runner has registers to spare - the small systems (cart-pole cold solve 4.18 -> 3.94 ms).  For the
     // tile forms it does not: the quadrotor's trial pass is mostly `dyn`, and inside the runner's register allocation (256 VGPRs, gather maps of both sweeps live)
     // that half alone took longer than the whole pass on the evaluator (line search 23 k -> 30 k cycles, spills into the sweeps: 0.318 -> 0.340 ms; profiles/r03_ms2_variants.txt)
-    constexpr bool SPLIT = SMALL;
+#ifndef PDP_MS2_SPLIT_ALL
+#define PDP_MS2_SPLIT_ALL 0             // 1: the tile forms (n > 4) share the line search's trial pass between the two waves as well - measured slower twice (profiles/r06_ms2_variants.txt)
+#endif
+    constexpr bool SPLIT = SMALL || PDP_MS2_SPLIT_ALL;      // the line search's trial pass shared between the two waves
+    constexpr bool SPLIT0 = SMALL;                           // ... and no speculative first sweep at the starting point (small systems)
     using PartAll = std::integral_constant<int, 0>;
     using PartPrimal = std::integral_constant<int, 1>;
     using PartDual = std::integral_constant<int, 2>;
@@ -922,22 +916,22 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // (RESTORE), the evaluator goes straight on with the first sweep at it (TRIAL_SWEEP with alpha = 0, source = destination): the runner reads the residuals when
         // the trial half is done and finds chunk 0 of the sweep already under way instead of asking for it then
         if (from_u) issue(MS2_CMD_RESTORE, 0.0, cur, cur);
-        else if constexpr (SPLIT) issue(MS2_CMD_TRIAL, 0.0, cur, cur);      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
+        else if constexpr (SPLIT0) issue(MS2_CMD_TRIAL, 0.0, cur, cur);      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
         else issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur);
         if (guard) {
             // ... and while the evaluator is on the predicted point, THIS wave evaluates the previous solution (round 6; until then both passes ran on the evaluator,
-            // one behind the other, with the runner asleep: +11 us per solve at C3).  Two VALU-bound waves on one SIMD take ~1.4 x the time of one, not 2 x
+            // one behind the other, with the runner asleep: +13 us per solve at C3, now +10).  Two VALU-bound waves on one SIMD take ~1.4 x the time of one, not 2 x
             // (profiles/r02_probe_two_waves_per_simd.txt).  The sums stay in registers (PART 3); the residual arrays of set 1 are written as by any other pass.
             double* s1 = Pt(1);
             for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : xb[q]; }
             for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s1[OU + i * TS + t] = ub[q]; }
             for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[OL + i * TS + t] = lb[q]; }
             __threadfence_block();
-            trial_pass(PartKeep{}, 0.0, 1, 1, false);
+            trial_pass(PartKeep{}, 0.0, 1, 1);
             g_f = a_f; g_th = a_th; g_pr = a_pr; g_du = a_du; g_z = a_z; g_l = a_l; g_lc = a_lc; g_fin = fin_all;
             g_err = g_primal ? g_pr / (1.0 + g_z) : fmax(g_pr / (1.0 + g_z), g_du / (1.0 + g_l));
         }
-        if (from_u || SPLIT) wait_done();
+        if (from_u || SPLIT0) wait_done();
         else { wait_slot(MS2_TDONE); pending = true; }
         read_res();
         if (guard && !dead) {
@@ -1054,7 +1048,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const double a_try = soc_mode ? 1.0 : alpha;           // (a corrected step is taken in full: no bounds, no fraction-to-the-boundary rule)
                 issue(MS2_CMD_TRIAL_SWEEP, a_try, cur, cur ^ 1);
                 if constexpr (SPLIT) {
-                    trial_pass(PartPrimal{}, a_try, cur, cur ^ 1, false); // this wave's half: (theta, phi) of the trial point - all the filter asks for
+                    trial_pass(PartPrimal{}, a_try, cur, cur ^ 1); // this wave's half: (theta, phi) of the trial point - all the filter asks for
                     fin_p = fin_all;
                     f3_signal(ctl + MS2_PDONE, seq);               // release: trial (x, u) and defects are in memory
                     ft = a_f; tht = a_th;
@@ -1328,8 +1322,6 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         };
         using Cap1 = std::integral_constant<int, L::BUF>;
         using Cap2 = std::integral_constant<int, 2 * L::BUF>;
-        if (lane == 0) fin[0] = 0.0;                            // [0.0 | terminal constants | terminal entries]: the first two never change
-        for (int i = lane; i < Mdl::FIN_NCONST; i += 64) fin[1 + i] = Mdl::fin_const(i);
         for (;;) {
             if (!ms2_wait_ge(ctl + MS2_SEQ, last + 1, ctl)) break;
             last = ms2_load(ctl + MS2_SEQ);
@@ -1340,9 +1332,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             MS2_E0();
             if (type == MS2_CMD_RESTORE) restore(cur);
             if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP || type == MS2_CMD_RESTORE) {
-                const bool fuse = type == MS2_CMD_TRIAL_SWEEP;           // the sweep that follows linearises at this very point: its terminal stage comes out of the pass
-                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP) trial_pass(PartDual{}, alpha, cur, dst, fuse);       // (the line search: the runner does the primal half meanwhile)
-                else trial_pass(PartAll{}, alpha, cur, dst, fuse);
+                const bool shared = SPLIT && type == MS2_CMD_TRIAL_SWEEP && dst != cur;      // (the starting point's TRIAL_SWEEP has dst == cur: all of it here)
+                if (shared) trial_pass(PartDual{}, alpha, cur, dst);       // (the line search: the runner does the primal half meanwhile)
+                else trial_pass(PartAll{}, alpha, cur, dst);
                 __threadfence_block();
                 MS2_E1(0);
 #ifdef PDP_MS_TIMING
@@ -1351,7 +1343,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #endif
                 f3_signal(ctl + MS2_TDONE, last);
                 // the sweep below reads the trial (x, u) and the defects the runner's half of the pass writes
-                if (SPLIT && type == MS2_CMD_TRIAL_SWEEP && !ms2_wait_ge(ctl + MS2_PDONE, last, ctl)) break;
+                if (shared && !ms2_wait_ge(ctl + MS2_PDONE, last, ctl)) break;
             }
             if (type == MS2_CMD_SWEEP || type == MS2_CMD_TRIAL_SWEEP) {
                 const int sw = type == MS2_CMD_SWEEP ? cur : dst;          // the set the sweep linearises at
@@ -1360,17 +1352,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const double* __restrict__ cdef = (type == MS2_CMD_SWEEP && csrc) ? csoc : rd + OL;       // defects of the point, or the constraint block of a second-order correction
                 bool aborted = false;
                 auto stop = [&]() { aborted = aborted || ms2_load(ctl + MS2_ABORT) == last; return aborted || dead; };
-                // terminal stage: hxx(x_T) entries and the terminal gradient (a TRIAL_SWEEP's trial pass has left the gradient in place and x_T in LDS: fuse_fin)
+                // terminal stage: hxx(x_T) entries and the terminal gradient
+                if (lane == 0) fin[0] = 0.0;
+                for (int i = lane; i < Mdl::FIN_NCONST; i += 64) fin[1 + i] = Mdl::fin_const(i);
                 if (lane == 0) {
                     PDP_MS2_PAR();
                     double xT[NX];
-                    if (type == MS2_CMD_SWEEP) {
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) xT[i] = xT_park[i];
-                    }
+                    for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
                     PackedSink s{fin + L::NCFIN};
                     Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
                 }
