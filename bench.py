@@ -183,6 +183,45 @@ def _event_ms(torch, fn, reps=10, warm=2):
     return Ms(ms, (len(WINDOWS) - 1,))
 
 
+def oc_solve_model(n, m, T, newton_iterations, residual_passes, B, ms):
+    """Flop / byte model of one multiple-shooting solve (pdp_oc_solve_ms_batched; reference: PDP/PDP.py:121-220 hands this NLP to IPOPT) and the roofline figures it gives
+    a measured launch.  Per Newton iteration and trajectory, dense unpadded counts of the formulation the kernel runs (model evaluation - the
+    KKT matrices and residuals, ~1.1 kflop per stage for the quadrotor - excluded, as SURVEY.md section 8d excludes it for the gradient unit):
+      backward (homogeneous Riccati step, NA = n + 1 rows): P~F~ and F~'(P~F~) 2 x 2 NA^3, P~G~, G~'(P~F~) and Qux~'K~ 3 x 2 NA^2 m, G'PG and Quu^-1 Qux~ 2 x 2 NA m^2,
+                the m x m inverse 2 m^3, the symmetrisation NA^2;
+      forward:  K~x~ 2 m NA, F~x~ and x~'P~ 2 x 2 NA^2, G(K~x~) 2 n m, the directional derivative 2 (n + m).
+    Executed on the matrix pipe (tiles padded to 16): 13 + 5 v_mfma_f64_16x16x4 (2048 flop, 64 cycles of issue) and 9 + 8 v_mfma_f64_4x4x4_4b (512 flop, ~28 cycles) per stage
+    for 4 < n < 16; 10 + 3 of the small form alone for n <= 4.
+    Bytes (fp64, every array of the solver's workspace read or written once per use, per iteration): the chunk evaluations read the point and its residuals (2 groups of
+    (2 n + m)(T + 1)), the forward sweep writes the step (1 group), the residual pass of the line search reads point + step and writes the trial point + its residuals
+    (4 groups), the sweeps write and re-read the per-stage records (gains m NA + upper triangle of P~ NA (NA + 1) / 2); each further residual pass (starting point, guard)
+    2 - 4 groups more.  For C3 this model gives 214 KB per iteration and trajectory, 540 MB per two-iteration launch of 1024 against the 499 MB the counters
+    measured (profiles/traffic.json): the solver moves what its algorithm asks for and no more, and that traffic lives in L2 / Infinity Cache."""
+    small = n <= 4
+    NA = n if (small or n >= 16) else n + 1
+    bwd = 2 * 2 * NA ** 3 + 3 * 2 * NA * NA * m + 2 * 2 * NA * m * m + 2 * m ** 3 + NA * NA
+    fwd = 2 * m * NA + 2 * 2 * NA * NA + 2 * n * m + 2 * (n + m)
+    flop_it = T * (bwd + fwd)
+    if small:
+        mfma_flop_it, mfma_cycles_it = T * 13 * 512, T * 13 * 28
+    else:
+        mfma_flop_it, mfma_cycles_it = T * ((13 + 5) * 2048 + (9 + 8) * 512), T * ((13 + 5) * 64 + (9 + 8) * 28)
+    grp = (2 * n + m) * (T + 1)
+    rec = T * (m * NA + NA * (NA + 1) // 2)
+    bytes_it = 8 * (7 * grp + 2 * rec)
+    byts = newton_iterations * bytes_it + residual_passes * 8 * 3 * grp + 8 * 2 * grp          # + the extra residual passes, the API arrays in and out
+    flop = newton_iterations * flop_it
+    t = ms * 1e-3
+    return {"bound": "latency (two serial MFMA chains per Newton iteration and trajectory: backward Riccati steps, forward steps)",
+            "newton_iterations": newton_iterations, "algorithmic_flop_per_solve": flop, "achieved_tflops": flop * B / t / 1e12,
+            "frac_of_fp64_mfma_peak": flop * B / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "executed_mfma_flop_per_solve": newton_iterations * mfma_flop_it, "executed_mfma_tflops": newton_iterations * mfma_flop_it * B / t / 1e12,
+            "executed_mfma_frac_of_peak": newton_iterations * mfma_flop_it * B / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "mfma_issue_cycles_per_iteration": mfma_cycles_it,
+            "algorithmic_bytes_per_solve": byts, "achieved_gbps": byts * B / t / 1e9, "frac_of_hbm_peak": byts * B / t / 1e9 / HBM_PEAK_GBPS,
+            "note": "priced on the mean number of Newton iterations of the launch; see bench.oc_solve_model for the counts"}
+
+
 def other_configs(torch):
     """The other BASELINE.json configurations on this GPU (single-GPU shards of C4 / C5), the complete IRL iterations of C2 / C3
     (OC solve + gradient) and the reference's materialised API route.  Per entry: kernel_ms (median HIP-event time of the call),
@@ -331,13 +370,14 @@ def other_configs(torch):
         entry(key, B, solve_ms + grad_sens_ms, flop=flop, T=T, latency_bound=(system == "cartpole"),
               note="per-sample theta = theta* +- 5 %% (C2) / 2 %% (C3); one IRL iteration = first-order prediction of the starting point from the previous iteration's "
                    "sensitivities (PDP_MS_PREDICT: applied inside the solver launch from the packed fp32 prediction record - the kind named in prediction_record_kind) + OC solve from it (pdp_oc_solve_ms_batched) + fused aux / "
-                   "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); the flop figure is section 8d's for the gradient unit "
-                   "(it has none for the solve)",
+                   "Riccati / gradient unit writing that record for the next prediction (pdp_oc_pdp_grad_sens_batched); frac prices the iteration on section 8d's figure for the gradient "
+                   "unit alone (it has none for the solve) - the solve is priced on its own model in oc_solve_roofline and in the *_oc_solve_* entry",
               extra={"oc_solve_ms": solve_ms, "oc_solve_ms_without_the_prediction_guard": unguarded_ms, "predictions_rejected_by_the_guard": rejected,
                      "prediction_as_a_launch_of_its_own_ms": predict_ms, "gradient_ms": grad_sens_ms, "gradient_ms_without_sensitivity_outputs": grad_ms,
                      "irl_loop_wall_clock": loop_res, "prediction_record_kind": record_kind, "prediction_includes_multipliers": record_kind == "full", "pipelines_by_record_kind": kinds,
                      "prediction_record_bytes": int(sens0["predict_record"].numel() * 4) if record_kind == "full" else int(B * T * (mdl.n + mdl.m) * mdl.p * 4), "oc_solve_converged": int(sol["converged"].sum()),
                      "oc_solve_iterations_mean_max": [float(it.mean()), float(it.max())], "oc_solves_per_s_warm": B / (solve_ms * 1e-3),
+                     "oc_solve_roofline": oc_solve_model(mdl.n, mdl.m, T, float(it.mean()), 2.0 if rejected == 0 else 2.0, B, float(solve_ms)),
                      "solution_agrees_with_plain_warm_start_rel": agree,
                      "round3_pipeline_plain_warm_start": {"oc_solve_ms": plain_ms, "gradient_ms": grad_ms, "iteration_ms": plain_ms + grad_ms,
                                                           "traj_per_s": B / ((plain_ms + grad_ms) * 1e-3), "converged": int(plain["converged"].sum()),
@@ -347,6 +387,13 @@ def other_configs(torch):
                      "oc_solve_at_ipopt_default_tol_1e-8": {"ms": solve8_ms, "converged": int(sol8["converged"].sum()),
                                                             "iterations_mean_max": [float(it8.mean()), float(it8.max())],
                                                             "irl_iteration_traj_per_s": B / ((solve8_ms + grad_sens_ms) * 1e-3)}})
+        # the solve alone, as an entry of its own: the dominant kernel of an IRL iteration, priced on ITS OWN model (round-5 verdict, item 1)
+        sm = oc_solve_model(mdl.n, mdl.m, T, float(it.mean()), 2.0, B, float(solve_ms))
+        res[key.replace("irl_iteration", "oc_solve")] = dict(sm, batch=B, kernel_ms=float(solve_ms), traj_per_s=B / (solve_ms * 1e-3), horizon=T,
+                                                            kernel="oc_solve_ms2_kernel", timing_windows=list(getattr(solve_ms, "wins", ())),
+                                                            cold_from_the_zero_guess=dict(oc_solve_model(mdl.n, mdl.m, T, float(itc.mean()), 1.0, B, float(cold_ms)),
+                                                                                          kernel_ms=float(cold_ms), converged=int(demo["converged"].sum())),
+                                                            what="warm solve from the predicted start (PDP_MS_PREDICT + guard), per-sample theta moved 2 % (C3) / 5 % (C2)")
         if system == "cartpole":
             entry("C2_cartpole_gradient_unit_B256", B, grad_ms, flop=flop, T=T, latency_bound=True, note="aux system + Riccati + gradient at a given optimum (quarter-filled GPU)")
     # ---- C4 shard: rocket T=100, B=512: fused OC unit (p=10) and ControlPlanning.step (Lagrange policy p=18)
@@ -445,6 +492,28 @@ def other_configs(torch):
                          "loss_first_last": [float(r_["loss_trace"][0]), float(r_["loss_trace"][-1])], "parameters": int(cp_.n_auxvar)})
     except Exception as e_:
         res["recmat_drivers"] = {"error": repr(e_)[:300]}
+    # ---- counter-backed floors of the latency-bound entries (round-5 verdict, item 7): a RECORD like roofline.traffic (counters cannot be collected inside a timed run) -
+    # profiles/latency_floors.json, written by probes/profile_r06.sh from SQ counter passes of each kernel on its own
+    lf = os.path.join(ROOT, "profiles", "latency_floors.json")
+    if os.path.exists(lf):
+        fl = json.load(open(lf))
+        current = None
+        try:
+            from pdp_amd import codegen as _cg
+            current = bool(fl.get("collected", {}).get("kernel_sources_sha1") == _cg.kernel_sources_digest())
+        except Exception:
+            pass
+        for key, w in (("C5a_quadrotor_sysid_step_T100_p5_B1024", "sysid"), ("C3_quadrotor_cp_step_T50_p24_B1024", "cp_poly"), ("C4_rocket_cp_step_T100_p18_B512", "cp_poly_c4"),
+                       ("C5b_quadrotor_mlp_step_T100_p420_B1024", "mlp"), ("C4_rocket_oc_unit_T100_p10_B512", "oc_c4"), ("C3_quadrotor_oc_solve_B1024", "solve"),
+                       ("C2_cartpole_oc_solve_B256", "solve_c2")):
+            e, f = res.get(key), fl.get(w)
+            if e is not None and f and "floor_frac" in f:
+                e["floor"] = {"floor_frac": f["floor_frac"], "parked_on_waits_frac": f["parked_on_waits_frac"], "issue_stall_frac": f["issue_stall_frac"],
+                              "wave_cycles_per_wave": f["wave_cycles_per_wave"], "mfma_pipe_busy_cycles_per_wave": f["mfma_pipe_busy_cycles_per_wave"],
+                              "instructions_per_wave": f["instructions_per_wave"], "kernel": f["kernel"], "collected_on_these_kernel_sources": current,
+                              "what": "floor_frac = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of this kernel's own launch: the share of a wavefront's life in which it was issuing "
+                                      "instructions; the rest is parked on waits (s_waitcnt, hand-over polls) or stalled at issue (a dependent MFMA / VALU result not ready).  "
+                                      "One serial chain per wavefront cannot finish before its instructions have issued: kernel_ms x floor_frac is the time with every stall removed"}
     # ---- the reference's materialised API route on C3 sizes (HBM-bound by construction)
     mdl = zoo.get("quadrotor", "irl")
     B, T = 1024, 50
@@ -799,11 +868,23 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
-        traffic, traffic_cal = None, None
+        traffic, traffic_cal, traffic_at, traffic_current = None, None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and B == BATCH:
             tj = json.load(open(tf))
             traffic, traffic_cal = tj.get("oc_pdp_fused_kernel_hbm_bytes_per_launch"), tj.get("calibration")
+            # the counters cannot be collected inside a timed run: the figure is a RECORD - and says of which kernel sources (round-5 verdict, item 9: a kernel change
+            # silently kept the old number)
+            traffic_at = tj.get("collected")
+            try:
+                from pdp_amd import codegen as _cg
+                now = _cg.kernel_sources_digest()
+                traffic_current = bool(traffic_at and traffic_at.get("kernel_sources_sha1") == now)
+                if not traffic_current:
+                    print("bench.py: profiles/traffic.json was collected on other kernel sources (%s) than this tree's (%s): roofline.traffic is STALE until "
+                          "probes/profile_r06.sh is re-run" % ((traffic_at or {}).get("kernel_sources_sha1", "unrecorded")[:12], now[:12]), file=sys.stderr)
+            except Exception:
+                pass
         ach_tflops = FLOP_PER_TRAJ * B / (kern_ms * 1e-3) / 1e12
         ach_gbps = BYTES_PER_TRAJ * B / (kern_ms * 1e-3) / 1e9
         kres = None
@@ -831,8 +912,9 @@ def main():
                        "collectives_forced_at_world_size_1": bool(distributed and world == 1)},
             "roofline": {"bound": "mfma", "kernel": "oc_pdp_fused3_kernel" if os.environ.get("PDP_FUSED_VARIANT", "3") == "3" else "oc_pdp_fused_kernel", "achieved": ach_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_calibration": traffic_cal, "kernel_resources": kres,
+                         "traffic_collected_at": traffic_at, "traffic_collected_on_these_kernel_sources": traffic_current,
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
-                                           "(probes/profile_r05.sh; counter values scaled by the factors measured on known byte counts in this repository's access "
+                                           "(probes/profile_r06.sh; counter values scaled by the factors measured on known byte counts in this repository's access "
                                            "shapes, probes/pmc_calibrate.hip: `traffic_calibration`), not collected in this run", "kernel_ms": float(kern_ms),
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B, "timing_windows": [headline_window], "timed_region_window": timed_window,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,

@@ -474,6 +474,18 @@ def source_closure(src):
     return [seen[0]] + sorted(seen[1:])
 
 
+def kernel_sources_digest():
+    """sha1 over every hand-written source the shipped kernels are built from (the include closures of both translation units; generated model headers excluded):
+    recorded beside counter-derived figures (profiles/traffic.json) so that bench.py can tell whether they were collected on the kernels it is running."""
+    files = sorted(set(source_closure(os.path.join(CSRC, "pdp_model.hip")) + source_closure(os.path.join(CSRC, "pdp_lqr.hip"))))
+    h = hashlib.sha1()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def tuned(name):
     env = os.environ.get("PDP_MFMA_VGPR_FORM")
     if env is not None:

@@ -32,7 +32,9 @@ struct CpGenLayout {
 };
 
 template <class Mdl>
-__host__ __device__ inline CpGenLayout cp_generic_layout(const pdp_policy& pol, int T, bool have_x, bool have_u) {
+// wide_bytes: above this many bytes of layer inputs + deltas the two arrays live in the workspace instead of LDS (96 KB; PDP_CP_GENERIC_WIDE_BYTES overrides it on the host so
+// that a test can send a SMALL network down that route and compare it bit for bit with the LDS route)
+__host__ __device__ inline CpGenLayout cp_generic_layout(const pdp_policy& pol, int T, bool have_x, bool have_u, int wide_bytes = 96 * 1024) {
     constexpr int STRIDE = (Mdl::PATH_NVAR + 1 + Mdl::PATH_NCONST) | 1;
     CpGenLayout L;
     int sum_in = Mdl::NX, sum_w = 0, actw = 0;
@@ -43,7 +45,7 @@ __host__ __device__ inline CpGenLayout cp_generic_layout(const pdp_policy& pol, 
         sum_in = nb; sum_w = Mdl::NU;
     }
     L.sum_in = sum_in + 2; L.sum_w = sum_w; L.actw = actw;
-    L.wide = (L.sum_in + L.sum_w) * 8 > 96 * 1024;
+    L.wide = (L.sum_in + L.sum_w) * 8 > wide_bytes;
     int o = 0;
     L.zs_l = o; o += L.wide ? 0 : L.sum_in;
     L.ds_l = o; o += L.wide ? 0 : L.sum_w;
@@ -87,7 +89,8 @@ __global__ void __launch_bounds__(64) cp_step_generic_kernel(int B, int T, pdp_p
                                                               double* __restrict__ ws, CpGenLayout L) {
     constexpr int NX = Mdl::NX, NU = Mdl::NU;
     constexpr int NV = Mdl::PATH_NVAR, STRIDE = (NV + 1 + Mdl::PATH_NCONST) | 1;      // pool row: [entries | 0.0 | constants]
-    static_assert(NX <= 64 && NU <= 64, "one lane per Jacobian column");
+    // (one lane per Jacobian column: NX, NU <= 64 - checked by the launcher, which returns PDP_E_SIZE beyond that; a static_assert here would make a 65-state model
+    //  fail to COMPILE its whole library)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x, lane = threadIdx.x;
     double* wsb = ws + (int64_t)b * L.ws_per_traj;

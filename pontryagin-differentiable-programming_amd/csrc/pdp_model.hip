@@ -459,11 +459,16 @@ bool cp_needs_generic(const pdp_policy* pol, int p) {
     }
     return false;
 }
+static int cp_generic_wide_bytes() {
+    static const int v = [] { const char* e = std::getenv("PDP_CP_GENERIC_WIDE_BYTES"); return e ? std::atoi(e) : 96 * 1024; }();
+    return v;
+}
 template <class Mdl>
 int cp_step_generic(int B, int T, const pdp_policy* pol, int p, const double* x0, const double* th, int tb, double* loss, double* grad, double* x, double* u,
                     void* ws, int64_t wsb, void* st) {
     if (!cp_policy_args_ok<Mdl>(pol, p)) return PDP_E_ARG;
-    const CpGenLayout L = cp_generic_layout<Mdl>(*pol, T, x != nullptr, u != nullptr);
+    if (Mdl::NX > 64 || Mdl::NU > 64) return PDP_E_SIZE;          // the size-generic adjoint kernel holds one Jacobian column per lane
+    const CpGenLayout L = cp_generic_layout<Mdl>(*pol, T, x != nullptr, u != nullptr, cp_generic_wide_bytes());
     if (L.rows < 1 || (size_t)L.lds_total * sizeof(double) > 160 * 1024) return PDP_E_SIZE;       // (a model whose single Jacobian row exceeds the LDS: not a policy size)
     if (L.ws_per_traj > 0 && (!ws || wsb < (int64_t)B * L.ws_per_traj * (int64_t)sizeof(double))) return PDP_E_ARG;
     const size_t lds = sizeof(double) * (size_t)L.lds_total;
@@ -482,7 +487,7 @@ int64_t cp_step_ws_bytes(int B, int T, const pdp_policy* pol, int p) {
     if constexpr (Mdl::KIND == PDP_KIND_CP) {
         if (pol && cp_needs_generic<Mdl>(pol, p)) {
             if (!cp_policy_args_ok<Mdl>(pol, p)) return 0;
-            return (int64_t)B * cp_generic_layout<Mdl>(*pol, T, false, false).ws_per_traj * (int64_t)sizeof(double);
+            return (int64_t)B * cp_generic_layout<Mdl>(*pol, T, false, false, cp_generic_wide_bytes()).ws_per_traj * (int64_t)sizeof(double);
         }
         if (pol && pol->kind == PDP_POLICY_POLY && p <= 64 && cp_prepass(B)) return cp_prepass_ws_bytes<Mdl>(B, T);
         if (!pol || pol->kind != PDP_POLICY_MLP || pol->n_layers < 1 || pol->n_layers > 8) return 0;

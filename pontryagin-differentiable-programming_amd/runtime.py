@@ -755,12 +755,21 @@ class ModelLib:
         nbytes = int(self.lib.pdp_sysid_step_workspace_bytes(B, T))              # > 0: large batch, the trajectories are rolled out beforehand, one lane each
         ws = None
         if nbytes > 0:
-            # kept per (B, T) and never replaced: an SGD loop calls this every step, and a captured hipGraph (irl.GDLoop) holds the raw pointer - a buffer that a later,
-            # larger call freed would leave the graph writing through a dangling pointer (round-4 advice)
-            cache = self.__dict__.setdefault("_sysid_ws", {})
+            # kept per (B, T): an SGD loop calls this every step, and a captured hipGraph (irl.GDLoop) holds the raw pointer - a buffer that a later, larger call freed
+            # would leave the graph writing through a dangling pointer (round-4 advice).  Bounded (round-5 advice: a caller with ragged batches or horizon sweeps grew
+            # one buffer per shape for the lifetime of the library): the eight most recently used shapes stay, and every shape that was used DURING a graph capture
+            # stays for good (its pointer is baked into the graph).
+            from collections import OrderedDict
+            cache = self.__dict__.setdefault("_sysid_ws", OrderedDict())
+            pinned = self.__dict__.setdefault("_sysid_ws_pinned", set())
             ws = cache.get((B, T))
             if ws is None:
                 ws = cache[(B, T)] = torch.empty((nbytes // 8,), dtype=torch.float64, device="cuda")
+            cache.move_to_end((B, T))
+            if torch.cuda.is_current_stream_capturing():
+                pinned.add((B, T))
+            for key in [k for k in cache if k not in pinned][:max(0, len(cache) - len(pinned) - 8)]:
+                del cache[key]
         rc = self.lib.pdp_sysid_step_ws_batched(B, T, ptr(u), ptr(xobs), ptr(th), tb, ptr(loss), ptr(grad), ptr(ws), nbytes, current_stream_ptr())
         if rc == -2:
             x = self.sysid_integrate(xobs[:, 0].contiguous(), u, th)

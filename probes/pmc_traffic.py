@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """FETCH_SIZE / WRITE_SIZE of the bench kernels, scaled by factors MEASURED on known byte counts (probes/pmc_calibrate.hip), written to <dir>/traffic.json
-(copied to profiles/traffic.json, which bench.py reads for roofline.traffic) and <dir>/pmc_calibration.json.  Run by probes/profile_r05.sh on the GPU box."""
+(copied to profiles/traffic.json, which bench.py reads for roofline.traffic) and <dir>/pmc_calibration.json.  Run by probes/profile_r06.sh (round 5: profile_r05.sh) on the GPU box.
+Round 6: the record says which kernel sources it was collected on (`collected.kernel_sources_sha1` = pdp_amd.codegen.kernel_sources_digest()); bench.py compares."""
 import collections
 import csv
 import glob
@@ -92,7 +93,14 @@ if head:
     best = max(head, key=lambda k: out["kernels"][k]["dispatches"])
     out["oc_pdp_fused_kernel_hbm_bytes_per_launch"] = out["kernels"][best]["hbm_bytes_per_launch_calibrated"]
     out["oc_pdp_fused_kernel_counted_as"] = best
+sys.path.insert(0, os.getcwd())
+try:
+    import time
+    from pdp_amd import codegen
+    out["collected"] = {"kernel_sources_sha1": codegen.kernel_sources_digest(), "date": time.strftime("%Y-%m-%d"), "by": "probes/profile_r06.sh"}
+except Exception as ex:
+    out["collected"] = {"error": repr(ex)}
 out["note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 20 --warmup 5 --no-cpu-baseline "
-               "--no-scaling-configs` (probes/profile_r05.sh); counters in bytes (rocprofv3 reports KB), mean over all dispatches of a (kernel, grid) pair")
+               "--no-scaling-configs` (probes/profile_r06.sh); counters in bytes (rocprofv3 reports KB), mean over all dispatches of a (kernel, grid) pair")
 json.dump(out, open(os.path.join(O, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])

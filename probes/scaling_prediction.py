@@ -7,7 +7,9 @@ an explicit assumption (`assumed`), so that the first measured curve can be judg
 
     step time(N)  =  max(kernel(shard(N)), exchange(N))     the exchange of step k runs on a side stream under the kernel of step k + 1 (parallel.OverlappedGather)
     step time, not overlapped  =  kernel + exchange         (what a driver that consumes the rows at once would see)
-    exchange(N)   =  software floor + (N - 1) ring steps x (assumed per-step latency + rows x row bytes / assumed per-link bandwidth)
+    exchange(N)   =  software floor + (N - 1) x assumed per-peer latency + block bytes / assumed per-link bandwidth
+                     (an MI355X node is FULLY CONNECTED - 7 xGMI links per GPU, one to each peer: a rank's block travels to its N - 1 peers over N - 1 links at once, so
+                     the bandwidth term does not grow with N; the latency term is kept per peer, which is pessimistic)
 
 Run under `python probes/scaling_prediction.py [out.json]` on the GPU box."""
 import json
@@ -27,10 +29,10 @@ import torch.distributed as dist  # noqa: E402
 import bench  # noqa: E402
 from pdp_amd import JinEnv, parallel, runtime as rt, zoo  # noqa: E402
 
-ASSUMED = {"xgmi_ring_step_latency_us": 4.0, "xgmi_per_link_GBps_effective": 45.0,
-           "note": "NOT measured (one-GPU boxes): a ring all-gather over N ranks takes N - 1 steps, each moving one rank's block over one xGMI link; 4 us per step and 45 GB/s "
-                   "effective per direction and link are conservative small-message figures for MI300-class xGMI (peak ~64 GB/s per direction and link); RCCL may pick a "
-                   "tree / direct all-to-all for small messages and do better.  The all-reduce form moves (p + 1) doubles: latency only."}
+ASSUMED = {"xgmi_per_peer_latency_us": 4.0, "xgmi_per_link_GBps_effective": 45.0,
+           "note": "NOT measured (one-GPU boxes).  Fully connected node: every rank sends its block to its N - 1 peers over N - 1 separate xGMI links in parallel; 45 GB/s "
+                   "effective per direction and link (peak ~64 GB/s: 153 GB/s bidirectional aggregate per link pair is the headline figure) and 4 us of latency PER PEER, "
+                   "summed as if the sends were serialised - conservative on both counts.  The all-reduce form moves (p + 1) doubles: latency only."}
 
 
 def event_ms(fn, reps=10, warm=2):
@@ -114,9 +116,9 @@ def main():
             ag_us = 1e3 * event_ms(lambda: parallel.gather_packed(rows, out=out), reps=20, warm=3)
             ar_us = 1e3 * event_ms(lambda: parallel.allreduce_mean_packed(rows, b), reps=20, warm=3)
             blk = b * (p + 1) * 8
-            wire_us = (N - 1) * (ASSUMED["xgmi_ring_step_latency_us"] + blk / (ASSUMED["xgmi_per_link_GBps_effective"] * 1e3))
+            wire_us = ((N - 1) * ASSUMED["xgmi_per_peer_latency_us"] + blk / (ASSUMED["xgmi_per_link_GBps_effective"] * 1e3)) if N > 1 else 0.0
             ex_us = ag_us + wire_us
-            ar_wire_us = 2 * (N - 1) * ASSUMED["xgmi_ring_step_latency_us"] if N > 1 else 0.0
+            ar_wire_us = 2 * (N - 1) * ASSUMED["xgmi_per_peer_latency_us"] if N > 1 else 0.0
             step_ov, step_no = max(k_ms, ex_us * 1e-3), k_ms + ex_us * 1e-3
             step_ar = k_ms + (ar_us + ar_wire_us) * 1e-3
             row = {"shard_per_gpu": b, "total_batch": total, "kernel_ms_measured": k_ms, "exchange_bytes_per_rank": blk, "allgather_software_floor_us_measured": ag_us,

@@ -74,6 +74,19 @@ def main():
                                         "cost_of_converged_min_median_max": [float(v) for v in np.percentile(s["cost"].cpu().numpy()[conv], [0, 50, 100])] if conv.any() else None}
                 print("%-24s %-14s converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  %.3f ms  status %s" %
                       (name, key, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), ms, entry["kernel"][key]["status_bits"]))
+        if system == "rocket":
+            # IPOPT's own iteration limit is 3000 (the reference passes none, PDP.py:178-182); this solver's default is 300.  What the longer leash buys:
+            for mi in (1000, 3000):
+                s = mdl.oc_solve_ms(x0, th, T, tol=1e-8, max_iter=mi)
+                conv = s["converged"].cpu().numpy().astype(bool)
+                it = s["iterations"].cpu().numpy()
+                st = s["status"].cpu().numpy()
+                ms = float(bench._event_ms(torch, lambda: mdl.oc_solve_ms(x0, th, T, tol=1e-8, max_iter=mi), reps=1, warm=0))
+                entry["kernel"]["tol_1e-08_max_iter_%d" % mi] = {"converged": int(conv.sum()), "of": B, "rate": float(conv.mean()), "ms": ms,
+                                                                "iterations": {"mean": float(it.mean()), "median": float(np.median(it)), "p95": float(np.percentile(it, 95)), "max": int(it.max())},
+                                                                "status_bits": {BITS.get(b, str(b)): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 64, 128, 1024) if ((st & b) != 0).any()}}
+                print("%-24s max_iter %-5d converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  %.1f ms  status %s" %
+                      (name, mi, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), ms, entry["kernel"]["tol_1e-08_max_iter_%d" % mi]["status_bits"]))
         # the class surface's route (what a user of OCSys.ocSolver_batch gets): kernel, then single shooting for the rows it left unconverged
         oc = make_oc(system)
         sol = ocsolver.solve_batch(oc, x0, T, th, tol=1e-9)

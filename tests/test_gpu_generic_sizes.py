@@ -267,3 +267,46 @@ def test_sysid_with_forty_states_against_the_oracle(margins):
     margins.check("40-state SysID.step vs oracle: gradient", np.abs(np.asarray(dp).reshape(-1) - np.asarray(g).reshape(-1)).max() / np.abs(g).max(), 1e-10)
     xs = sid.integrateDyn(x0[0], inputs[0], th_true)
     margins.check("40-state SysID.integrateDyn vs oracle", rel(xs, states[0]), 1e-10)
+
+
+WIDE_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from pdp_amd import runtime as rt, zoo
+mdl = zoo.get("quadrotor", "oc")
+rng = np.random.default_rng(9)
+hidden = [40, 3, 36]
+layers = hidden + [4]
+p = sum(a * b + a for a, b in zip(layers, [13] + layers[:-1]))
+pol = rt.make_policy("mlp", layers=layers)
+B, T = 5, 20
+theta = rng.standard_normal(p) * 0.05
+x0 = np.zeros((B, 13)); x0[:, :3] = rng.uniform(-2, 2, (B, 3)); x0[:, 6] = 1.0
+loss, grad, x, u = mdl.cp_step(pol, p, x0, theta, T, want_traj=True)
+np.savez(sys.argv[1], loss=loss.cpu().numpy(), grad=grad.cpu().numpy(), x=x.cpu().numpy(), u=u.cpu().numpy())
+"""
+
+
+def test_wide_network_route_equals_the_lds_route_bit_for_bit(tmp_path):
+    """Round-5 advice: above 96 KB of layer inputs + deltas (about 12 k units in total) cp_step_generic_kernel keeps both arrays in its workspace slice instead of LDS, and
+    the lanes' hand-overs through global memory rest on workgroup-scope fences - a route no test network was wide enough to take.  PDP_CP_GENERIC_WIDE_BYTES=0 sends a small
+    network ([40, 3, 36]) down it: loss, gradient and trajectories must equal the LDS route's bit for bit (same arithmetic, only the address space differs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, val in (("lds", None), ("wide", "0")):
+        env = dict(os.environ)
+        env.pop("PDP_CP_GENERIC_WIDE_BYTES", None)
+        if val is not None:
+            env["PDP_CP_GENERIC_WIDE_BYTES"] = val
+        out = str(tmp_path / ("%s.npz" % tag))
+        r = subprocess.run([sys.executable, "-c", WIDE_WORKER, out], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.all(np.isfinite(a["grad"])) and np.abs(a["grad"]).max() > 0
+    for k in ("loss", "grad", "x", "u"):
+        assert np.array_equal(a[k], b[k]), k
