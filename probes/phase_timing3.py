@@ -5,15 +5,25 @@ sys.path.insert(0, os.getcwd())
 import torch
 from pdp_amd import codegen, zoo, runtime
 import bench
-pb = zoo.make_problem('quadrotor', 'irl'); _, info = codegen.write_header(pb)
+SYSTEM = os.environ.get('PDP_SYSTEM', 'quadrotor')      # round 6: PDP_SYSTEM=rocket PDP_B=512 -> one GPU's shard of C4 (rocket T = 100, TPW = 2)
+pb = zoo.make_problem(SYSTEM, 'irl'); _, info = codegen.write_header(pb)
 out = '/tmp/libtiming3.so'
 EXTRA = [a for a in os.environ.get('PDP_EXTRA', '').split() if a]
 subprocess.run([codegen.HIPCC] + codegen.HIP_FLAGS + codegen.OC_EXTRA_FLAGS + EXTRA + ['-DPDP_PHASE_TIMING', '-DPDP_MODEL_HEADER="generated/%s.h"' % info['name'], '-I', codegen.CSRC,
                 os.path.join(codegen.CSRC, 'pdp_model.hip'), '-o', out], check=True)
 mdl = runtime.ModelLib(out)
-for B in (1024,):
-    x0, u, dx, du = (torch.as_tensor(a, device='cuda') for a in bench.synth_inputs(B, 1000))
-    th = torch.tensor(bench.THETA, dtype=torch.float64, device='cuda')
+for B in (int(os.environ.get('PDP_B', '1024')),):
+    if SYSTEM == 'rocket':
+        from pdp_amd import JinEnv
+        rng = np.random.default_rng(0)
+        T = 100
+        x0 = np.zeros((B, 13)); x0[:, :3] = np.array([10, -8, 5.0]) + rng.standard_normal((B, 3)); x0[:, 3] = -0.1; x0[:, 6:10] = JinEnv.toQuaternion(1.5, [0, 0, 1])
+        u = np.tile(np.array([10.0, 0, 0]), (B, T, 1)) + 0.1 * rng.standard_normal((B, T, 3))
+        x0, u, dx, du = (torch.as_tensor(a, device='cuda') for a in (x0, u, np.zeros((B, T + 1, 13)), np.zeros((B, T, 3))))
+        th = torch.tensor([0.5, 1, 1, 1, 1, 1, 1, 50, 1, 1.0], dtype=torch.float64, device='cuda')
+    else:
+        x0, u, dx, du = (torch.as_tensor(a, device='cuda') for a in bench.synth_inputs(B, 1000))
+        th = torch.tensor(bench.THETA, dtype=torch.float64, device='cuda')
     big = torch.zeros(B + 64 + 4 * B, dtype=torch.float64, device='cuda')
     bufs = {'loss': big[:B]}
     for _ in range(3):
