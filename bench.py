@@ -727,6 +727,7 @@ def main():
                          "gives their mean (adds a ragged total); results under `verified`")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (the host driver only supports dmabuf IPC: without it RCCL's cross-process set-up fails; exported by the image, kept here)
     import torch
     import torch.distributed as dist
     from pdp_amd import parallel, zoo

@@ -21,7 +21,7 @@ out = {}
 for w, kern in KERNEL.items():
     vals = collections.defaultdict(list)
     names = collections.Counter()
-    for f in sorted(glob.glob(os.path.join(O, "floor_%s_*" % w, "**", "*counter_collection.csv"), recursive=True)):
+    for f in sorted(glob.glob(os.path.join(O, "floor_%s_[0-9]" % w, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 vals[r["Counter_Name"]].append(float(r["Counter_Value"]))

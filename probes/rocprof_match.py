@@ -72,7 +72,7 @@ def main():
 
     out = []
 
-    def report(label, event_ms, windows, plain_ms=None):
+    def report(label, event_ms, windows, plain_ms=None, wall_clock=False):
         tot, parts = 0.0, []
         for k in windows:
             t, p = window_kernels(k)
@@ -85,6 +85,10 @@ def main():
         over_us = (event_ms - tot) * 1e3
         if abs(ratio - 1) <= tol:
             verdict = "PASS"
+        elif wall_clock and 0 <= over_us <= 15.0:
+            # the timed region is a WALL-CLOCK figure over K steps: kernel time + the gap between consecutive launches + the fixed ends of the region (first launch from an
+            # idle GPU, the final synchronize) spread over K - 6 to 10 us per step at K = 20 on the boxes seen so far, and what `value` pays against roofline.kernel_ms
+            verdict = "PASS (kernels account for %.1f %% of the step; %.1f us per step are launch gap and the fixed ends of the timed region over its K steps)" % (100 * tot / event_ms, over_us)
         elif 0 <= over_us <= 6.0 * max(1, n_launch):
             verdict = "PASS (+%.1f us of event / launch overhead around %d launch(es): above %.0f %% only because the kernel is short)" % (over_us, n_launch, 100 * tol)
         elif plain_ms is not None and (abs(plain_ms / tot - 1) <= tol or 0 <= (plain_ms - tot) * 1e3 <= 6.0 * max(1, n_launch)):
@@ -101,7 +105,7 @@ def main():
                 return None
         return float(v)
     report("headline kernel_ms (roofline.achieved)", line["roofline"]["kernel_ms"], [hw], pl("roofline", "kernel_ms"))
-    report("timed region ms_per_step", line["ms_per_step"], [line["roofline"]["timed_region_window"]], pl("ms_per_step"))
+    report("timed region ms_per_step", line["ms_per_step"], [line["roofline"]["timed_region_window"]], pl("ms_per_step"), wall_clock=True)
     for name, e in (line.get("other_configs") or {}).items():
         if isinstance(e, dict) and e.get("timing_windows"):
             report("other_configs." + name + ".kernel_ms", e["kernel_ms"], e["timing_windows"], pl("other_configs", name, "kernel_ms"))
