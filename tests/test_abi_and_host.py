@@ -358,3 +358,29 @@ def test_no_result_changing_macros_in_product_headers():
     text = "".join(open(os.path.join(patches, p)).read() for p in os.listdir(patches) if p.endswith(".patch"))
     for name in retired:
         assert name in text, name
+
+
+def test_bench_solver_model_and_recorded_counter_figures():
+    """bench.py's flop / byte model of the OC solve (round-5 verdict, item 1) on the C3 sizes, and the bookkeeping of counter-derived records: the digest of the kernel sources
+    is stable, profiles/traffic.json and profiles/latency_floors.json carry one, and every latency-bound entry bench.py maps a floor onto exists in the record."""
+    import json
+    import bench
+    from pdp_amd import codegen
+    m = bench.oc_solve_model(13, 4, 50, 2.0, 2.0, 1024, 0.241)
+    # 50 stages x (backward 16.9 k + forward 1.0 k) flop per Newton iteration; 13 + 5 big and 9 + 8 small MFMAs per stage executed
+    assert abs(m["algorithmic_flop_per_solve"] - 2 * 50 * (16900 + 1034)) < 1 and m["executed_mfma_flop_per_solve"] == 2 * 50 * (18 * 2048 + 17 * 512)
+    assert m["mfma_issue_cycles_per_iteration"] == 50 * (18 * 64 + 17 * 28)
+    assert 0.05 < m["frac_of_fp64_mfma_peak"] < 0.15 and 0.2 < m["frac_of_hbm_peak"] < 0.35
+    assert 4.5e5 < m["algorithmic_bytes_per_solve"] < 6e5                 # ~0.5 MB per trajectory: x 1024 = the ~500 MB the counters measured per launch
+    small = bench.oc_solve_model(4, 1, 50, 2.2, 2.0, 256, 0.141)
+    assert small["executed_mfma_flop_per_solve"] == 2.2 * 50 * 13 * 512
+    d = codegen.kernel_sources_digest()
+    assert d == codegen.kernel_sources_digest() and len(d) == 40
+    root = os.path.dirname(os.path.dirname(os.path.abspath(codegen.CSRC)))
+    for rec in ("traffic.json", "latency_floors.json"):
+        j = json.load(open(os.path.join(root, "profiles", rec)))
+        assert len(j["collected"]["kernel_sources_sha1"]) == 40, rec
+    fl = json.load(open(os.path.join(root, "profiles", "latency_floors.json")))
+    for w in ("sysid", "cp_poly", "cp_poly_c4", "mlp", "oc_c4", "headline", "solve", "solve_c2"):
+        e = fl[w]
+        assert 0.0 < e["floor_frac"] < 1.0 and abs(e["floor_frac"] + e["parked_on_waits_frac"] + e["issue_stall_frac"] - 1.0) < 0.05, (w, e["floor_frac"])
