@@ -574,6 +574,39 @@ class ModelLib:
             out["predict_record"] = prec
         return out
 
+    def oc_pdp_grad_prepared(self, u, theta, demo_x, demo_u, x0, packed_out=None):
+        """The fused OC unit as a PREPARED call: every argument of pdp_oc_pdp_grad_batched marshalled once; the returned step() is one foreign call on the stream that is
+        current when it runs (no tensor conversions, no dictionary, no allocation per step) - what a driver that calls the unit in a loop on fixed buffers should use, and what
+        bench.py times: oc_pdp_grad's Python wrapper costs 25 - 60 us per call, which a busy host cannot always hide under a 97 us kernel (the driver's 0.104 - 0.109 ms per step
+        against 0.097 - 0.099 ms of kernel time).  Returns (step, out) with out = dict(loss, grad, x, lam, status, packed): the tensors every step() overwrites.
+        packed_out: a [B, p + 1] tensor to receive gradient | loss (PDP_OC_PACKED), e.g. the buffer a collective sends; allocated when None."""
+        torch = torch_cuda()
+        u, demo_x, demo_u = dev(u), dev(demo_x), dev(demo_u)
+        B, T = u.shape[0], u.shape[1]
+        n, p = self.n, self.p
+        th, tb = self._theta(theta, B)
+        x0 = dev(x0).reshape(B, n)
+        f64 = dict(dtype=torch.float64, device="cuda")
+        x, lam, loss = torch.empty((B, T + 1, n), **f64), torch.empty((B, T, n), **f64), torch.empty((B,), **f64)
+        pk = torch.empty((B, p + 1), **f64) if packed_out is None else packed_out
+        assert pk.is_cuda and pk.dtype == torch.float64 and pk.is_contiguous() and tuple(pk.shape) == (B, p + 1)
+        status = torch.empty((B,), dtype=torch.int32, device="cuda")
+        nbytes = self.lib.pdp_oc_pdp_workspace_bytes(B, T)
+        ws = torch.empty((max(nbytes, 8) // 8,), **f64)
+        keep = (u, th, demo_x, demo_u, x0, x, lam, loss, pk, status, ws)                 # (the closure owns every buffer the kernel touches)
+        fn = self.lib.pdp_oc_pdp_grad_batched
+        args = (B, T, 2, ptr(x0), ptr(u), ptr(th), tb, ptr(demo_x), ptr(demo_u), ptr(x), ptr(lam), ptr(loss), ptr(pk), ptr(None), ptr(None), ptr(status), ptr(ws), nbytes)
+        rc0 = fn(*args, current_stream_ptr())
+        if rc0 != 0:
+            raise RuntimeError("pdp_oc_pdp_grad_batched (prepared call): %s - problems outside the fused kernel's limits take oc_pdp_grad" % PDP_E.get(rc0, rc0))
+        cur = torch.cuda.current_stream
+
+        def step(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args, C.c_void_p(cur().cuda_stream))
+            if rc != 0:
+                check(rc, "pdp_oc_pdp_grad_batched")
+        return step, dict(loss=loss, grad=pk[:, :p], x=x, lam=lam, status=status, packed=pk)
+
     def oc_predict_from_record(self, x, u, lam, dtheta, record, primal=False):
         """oc_predict from the packed fp32 record (pdp_oc_predict_record_batched): new tensors (x, u, lam) + first-order change for the step dtheta
         (primal: states and controls only, lam is returned as it came)"""

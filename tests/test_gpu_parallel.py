@@ -102,3 +102,41 @@ def test_packed_output_equals_separate_outputs():
     b = mdl.oc_pdp_grad(u, th, dx, du, x0=x0, packed=True)
     assert b["packed"].shape == (96, 10)
     assert torch.equal(b["packed"][:, :9], g) and torch.equal(b["packed"][:, 9], l) and torch.equal(b["loss"], l)
+
+
+def test_prepared_call_equals_the_wrapper_and_follows_the_current_stream():
+    """runtime.oc_pdp_grad_prepared (what bench.py times since round 6): the arguments of pdp_oc_pdp_grad_batched marshalled once, one foreign call per step - the same kernel
+    on the same buffers as runtime.oc_pdp_grad(packed=True), bit for bit; rows land in a caller's buffer (the one a collective sends); the launch goes to the stream that is
+    current when step() runs (a side stream here), and can be captured into a hipGraph."""
+    import torch
+    import bench
+    from pdp_amd import zoo
+    mdl = zoo.get("quadrotor", "irl")
+    x0, u, dx, du = (torch.as_tensor(a, device="cuda") for a in bench.synth_inputs(192, 5))
+    th = torch.tensor(bench.THETA, dtype=torch.float64, device="cuda")
+    ref = mdl.oc_pdp_grad(u, th, dx, du, x0=x0, packed=True)
+    ref = {k: v.clone() for k, v in ref.items()}
+    mine = torch.full((192, 10), float("nan"), dtype=torch.float64, device="cuda")
+    step, out = mdl.oc_pdp_grad_prepared(u, th, dx, du, x0, packed_out=mine)
+    assert out["packed"].data_ptr() == mine.data_ptr()
+    for k in ("packed", "loss", "x", "lam"):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(out["grad"], ref["packed"][:, :9]) and int(out["status"].sum()) == 0
+    mine.fill_(float("nan"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        done = torch.cuda.Event()
+        done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    assert torch.equal(mine, ref["packed"])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    mine.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(mine, ref["packed"])
+    with pytest.raises(AssertionError):
+        mdl.oc_pdp_grad_prepared(u, th, dx, du, x0, packed_out=torch.empty((192, 9), dtype=torch.float64, device="cuda"))
