@@ -180,6 +180,32 @@ PDP_DEV d4 buf_load(RS rs, unsigned soff, const BufMap& m) {
     return v;
 }
 
+// Cross-lane traffic of this kernel through DPP modifiers instead of ds_bpermute (round 6): the shuffle form keeps one address register per distance - (lane ^ o) << 2, the
+// same values at every call site, so the compiler shares them across the WHOLE kernel: six registers live through both sweeps of an instantiation that sits on its 256 -
+// and sends every word through the LDS crossbar.  ms2_sum / ms2_max: rotations inside the rows of 16 lanes (row_ror 1, 2, 4, 8: every lane of a row holds the row's
+// total), then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3; lane 63 holds the total, returned through v_readlane (uniform).  The ORDER of the
+// additions differs from wave_sum's butterfly: sums agree to rounding, not bit for bit.
+template <int CTRL, int ROWMASK = 0xf>
+PDP_DEV double ms2_dpp(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+PDP_DEV double ms2_sum(double v) {
+    v += ms2_dpp<0x121>(0.0, v); v += ms2_dpp<0x122>(0.0, v); v += ms2_dpp<0x124>(0.0, v); v += ms2_dpp<0x128>(0.0, v);
+    v += ms2_dpp<0x142, 0xa>(0.0, v);
+    v += ms2_dpp<0x143, 0xc>(0.0, v);
+    return readlane_f64(v, 63);
+}
+PDP_DEV double ms2_max(double v) {
+    v = fmax(v, ms2_dpp<0x121>(v, v)); v = fmax(v, ms2_dpp<0x122>(v, v)); v = fmax(v, ms2_dpp<0x124>(v, v)); v = fmax(v, ms2_dpp<0x128>(v, v));
+    v = fmax(v, ms2_dpp<0x142, 0xa>(v, v));
+    v = fmax(v, ms2_dpp<0x143, 0xc>(v, v));
+    return readlane_f64(v, 63);
+}
+// lane l <- lane l - 1 (wave_shr:1); lane 0 keeps its own value, like __shfl_up(v, 1)
+PDP_DEV double ms2_up1(double v) { return ms2_dpp<0x138>(v, v); }
+
 // stage-minor access: UNIFORM row pointer (array base + component * stride: scalar registers) + this lane's byte offset (8 * stage, one VGPR shared by
 // every access of the pass) - the saddr + voffset form of global_load / global_store; `row[i * TS + t]` would carry a 64-bit address per component
 PDP_DEV double sm_ld(const double* row, unsigned off8) { return *(const double*)((const char*)row + off8); }
@@ -307,7 +333,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             double nl[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {                              // the previous node's lambda
-                nl[i] = __shfl_up(lc[i], 1, 64);
+                nl[i] = ms2_up1(lc[i]);
                 if (lane == 0) nl[i] = lprev[i];
                 lprev[i] = readlane_f64(lc[i], 63);
             }
@@ -315,7 +341,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 Mdl::dyn(xc, uc, th, pc, v);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    double nv = __shfl_up(v[i], 1, 64);                  // the previous node's f(x, u)
+                    double nv = ms2_up1(v[i]);                           // the previous node's f(x, u)
                     if (lane == 0) nv = vprev[i];
                     vprev[i] = readlane_f64(v[i], 63);
                     const double ci = nv - xc[i];                        // defect of stage t - 1
@@ -348,8 +374,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OU + i * TS) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
             }
         }
-        if constexpr (PRIMAL) { a_f = wave_sum(a_f); a_th = wave_sum(a_th); a_lc = wave_sum(a_lc); a_pr = wave_max(a_pr); a_z = wave_max(a_z); }
-        if constexpr (DUAL) { a_du = wave_max(a_du); a_l = wave_max(a_l); }
+        if constexpr (PRIMAL) { a_f = ms2_sum(a_f); a_th = ms2_sum(a_th); a_lc = ms2_sum(a_lc); a_pr = ms2_max(a_pr); a_z = ms2_max(a_z); }
+        if constexpr (DUAL) { a_du = ms2_max(a_du); a_l = ms2_max(a_l); }
         fin_all = __all(fin);
         if constexpr (DUAL && !KEEP) {                               // (the runner keeps its half - PART 3: all of it - in registers)
             if (lane == 0) {
@@ -372,9 +398,48 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     using PartDual = std::integral_constant<int, 2>;
     using PartKeep = std::integral_constant<int, 3>;
 
+    // Stage-major API array [t][NC] <-> stage-minor workspace rows [i TS + t], one wave: all loads of a batch (up to UNB x 64 elements) are requested before the first
+    // store - written as plain `for (q = lane; ...) dst[..] = src[q]` loops these copies were 24 dependent round trips to memory per array set (round 6, probes/ms_timeline.py:
+    // 24 k cycles for the starting point, 17 k for the result, of a 500 k-cycle solve).  `from_t`: first stage copied (1: node 0 of the states is x_0, written by the caller).
+    constexpr int UNB = 12;
+    // (index arithmetic from an opaque lane id, like the sweeps' maps: shared between the copies at the start and the one at the end of the launch it would stay live across the
+    // whole iteration loop - the four-trajectory instantiation then spills)
+    auto tr_in = [&](const double* __restrict__ src, int N, auto nc_tag, double* dst, int from_t) {
+        constexpr int NC = decltype(nc_tag)::value;
+        const int ln = opaque(lane);
+        for (int q0 = 0; q0 < N; q0 += 64 * UNB) {
+            double v[UNB];
+#pragma unroll
+            for (int k = 0; k < UNB; ++k) { const int q = q0 + ln + 64 * k; v[k] = src[q < N ? q : N - 1]; }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < UNB; ++k) {
+                const int q = q0 + ln + 64 * k, t = q / NC, i = q - t * NC;
+                if (q < N && t >= from_t) dst[i * TS + t] = v[k];
+            }
+        }
+    };
+    auto tr_out = [&](const double* src, int N, auto nc_tag, double* __restrict__ dst) {
+        constexpr int NC = decltype(nc_tag)::value;
+        const int ln = opaque(lane);
+        for (int q0 = 0; q0 < N; q0 += 64 * UNB) {
+            double v[UNB];
+#pragma unroll
+            for (int k = 0; k < UNB; ++k) { int q = q0 + ln + 64 * k; q = q < N ? q : N - 1; const int t = q / NC, i = q - t * NC; v[k] = src[i * TS + t]; }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < UNB; ++k) { const int q = q0 + ln + 64 * k; if (q < N) dst[q] = v[k]; }
+        }
+    };
+    using TagNX = std::integral_constant<int, NX>;
+    using TagNU = std::integral_constant<int, NU>;
+
     if (runner) {
         // ================================================ runner ================================================
         __builtin_amdgcn_s_setprio(3);
+#ifdef PDP_MS_TIMING      // whole-launch timeline of the runner (row log_rows / 2 - 1 of the log): entry | starting point loaded | first residuals read | loop left | results written
+        const long long tk0 = __builtin_readcyclecounter();
+#endif
         {
             double th0[NP > 0 ? NP : 1], pc0[Mdl::NPC];
             load_theta<Mdl>(theta, b, tb, th0);
@@ -402,83 +467,102 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             double* s0 = Pt(0);
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
             if (rec) {
-                // one pass over blocks of SB stages: the block's records (SB x PredRec::SIZE floats, contiguous) come in with coalesced loads, lane (stage, row) forms
-                // dx_{t+1}, du_t, parks dx in LDS, and - after the exchange - dlam_t = W_{t+1} dtheta + P_{t+1} dx_{t+1} from the same block
+                // Round 6.  The records of a BATCH of CH stages (as many as the pool holds: CH x PredRec::SIZE floats, contiguous in memory) go from memory straight into
+                // LDS (global_load_lds_dword: no registers, 64 consecutive floats per instruction), this lane's x_{t+1}, lambda_t, u_t of the batch are requested behind
+                // them, and ONE wait covers all of it; then lane = (stage, row) forms dx_{t+1}, du_t, parks dx in LDS, and - after the exchange -
+                // dlam_t = W_{t+1} dtheta + P_{t+1} dx_{t+1}.  Until round 6 this was a loop over blocks of 64 / NX stages with three dependent round trips to memory per
+                // block (records -> registers -> LDS, then x / u, then lambda): 70 k cycles of a 510 k-cycle solve at C3 (probes/ms_timeline.py), the runner's alone.
+                // Same sums in the same order as before (and as oc_predict_kernel).
                 using R = PredRec<Mdl>;
-                constexpr int SB = 64 / NX, NQ = (SB * R::SIZE + 63) / 64;
-                static_assert(SB * R::SIZE / 2 + SB * NX + 2 <= L::PRED_STG + 64, "record staging block");
+                constexpr int CHMAX_ = (4 * L::BUF - 192) / (R::SIZE + 2 * NX);
+                constexpr int CHCAP = 256 / NX < 64 ? 256 / NX : 64;         // (at most four rounds of 64 (stage, row) items per batch: their x / lambda values wait in registers)
+                constexpr int CHMAX = CHMAX_ < CHCAP ? CHMAX_ : CHCAP;
+                static_assert(CHMAX >= 1, "prediction record: one stage must fit the pool");
+                constexpr int RD = (CHMAX * NX + 63) / 64, RDU = (CHMAX * NU + 63) / 64;
+                const int RS = recp ? R::P : R::SIZE;               // floats per stage in LDS (PDP_MS_PREDICT_PRIMAL: the X | U part of every record only)
+                const int nbat = (T + CHMAX - 1) / CHMAX, CH = (T + nbat - 1) / nbat;
                 float* stage = (float*)pool;
-                double* dxb = pool + (SB * R::SIZE + 1) / 2;          // dx of the block: [stage][row]
+                double* dxb = pool + (CHMAX * R::SIZE + 64 + 1) / 2;          // dx of the batch: [stage][row]
                 double dth[NP > 0 ? NP : 1];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) dth[j] = op.dtheta[(int64_t)b * op.dtheta_bstride + j];
                 for (int i = lane; i < NX; i += 64) s0[i * TS] = x0[(int64_t)b * NX + i];
-                const int sg = lane / NX, i = lane - sg * NX;
-                for (int t0 = 0; t0 < T; t0 += SB) {
-                    const int nst = min(SB, T - t0), nd = nst * R::SIZE;
+                for (int t0 = 0; t0 < T; t0 += CH) {
+                    const int nst = min(CH, T - t0), nd = nst * RS;
                     const float* s_ = rec + ((int64_t)b * T + t0) * R::SIZE;
-                    if (recp) {      // PDP_MS_PREDICT_PRIMAL: the X | U part of every stage only (R::P floats of R::SIZE), to the same places of the staging block
-                        constexpr int NQP = (SB * R::P + 63) / 64;
-                        float v[NQP];
-                        int at[NQP];
-#pragma unroll
-                        for (int k = 0; k < NQP; ++k) {
-                            const int idx = lane + 64 * k, s = idx / R::P;
-                            at[k] = s * R::SIZE + (idx - s * R::P);
-                            v[k] = s_[idx < nst * R::P ? at[k] : 0];
-                        }
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int k = 0; k < NQP; ++k) { if (lane + 64 * k < SB * R::P) stage[at[k]] = v[k]; }
-                    } else {
-                    float v[NQ];
-#pragma unroll
-                    for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; v[k] = s_[idx < nd ? idx : 0]; }
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int k = 0; k < NQ; ++k) { const int idx = lane + 64 * k; if (idx < SB * R::SIZE) stage[idx] = v[k]; }
+                    for (int k0 = 0; k0 < nd; k0 += 64) {
+                        int idx = k0 + lane;
+                        idx = idx < nd ? idx : 0;
+                        if (recp) { const int si = idx / R::P; idx = si * R::SIZE + (idx - si * R::P); }
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + idx), (__attribute__((address_space(3))) void*)(stage + k0), 4, 0, 0);
                     }
-                    wave_lds_sync();
-                    const bool live = lane < nst * NX;
-                    const int t = t0 + (live ? sg : 0);
-                    const float* r = stage + (live ? sg : 0) * R::SIZE;
-                    double dx = 0.0;
-                    if (live) {
+                    double xv[RD], lv[RD], uv[RDU];
 #pragma unroll
-                        for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
-                        dxb[sg * NX + i] = dx;
-                        const double xv = xb[(t + 1) * NX + i];
-                        corr_upd(dx, xv);
-                        s0[i * TS + t + 1] = xv + dx;
-                        // control rows: lane (stage, i) takes rows i, i + NX, ... - one row per lane when NU <= NX, and every row is still written when a model has more
-                        // controls than states (round-4 advice: rows >= NX used to be skipped)
+                    for (int rd = 0; rd < RD; ++rd) {
+                        const int it_ = lane + 64 * rd, q = t0 * NX + (it_ < nst * NX ? it_ : 0);
+                        xv[rd] = xb[NX + q];
+                        lv[rd] = lb[q];
+                    }
 #pragma unroll
-                        for (int iu = i; iu < NU; iu += NX) {
+                    for (int rd = 0; rd < RDU; ++rd) { const int it_ = lane + 64 * rd; uv[rd] = ub[t0 * NU + (it_ < nst * NU ? it_ : 0)]; }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int rd = 0; rd < RD; ++rd) {
+                        const int it_ = lane + 64 * rd;
+                        if (it_ < nst * NX) {
+                            const int sg = it_ / NX, i = it_ - sg * NX, t = t0 + sg;
+                            const float* r = stage + sg * RS;
+                            double dx = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
+                            dxb[it_] = dx;
+                            corr_upd(dx, xv[rd]);
+                            s0[i * TS + t + 1] = xv[rd] + dx;
+                        }
+                    }
+#pragma unroll
+                    for (int rd = 0; rd < RDU; ++rd) {
+                        const int it_ = lane + 64 * rd;
+                        if (it_ < nst * NU) {
+                            const int sg = it_ / NU, iu = it_ - sg * NU, t = t0 + sg;
+                            const float* r = stage + sg * RS;
                             double du = 0.0;
 #pragma unroll
                             for (int j = 0; j < NP; ++j) du = fma((double)r[R::U + iu * NP + j], dth[j], du);
-                            const double uv = ub[t * NU + iu];
-                            corr_upd(du, uv);
-                            s0[OU + iu * TS + t] = uv + du;
+                            corr_upd(du, uv[rd]);
+                            s0[OU + iu * TS + t] = uv[rd] + du;
                         }
                     }
                     wave_lds_sync();
-                    if (live) {
-                        double dl = 0.0;
-                        if (!recp) {
 #pragma unroll
-                            for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
+                    for (int rd = 0; rd < RD; ++rd) {
+                        const int it_ = lane + 64 * rd;
+                        if (it_ < nst * NX) {
+                            const int sg = it_ / NX, i = it_ - sg * NX, t = t0 + sg;
+                            const float* r = stage + sg * RS;
+                            double dl = 0.0;
+                            if (!recp) {
 #pragma unroll
-                            for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                                for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
+#pragma unroll
+                                for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                            }
+                            s0[OL + i * TS + t] = lv[rd] + dl;
                         }
-                        s0[OL + i * TS + t] = lb[t * NX + i] + dl;
                     }
                     wave_lds_sync();
                 }
             } else if (!pred) {
-                for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : (warm ? xb[q] : 0.0); }
-                for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = warm ? ub[q] : 0.0; }
-                for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = warm ? lb[q] : 0.0; }
+                if (warm) {
+                    for (int i = lane; i < NX; i += 64) s0[i * TS] = x0[(int64_t)b * NX + i];
+                    tr_in(xb, (T + 1) * NX, TagNX{}, s0, 1);
+                    tr_in(ub, T * NU, TagNU{}, s0 + OU, 0);
+                    tr_in(lb, T * NX, TagNX{}, s0 + OL, 0);
+                } else {
+                for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : 0.0; }
+                for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = 0.0; }
+                for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[OL + i * TS + t] = 0.0; }
+                }
             } else {
                 // The sensitivity arrays are row-major [row][NP] (a row = one element of the trajectory): read lane-per-row they would put every lane in its own
                 // cache line (72-byte rows), and with four trajectories per CU the address unit, not the memory, sets the pace (measured: 29 us of a 255 us
@@ -610,7 +694,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             if constexpr (AUG) {
                 // homogeneous form: F~ = [F c; 0 1], G~ = [G; 0], Hxx~ = [Hxx rx; rx' 0], Hux~ = [Hxu' | ru], Huu
                 make_gather3(gF, ln, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(0, r * NX + c) : ((r < NX && c == NX) ? L::C0 + r : ((r == NX && c == NX) ? L::ONEB : -1)); });
-                make_gather3(gY, ln, L::CB0, [&](int r, int c) { return (r < NX && c < M) ? codeS(1, r * NU + c) : -1; });
+                // (G~ "by row blocks", one register: lane 16 k + 4 b + i <- G[4 b + k][i]; riccati_backward_aug's second operand form of G)
+                make_gather3(gY, ln, L::CB0, [&](int r, int c) { return (r < 4 && (c & 3) < M && 4 * (c >> 2) + r < NX) ? codeS(1, (4 * (c >> 2) + r) * NU + (c & 3)) : -1; });
                 make_gather3(gHxx, ln, L::CB0, [&](int r, int c) { return (r < NX && c < NX) ? codeS(2, r * NX + c) : ((r < NX && c == NX) ? L::RX + r : ((r == NX && c < NX) ? L::RX + c : -1)); });
                 make_gather3(gHux, ln, L::CB0, [&](int r, int c) { return (r < M && c < NX) ? codeS(3, c * NU + r) : ((r < M && c == NX) ? L::RU + r : -1); });
                 make_gather3(gHU, ln, L::CB0, [&](int r, int c) { return (r < M && c < M) ? codeS(4, r * NU + c) : -1; });
@@ -676,15 +761,16 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const double* r0 = pb + (tl - 1) * BS;      // the runs sit one row BELOW the step's row: the step reads at +RB, its one-step-ahead requests at +0
                 Run3 rF = run3_at(gF, r0), rY = run3_at(gY, r0), rHxx = run3_at(gHxx, r0), rHX = run3_at(gHX, r0), rHU = run3_at(gHU, r0),
                      rGr = run3_at(gGr, r0), rHux = run3_at(gHux, r0);
+                constexpr int NRY = AUG ? 1 : NRT;              // (homogeneous form: G by row blocks, one register)
                 auto move_all = [&](int bytes) {
-                    move3<NRT>(rF, bytes); move3<NRT>(rY, bytes); move3<NRT>(rHxx, bytes); move3<NRT>(rHX, bytes); move3<1>(rHU, bytes); move3<NRT>(rGr, bytes); move3<1>(rHux, bytes);
+                    move3<NRT>(rF, bytes); move3<NRY>(rY, bytes); move3<NRT>(rHxx, bytes); move3<NRT>(rHX, bytes); move3<1>(rHU, bytes); move3<NRT>(rGr, bytes); move3<1>(rHux, bytes);
                 };
-                d4 Fa = read3<NRT>(rF, RB), Ya = read3<NRT>(rY, RB), Fb = z, Yb = z;
+                d4 Fa = read3<NRT>(rF, RB), Ya = read3<NRY>(rY, RB), Fb = z, Yb = z;
                 auto bstep = [&](int tl, unsigned imm, const d4 Fc, const d4 Yc, d4& Fn, d4& Yn) {
                     const int t = t0 + tl;
                     d4 Hxx = read3<NRT>(rHxx, imm), HX2 = z, HU2 = read3<1>(rHU, imm), Grep = read3<NRT>(rGr, imm), Hux = read3<1>(rHux, imm);
                     if constexpr (!AUG) HX2 = read3<NRT>(rHX, imm);
-                    if (tl > 0) { Fn = read3<NRT>(rF, imm - RB); Yn = read3<NRT>(rY, imm - RB); }
+                    if (tl > 0) { Fn = read3<NRT>(rF, imm - RB); Yn = read3<NRY>(rY, imm - RB); }
                     d4 Ys = Yc, Fs = Fc;
                     double Hux0 = Hux[0];
                     if (scaled) {
@@ -711,7 +797,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     if constexpr (!AUG) buf_store<NRT>(rsP, soP, mW, W2);
                     if constexpr (AUG) {
                         RiccatiGains gn;
-                        ok = riccati_backward_aug<M, true>(P, Fs, Ys, Grep, Hxx, HU2[0], Hux0, scratch, lane, gn) && ok;
+                        ok = riccati_backward_aug<M, true>(P, Fs, Ys[0], Grep, Hxx, HU2[0], Hux0, scratch, lane, gn) && ok;
                         pdall = pdall && gn.pd;
                         buf_store<1>(rsG, soG, mK, gn.K);
                     } else if constexpr (SMALL) {
@@ -881,7 +967,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 f3_signal(ctl + MS2_CONS, g + 1);       // release: dx, du of the chunk are in memory
                 MS2_T1(3);
             }
-            return wave_sum(acc) + lamc;
+            return ms2_sum(acc) + lamc;
         };
 
         // ---- main loop (IPOPT's order: convergence test, sweep with inertia correction, line search).
@@ -907,7 +993,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // A correction that moves no state or control by more than PDP_MS_GUARD_TRUST (2 %) of max(1, |its value|) is trusted without the extra pass: the error of a
         // first-order prediction is of the order of the square of that.  (The steps of a running gradient-descent loop are ~1e-4: the guard then costs nothing; the
         // rocket's rejected predictions move the trajectory by 150 %.)
-        const double corr = wave_max(corr_l);
+        const double corr = ms2_max(corr_l);
         const bool guard = ph1 && (rec || pred) && (op.flags & PDP_MS_PREDICT_GUARD) != 0 && !(corr <= PDP_MS_GUARD_TRUST);
         const bool g_primal = rec ? recp : !predl;
         double g_f = 0.0, g_th = 0.0, g_pr = 0.0, g_du = 0.0, g_z = 0.0, g_l = 0.0, g_lc = 0.0, g_err = 0.0;
@@ -923,9 +1009,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             // one behind the other, with the runner asleep: +13 us per solve at C3, now +10).  Two VALU-bound waves on one SIMD take ~1.4 x the time of one, not 2 x
             // (profiles/r02_probe_two_waves_per_simd.txt).  The sums stay in registers (PART 3); the residual arrays of set 1 are written as by any other pass.
             double* s1 = Pt(1);
-            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : xb[q]; }
-            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s1[OU + i * TS + t] = ub[q]; }
-            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; s1[OL + i * TS + t] = lb[q]; }
+            for (int i = lane; i < NX; i += 64) s1[i * TS] = x0[(int64_t)b * NX + i];
+            tr_in(xb, (T + 1) * NX, TagNX{}, s1, 1);
+            tr_in(ub, T * NU, TagNU{}, s1 + OU, 0);
+            tr_in(lb, T * NX, TagNX{}, s1 + OL, 0);
             __threadfence_block();
             trial_pass(PartKeep{}, 0.0, 1, 1);
             g_f = a_f; g_th = a_th; g_pr = a_pr; g_du = a_du; g_z = a_z; g_l = a_l; g_lc = a_lc; g_fin = fin_all;
@@ -954,6 +1041,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // What the line search must remember across the sweep of a correction (directional derivative, alpha_min, theta of the attempt before, the two counters) waits
         // in the mailbox, not in registers: held live across the sweeps, those few values were exactly what the 256-register instantiation then spilled.
         const bool soc_on = (op.flags & PDP_MS_WITH_SOC) != 0;
+#ifdef PDP_MS_TIMING
+        const long long tk1 = tmi, tk2 = __builtin_readcyclecounter();
+#endif
         for (;;) {
             if (dead) break;
             const int soc_sweep = uni(ctl[MS2_SOCM]);   // this pass of the loop computes a correction of the step, not a step
@@ -1008,7 +1098,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 bool fin = true;
                 const double* dl_ = stp + OL;
                 for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) { const double v = dl_[q]; lm = fmax(lm, fabs(v)); fin = fin && fabs(v) <= 1.7e308; }
-                lm = wave_max(lm);
+                lm = ms2_max(lm);
                 if (__all(fin) && lm <= 1000.0) {
                     double* lc_ = Pt(cur) + OL;
                     for (int q = lane; q < NX * TS; q += 64) if (q % TS < T) lc_[q] = dl_[q];
@@ -1164,14 +1254,17 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             dw = 0.0;
             ++it;
         }
+#ifdef PDP_MS_TIMING
+        const long long tk3 = __builtin_readcyclecounter();
+#endif
         issue(MS2_CMD_EXIT, 0.0, cur, cur);
         if (dead) st |= PDP_MS_INTERNAL;
         {                                               // the iterate, stage-minor in the workspace, into the API arrays
             __threadfence_block();
             const double* sc = Pt(cur);
-            for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; xb[q] = sc[i * TS + t]; }
-            for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; ub[q] = sc[OU + i * TS + t]; }
-            for (int q = lane; q < T * NX; q += 64) { const int t = q / NX, i = q - t * NX; lb[q] = sc[OL + i * TS + t]; }
+            tr_out(sc, (T + 1) * NX, TagNX{}, xb);
+            tr_out(sc + OU, T * NU, TagNU{}, ub);
+            tr_out(sc + OL, T * NX, TagNX{}, lb);
         }
         if (lane == 0) {
             if (cost) cost[b] = f_cur;
@@ -1191,6 +1284,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             if (!have) st |= PDP_MS_NOGAINS;
         }
         if (lane == 0 && status) status[b] = st;
+#ifdef PDP_MS_TIMING
+        if (iter_log && op.log_rows >= 4 && it < op.log_rows / 2 - 1 && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long tk4 = __builtin_readcyclecounter();
+            double* row = iter_log + ((int64_t)b * op.log_rows + op.log_rows / 2 - 1) * 8;
+            row[0] = (double)(tk1 - tk0); row[1] = (double)(tk2 - tk1); row[2] = (double)(tk3 - tk2); row[3] = (double)(tk4 - tk3); row[4] = (double)(tk4 - tk0);
+            row[5] = (double)(__builtin_amdgcn_s_memrealtime()); row[6] = (double)tk0; row[7] = (double)tk4;
+        }
+#endif
     } else {
         // ============================================== evaluator ==============================================
         __builtin_amdgcn_s_setprio(0);

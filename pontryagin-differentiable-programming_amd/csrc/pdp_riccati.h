@@ -194,15 +194,31 @@ PDP_DEV bool riccati_backward(d4& P, d4& W0, const d4 Ft, const d4 Y2, const d4 
 // and the step is the plain Riccati step of a purely quadratic problem (same algebra as riccati_backward, K~ = [K | k], P~- = Hxx~ + F~'P~F~ - Qux~'K~,
 // whose (x, 1) block is W- = rx + F'(P c + W) - Qux' k): no separate W recursion, no [G | c] / [Hxu | rx] / [Huu | ru] packing, 13 full-tile and 9
 // four-row MFMAs instead of 18 and 10.  The (1, 1) element of P~ carries the constant of the cost-to-go (never used).
-// Ft = F~ tile, Y = G~ tile (columns < M), Grep = G~ replicated in the four column blocks, HU0 = Huu (rows < M), Hux0 = Hux~ (rows < M, n + 1 columns).
+// Ft = F~ tile, Grep = G~ replicated in the four column blocks, HU0 = Huu (rows < M, columns < M of the FIRST column block only), Hux0 = Hux~ (rows < M, n + 1 columns).
+// Quu = Huu + G'(P G) without a full-tile product (round 6; P~ G~ used to be one: 4 x 64 cycles for 4 useful columns, and 4 more four-row MFMAs on top):
+//     PGb = sum_q mfma4(P[q], Grep[q])      lane 16 i + 4 b + j  <-  (P~ G~)[4 b + i][j]      (P~ symmetric: the row block b of P~ G~ lands in COLUMN block b)
+//     Quu_b = mfma4(Gblk, PGb)              lane 16 i + 4 b + j  <-  sum_k G[4 b + k][i] (P G)[4 b + k][j]      Gblk: lane 16 k + 4 b + i  <-  G~[4 b + k][i]
+//     Quu = Huu + sum_b Quu_b               two rotations inside the rows of 16 lanes (DPP row_ror 8, 4): every column block ends with the whole sum
+// 5 four-row MFMAs and 2 adds instead of 4 full-tile and 4 four-row MFMAs: ~180 cycles of a 2075-cycle stage.
+template <int CTRL>
+PDP_DEV double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int M, bool WANT_PD = true>
-PDP_DEV bool riccati_backward_aug(d4& P, const d4 Ft, const d4 Y, const d4 Grep, const d4 Hxx, const double HU0, const double Hux0, double* scratch, int lane,
+PDP_DEV bool riccati_backward_aug(d4& P, const d4 Ft, const double Gblk, const d4 Grep, const d4 Hxx, const double HU0, const double Hux0, double* scratch, int lane,
                                   RiccatiGains& g) {
     const d4 z = zero4();
     d4 PF = mma_tn(P, Ft, z);             // P~ F~      (P~ symmetric)
-    d4 PG = mma_tn(P, Y, z);              // P~ G~
+    const double PGb = mma4_tn(P, Grep, 0.0);      // (P~ G~) by row blocks (see above)
     d4 Q2 = z;
-    Q2[0] = mma4_tn(Grep, PG, HU0);       // Quu = Huu + G'PG   (m x m)
+    {
+        double q = mma4_blk(Gblk, PGb, HU0);       // Huu (column block 0 only) + the four partial sums of G'(P G)
+        q += dpp_mov_f64<0x128>(q);                // row_ror:8
+        q += dpp_mov_f64<0x124>(q);                // row_ror:4
+        Q2[0] = q;                                 // Quu, replicated in the four column blocks
+    }
     d4 Qux = z;
     Qux[0] = mma4_tn(Grep, PF, Hux0);     // Qux~ = Hux~ + G~'P~F~   (m x (n + 1)): [Qux | Que]
     d4 Pn = mma_tn(Ft, PF, Hxx);          // Hxx~ + F~'P~F~
