@@ -144,6 +144,12 @@ PDP_DEV double uni(double v) { return __hiloint2double(__builtin_amdgcn_readfirs
 // the sweep's 50 - 100 k) instead of being hoisted out of the iteration loop, where the maps of BOTH sweeps stayed live across each other and pushed the
 // four-trajectories-per-workgroup instantiation (256 registers per wave) into scratch memory (round 3: 21 spilled VGPRs)
 PDP_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// the same for values that live in SCALAR registers (launch constants: T, the workspace pointers).  Row offsets and row pointers derived from the plain T + 1 or from `stp`
+// are invariants of the whole launch: the compiler forms all of them at kernel entry - two scalar registers per row pointer, 2 NX + NU rows per array - and keeps them, i.e.
+// parks them in lanes of vector registers (round 6: FOUR vector registers of the four-trajectory instantiation held ~200 such words, read back ~1000 times).  Derived from an
+// opaque copy inside a pass they are formed there (a few scalar instructions beside thousands of vector ones) and die with it.
+PDP_DEV int sopaque(int v) { asm volatile("" : "+s"(v)); return v; }
+template <class P> PDP_DEV P* sopaque(P* p) { asm volatile("" : "+s"(p)); return p; }
 PDP_DEV int ms2_load(int* f) { return uni(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 // wait until *f >= v; false when the partner never gets there (watchdog) or the trajectory has been declared dead
 PDP_DEV bool ms2_wait_ge(int* f, int v, int* ctl) {
@@ -293,6 +299,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         constexpr int PART = decltype(part_tag)::value;
         constexpr bool PRIMAL = PART != 2, DUAL = PART != 1, KEEP = PART == 3;
         PDP_MS2_PAR();
+        const int TSl = sopaque(TS), OUl = NX * TSl, OLl = (NX + NU) * TSl;      // (see sopaque)
+        const double* stpl = sopaque((const double*)stp);
         const bool stepped = a != 0.0, put = dst != cur;
         const double* __restrict__ ps = Pt(cur);
         const auto rsPd = __builtin_amdgcn_make_buffer_rsrc((void*)Pt(dst), 0, (int)(GRP * 8), 0x00020000);
@@ -304,48 +312,45 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         };
         a_f = 0.0; a_th = 0.0; a_pr = 0.0; a_du = 0.0; a_z = 0.0; a_l = 0.0; a_lc = 0.0;
         bool fin = true;
-        double vprev[NX], lprev[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) { vprev[i] = 0.0; lprev[i] = 0.0; }
-        for (int base = 0; base <= T; base += 64) {
+        // Groups of 64 lanes OVERLAP by one node (round 6): lane 0 of a later group evaluates node `base` once more - it was lane 63 of the group before - only to hand its f and
+        // lambda up to lane 1; it stores and sums nothing.  Carried from group to group instead (2 NX doubles held across the whole body of the pass, read with v_readlane)
+        // they cost the pass registers it does not have, for a case - more than 64 nodes - that most horizons never meet.
+        for (int base = 0; base == 0 || base < T; base += 63) {
             const int t = base + lane;
-            const bool node = t <= T, stage = t < T, last = t == T;
-            const unsigned o8 = 8u * (unsigned)(node ? t : T);      // (lanes behind the horizon read node T's slots and store nothing)
+            const bool mine = !(base > 0 && lane == 0);
+            const bool node = t <= T && mine, stage = t < T && mine, last = t == T && mine;
+            const unsigned o8 = 8u * (unsigned)(t <= T ? t : T);      // (lanes behind the horizon read node T's slots and store nothing)
             const unsigned on = node ? o8 : MS2_OOB, os = stage ? o8 : MS2_OOB, oc = (node && t > 0) ? o8 - 8u : MS2_OOB;
             double xc[NX], uc[NU], lc[NX], v[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const double xa = sm_ld(ps + i * TS, o8), xd = sm_ld(stp + i * TS, o8), la = sm_ld(ps + OL + i * TS, o8), ld = sm_ld(stp + OL + i * TS, o8);
+                const double xa = sm_ld(ps + i * TSl, o8), xd = sm_ld(stpl + i * TSl, o8), la = sm_ld(ps + OLl + i * TSl, o8), ld = sm_ld(stpl + OLl + i * TSl, o8);
                 xc[i] = stepped ? fma(a, xd, xa) : xa;
                 lc[i] = stepped ? fma(a, ld, la) : la;                 // (slot T of the lambda / u rows exists and is unused: node T reads it and drops it)
             }
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { const double ua = sm_ld(ps + OU + i * TS, o8), ud = sm_ld(stp + OU + i * TS, o8); uc[i] = stepped ? fma(a, ud, ua) : ua; }
+            for (int i = 0; i < NU; ++i) { const double ua = sm_ld(ps + OUl + i * TSl, o8), ud = sm_ld(stpl + OUl + i * TSl, o8); uc[i] = stepped ? fma(a, ud, ua) : ua; }
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                if constexpr (PRIMAL) { a_z = fmax(a_z, node ? fabs(xc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(i * TS) * 8u, on, xc[i]); }
-                if constexpr (DUAL) { a_l = fmax(a_l, stage ? fabs(lc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OL + i * TS) * 8u, os, lc[i]); }
+                if constexpr (PRIMAL) { a_z = fmax(a_z, node ? fabs(xc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(i * TSl) * 8u, on, xc[i]); }
+                if constexpr (DUAL) { a_l = fmax(a_l, stage ? fabs(lc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OLl + i * TSl) * 8u, os, lc[i]); }
             }
             if constexpr (PRIMAL) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) { a_z = fmax(a_z, stage ? fabs(uc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OU + i * TS) * 8u, os, uc[i]); }
+                for (int i = 0; i < NU; ++i) { a_z = fmax(a_z, stage ? fabs(uc[i]) : 0.0); if (put) bst(rsPd, (unsigned)(OUl + i * TSl) * 8u, os, uc[i]); }
             }
             double nl[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {                              // the previous node's lambda
-                nl[i] = ms2_up1(lc[i]);
-                if (lane == 0) nl[i] = lprev[i];
-                lprev[i] = readlane_f64(lc[i], 63);
+                nl[i] = ms2_up1(lc[i]);                                    // (lane 0: its own - node 0 has no predecessor, a later group's lane 0 uses none)
             }
             if constexpr (PRIMAL) {
                 Mdl::dyn(xc, uc, th, pc, v);
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
-                    double nv = ms2_up1(v[i]);                           // the previous node's f(x, u)
-                    if (lane == 0) nv = vprev[i];
-                    vprev[i] = readlane_f64(v[i], 63);
+                    const double nv = ms2_up1(v[i]);                     // the previous node's f(x, u)
                     const double ci = nv - xc[i];                        // defect of stage t - 1
-                    bst(rsRd, (unsigned)(OL + i * TS) * 8u, oc, ci);
+                    bst(rsRd, (unsigned)(OLl + i * TSl) * 8u, oc, ci);
                     const bool has = node && t > 0;
                     a_th += has ? fabs(ci) : 0.0; a_pr = fmax(a_pr, has ? fabs(ci) : 0.0); a_lc += has ? nl[i] * ci : 0.0;
                     fin = fin && (!has || fabs(ci) <= 1.7e308);
@@ -364,14 +369,14 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     const double g = last ? hT[i] - nl[i] : ((stage && t > 0) ? v[i] - nl[i] : 0.0);      // grad_x L of node t (x_0 is fixed: no row)
-                    bst(rsRd, (unsigned)(i * TS) * 8u, on, g);
+                    bst(rsRd, (unsigned)(i * TSl) * 8u, on, g);
                     a_du = fmax(a_du, node ? fabs(g) : 0.0);
                     fin = fin && (!node || fabs(g) <= 1.7e308);
                 }
                 double hu[NU];
                 Mdl::dHu(xc, uc, lc, th, pc, hu);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OU + i * TS) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
+                for (int i = 0; i < NU; ++i) { bst(rsRd, (unsigned)(OUl + i * TSl) * 8u, os, hu[i]); a_du = fmax(a_du, stage ? fabs(hu[i]) : 0.0); fin = fin && (!stage || fabs(hu[i]) <= 1.7e308); }
             }
         }
         if constexpr (PRIMAL) { a_f = ms2_sum(a_f); a_th = ms2_sum(a_th); a_lc = ms2_sum(a_lc); a_pr = ms2_max(a_pr); a_z = ms2_max(a_z); }
@@ -398,38 +403,72 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     using PartDual = std::integral_constant<int, 2>;
     using PartKeep = std::integral_constant<int, 3>;
 
-    // Stage-major API array [t][NC] <-> stage-minor workspace rows [i TS + t], one wave: all loads of a batch (up to UNB x 64 elements) are requested before the first
-    // store - written as plain `for (q = lane; ...) dst[..] = src[q]` loops these copies were 24 dependent round trips to memory per array set (round 6, probes/ms_timeline.py:
-    // 24 k cycles for the starting point, 17 k for the result, of a 500 k-cycle solve).  `from_t`: first stage copied (1: node 0 of the states is x_0, written by the caller).
-    constexpr int UNB = 12;
-    // (index arithmetic from an opaque lane id, like the sweeps' maps: shared between the copies at the start and the one at the end of the launch it would stay live across the
-    // whole iteration loop - the four-trajectory instantiation then spills)
-    auto tr_in = [&](const double* __restrict__ src, int N, auto nc_tag, double* dst, int from_t) {
+    // Stage-major API array [t][NC] <-> stage-minor workspace rows [i TS + t], by ONE wave, transposed through its LDS scratch so that BOTH sides are coalesced: lane = stage on
+    // the workspace side (64 consecutive doubles per row and instruction), lane + 64 k on the API side.  Round 6 (probes/ms_timeline.py): written as `for (q = lane; ...)
+    // dst[..] = src[q]` loops these copies were 24 dependent round trips to memory with one cache line per LANE on the workspace side - 24 k cycles for the starting point,
+    // 17 k for the result, of a 500 k-cycle solve; with the loads batched but still scattered they slowed a trial pass running beside them by a third (the address unit).
+    // (Index arithmetic from an opaque lane id, like the sweeps' maps: shared between the copies at the start and at the end of the launch it would stay live across the whole
+    // iteration loop.)  `from_t`: first stage written (1: node 0 of the states is x_0, written by the caller).  (Tried and dropped: the runner writing the TRIAL point into the
+    // API arrays beside the evaluator's trial pass, so that a solve ending with that trial has nothing left to write - the copy costs the pass what it saves at the end.)
+    // rows_get: the API rows of the stages [0, ng), ng <= 64, of `src` (contiguous, NC per stage) into registers, lane = stage
+    auto rows_get = [&](const double* __restrict__ src, int ng, auto nc_tag, auto& v, double* buf) {
         constexpr int NC = decltype(nc_tag)::value;
+        constexpr int TB = RICCATI_SCRATCH / NC < 64 ? RICCATI_SCRATCH / NC : 64;      // stages per LDS batch
+        constexpr int KQ = (TB * NC + 63) / 64;
         const int ln = opaque(lane);
-        for (int q0 = 0; q0 < N; q0 += 64 * UNB) {
-            double v[UNB];
 #pragma unroll
-            for (int k = 0; k < UNB; ++k) { const int q = q0 + ln + 64 * k; v[k] = src[q < N ? q : N - 1]; }
-            asm volatile("" ::: "memory");
+        for (int i = 0; i < NC; ++i) v[i] = 0.0;
+        for (int b0 = 0; b0 < ng; b0 += TB) {
+            const int nq = min(TB, ng - b0) * NC;
+            const double* s_ = src + (int64_t)b0 * NC;
+            double w[KQ];
 #pragma unroll
-            for (int k = 0; k < UNB; ++k) {
-                const int q = q0 + ln + 64 * k, t = q / NC, i = q - t * NC;
-                if (q < N && t >= from_t) dst[i * TS + t] = v[k];
+            for (int k = 0; k < KQ; ++k) { const int idx = ln + 64 * k; w[k] = s_[idx < nq ? idx : 0]; }
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) { const int idx = ln + 64 * k; if (idx < nq) buf[idx] = w[k]; }
+            wave_lds_sync();
+            if (ln >= b0 && ln < b0 + TB) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) v[i] = buf[(ln - b0) * NC + i];
+            }
+        }
+        wave_lds_sync();
+    };
+    auto rows_in = [&](const double* __restrict__ src, int nt, auto nc_tag, double* dst, int from_t, double* buf) {
+        constexpr int NC = decltype(nc_tag)::value;
+        for (int g0 = 0; g0 < nt; g0 += 64) {
+            double v[NC];
+            rows_get(src + (int64_t)g0 * NC, min(64, nt - g0), nc_tag, v, buf);
+            const int t = g0 + opaque(lane);
+            if (t < nt && t >= from_t) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) dst[i * TS + t] = v[i];
             }
         }
     };
-    auto tr_out = [&](const double* src, int N, auto nc_tag, double* __restrict__ dst) {
+    auto rows_out = [&](const double* src, int nt, auto nc_tag, double* __restrict__ dst, double* buf) {
         constexpr int NC = decltype(nc_tag)::value;
+        constexpr int TB = RICCATI_SCRATCH / NC < 64 ? RICCATI_SCRATCH / NC : 64;
         const int ln = opaque(lane);
-        for (int q0 = 0; q0 < N; q0 += 64 * UNB) {
-            double v[UNB];
+        for (int g0 = 0; g0 < nt; g0 += 64) {
+            const int t = g0 + ln < nt ? g0 + ln : nt - 1;
+            double v[NC];
 #pragma unroll
-            for (int k = 0; k < UNB; ++k) { int q = q0 + ln + 64 * k; q = q < N ? q : N - 1; const int t = q / NC, i = q - t * NC; v[k] = src[i * TS + t]; }
-            asm volatile("" ::: "memory");
+            for (int i = 0; i < NC; ++i) v[i] = src[i * TS + t];
+            for (int b0 = 0; b0 < 64 && g0 + b0 < nt; b0 += TB) {
+                const int nq = min(TB, nt - g0 - b0) * NC;
+                wave_lds_sync();
+                if (ln >= b0 && ln < b0 + TB) {
 #pragma unroll
-            for (int k = 0; k < UNB; ++k) { const int q = q0 + ln + 64 * k; if (q < N) dst[q] = v[k]; }
+                    for (int i = 0; i < NC; ++i) buf[(ln - b0) * NC + i] = v[i];
+                }
+                wave_lds_sync();
+                double* d_ = dst + (int64_t)(g0 + b0) * NC;
+                for (int q = ln; q < nq; q += 64) d_[q] = buf[q];
+            }
         }
+        wave_lds_sync();
     };
     using TagNX = std::integral_constant<int, NX>;
     using TagNU = std::integral_constant<int, NU>;
@@ -439,6 +478,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         __builtin_amdgcn_s_setprio(3);
 #ifdef PDP_MS_TIMING      // whole-launch timeline of the runner (row log_rows / 2 - 1 of the log): entry | starting point loaded | first residuals read | loop left | results written
         const long long tk0 = __builtin_readcyclecounter();
+        long long tkw = 0, tkc = 0, tkp = 0;            // record prologue: cycles waiting for the loads of a batch | computing | before the first batch
 #endif
         {
             double th0[NP > 0 ? NP : 1], pc0[Mdl::NPC];
@@ -462,69 +502,105 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         const bool pred = !rec && warm && (op.flags & PDP_MS_PREDICT) != 0 && op.dtheta && op.dxdp && op.dudp;
         const bool predl = pred && op.riccati != nullptr;
         double corr_l = 0.0;           // largest predicted change of a state or control against max(1, |its value|): the guard below trusts small corrections unseen
-        auto corr_upd = [&](double d, double v) { corr_l = fabs(d) <= 1.7e308 ? fmax(corr_l, fabs(d) / fmax(1.0, fabs(v))) : 1e300; };      // (a non-finite correction is never trusted)
+        // (only the comparison with PDP_MS_GUARD_TRUST is ever used: |d| <= trust max(1, |v|) says the same without the division - fifty of them per lane since the prediction runs
+        // with one lane per stage; a non-finite correction fails the comparison and is never trusted)
+        auto corr_upd = [&](double d, double v) { corr_l = fabs(d) <= PDP_MS_GUARD_TRUST * fmax(1.0, fabs(v)) ? corr_l : 1e300; };
         {
             double* s0 = Pt(0);
             constexpr int RSZ = oc_riccati_doubles<Mdl>();
             if (rec) {
-                // Round 6.  The records of a BATCH of CH stages (as many as the pool holds: CH x PredRec::SIZE floats, contiguous in memory) go from memory straight into
-                // LDS (global_load_lds_dword: no registers, 64 consecutive floats per instruction), this lane's x_{t+1}, lambda_t, u_t of the batch are requested behind
-                // them, and ONE wait covers all of it; then lane = (stage, row) forms dx_{t+1}, du_t, parks dx in LDS, and - after the exchange -
-                // dlam_t = W_{t+1} dtheta + P_{t+1} dx_{t+1}.  Until round 6 this was a loop over blocks of 64 / NX stages with three dependent round trips to memory per
-                // block (records -> registers -> LDS, then x / u, then lambda): 70 k cycles of a 510 k-cycle solve at C3 (probes/ms_timeline.py), the runner's alone.
-                // Same sums in the same order as before (and as oc_predict_kernel).
+                // Round 6.  The records of a BATCH of stages (as many as the pool holds - all of them for the X | U part of a quadrotor record at T = 50; contiguous in
+                // memory) go from memory straight into LDS (global_load_lds: no registers, a kilobyte per instruction for whole records), every lane's x_{t+1}, lambda_t,
+                // u_t of the batch are requested behind them, and ONE wait covers all of it.  Then lane = item (row i, stage sg) WITH THE STAGE RUNNING FASTEST - the stores
+                // into the stage-minor rows are runs of consecutive doubles - forms dx_{t+1}, du_t, parks dx in LDS, and, after the exchange,
+                // dlam_t = W_{t+1} dtheta + P_{t+1} dx_{t+1}.  Until round 6: blocks of 64 / NX stages, three dependent round trips to memory per block (records -> registers
+                // -> LDS, then x / u, then lambda), the row running fastest (every lane of a store in its own cache line): 70 k cycles of a 510 k-cycle solve at C3
+                // (probes/ms_timeline.py), the runner's alone.  (Also measured: one lane per stage with literal offsets - no index arithmetic, no exchange, but a quarter of the
+                // lanes busy: twice as slow.)  Same sums in the same order as before (and as oc_predict_kernel).
                 using R = PredRec<Mdl>;
-                constexpr int CHMAX_ = (4 * L::BUF - 192) / (R::SIZE + 2 * NX);
-                constexpr int CHCAP = 256 / NX < 64 ? 256 / NX : 64;         // (at most four rounds of 64 (stage, row) items per batch: their x / lambda values wait in registers)
-                constexpr int CHMAX = CHMAX_ < CHCAP ? CHMAX_ : CHCAP;
-                static_assert(CHMAX >= 1, "prediction record: one stage must fit the pool");
-                constexpr int RD = (CHMAX * NX + 63) / 64, RDU = (CHMAX * NU + 63) / 64;
+                constexpr int RD = NX, RDU = NU;                    // rounds of 64 items a batch of 64 stages needs
                 const int RS = recp ? R::P : R::SIZE;               // floats per stage in LDS (PDP_MS_PREDICT_PRIMAL: the X | U part of every record only)
-                const int nbat = (T + CHMAX - 1) / CHMAX, CH = (T + nbat - 1) / nbat;
+                const int chcap_ = (4 * L::BUF - 320) / (RS + (recp ? 0 : 2 * NX));      // (256 floats of slack behind the records: the last load instruction of a batch writes a whole kilobyte)
+                const int chcap = chcap_ < 64 ? chcap_ : 64;
+                const int nbat = (T + chcap - 1) / chcap, CH = (T + nbat - 1) / nbat;
                 float* stage = (float*)pool;
-                double* dxb = pool + (CHMAX * R::SIZE + 64 + 1) / 2;          // dx of the batch: [stage][row]
+                double* dxb = pool + (chcap * RS + 256 + 1) / 2;   // dx of the batch: [stage][row]
                 double dth[NP > 0 ? NP : 1];
 #pragma unroll
                 for (int j = 0; j < NP; ++j) dth[j] = op.dtheta[(int64_t)b * op.dtheta_bstride + j];
                 for (int i = lane; i < NX; i += 64) s0[i * TS] = x0[(int64_t)b * NX + i];
+#ifdef PDP_MS_TIMING
+                tkp = __builtin_readcyclecounter() - tk0;
+#endif
                 for (int t0 = 0; t0 < T; t0 += CH) {
+#ifdef PDP_MS_TIMING
+                    const long long tb0_ = __builtin_readcyclecounter();
+#endif
                     const int nst = min(CH, T - t0), nd = nst * RS;
                     const float* s_ = rec + ((int64_t)b * T + t0) * R::SIZE;
-                    for (int k0 = 0; k0 < nd; k0 += 64) {
-                        int idx = k0 + lane;
-                        idx = idx < nd ? idx : 0;
-                        if (recp) { const int si = idx / R::P; idx = si * R::SIZE + (idx - si * R::P); }
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + idx), (__attribute__((address_space(3))) void*)(stage + k0), 4, 0, 0);
+                    if (recp) {
+                        for (int k0 = 0; k0 < nd; k0 += 64) {
+                            int idx = k0 + lane;
+                            idx = idx < nd ? idx : 0;
+                            const int si = idx / R::P;
+                            idx = si * R::SIZE + (idx - si * R::P);
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + idx), (__attribute__((address_space(3))) void*)(stage + k0), 4, 0, 0);
+                        }
+                    } else {                                        // whole records: 16 bytes per lane and instruction (global_load_lds_dwordx4, gfx950)
+                        for (int k0 = 0; k0 < nd; k0 += 256) {
+                            int idx = k0 + 4 * lane;
+                            idx = idx + 4 <= nd ? idx : 0;         // (no read beyond the batch; the words behind the last whole quadruple come in with the dword form below)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + idx), (__attribute__((address_space(3))) void*)(stage + k0), 16, 0, 0);
+                        }
+                        const int tail = nd & ~3;
+                        if (tail < nd)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + (tail + lane < nd ? tail + lane : tail)), (__attribute__((address_space(3))) void*)(stage + tail), 4, 0, 0);      // (behind the quadruples: loads land in order; lanes beyond nd write into the slack)
                     }
+                    const int mdiv = ((1 << 20) + nst - 1) / nst;   // it_ / nst = (it_ * mdiv) >> 20, exact for it_ < 1024
+                    const int nrx = (nst * NX + 63) >> 6, nru = (nst * NU + 63) >> 6;      // rounds of this batch
                     double xv[RD], lv[RD], uv[RDU];
 #pragma unroll
                     for (int rd = 0; rd < RD; ++rd) {
-                        const int it_ = lane + 64 * rd, q = t0 * NX + (it_ < nst * NX ? it_ : 0);
-                        xv[rd] = xb[NX + q];
-                        lv[rd] = lb[q];
+                        xv[rd] = 0.0; lv[rd] = 0.0;
+                        if (rd < nrx) {
+                            const int it_ = lane + 64 * rd, ok_ = it_ < nst * NX, i = ok_ ? (it_ * mdiv) >> 20 : 0, sg = ok_ ? it_ - i * nst : 0, q = (t0 + sg) * NX + i;
+                            xv[rd] = xb[NX + q];
+                            lv[rd] = lb[q];
+                        }
                     }
 #pragma unroll
-                    for (int rd = 0; rd < RDU; ++rd) { const int it_ = lane + 64 * rd; uv[rd] = ub[t0 * NU + (it_ < nst * NU ? it_ : 0)]; }
+                    for (int rd = 0; rd < RDU; ++rd) {
+                        uv[rd] = 0.0;
+                        if (rd < nru) {
+                            const int it_ = lane + 64 * rd, ok_ = it_ < nst * NU, iu = ok_ ? (it_ * mdiv) >> 20 : 0, sg = ok_ ? it_ - iu * nst : 0;
+                            uv[rd] = ub[(t0 + sg) * NU + iu];
+                        }
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PDP_MS_TIMING
+                    const long long tb1_ = __builtin_readcyclecounter();
+                    tkw += tb1_ - tb0_;
+#endif
 #pragma unroll
                     for (int rd = 0; rd < RD; ++rd) {
                         const int it_ = lane + 64 * rd;
-                        if (it_ < nst * NX) {
-                            const int sg = it_ / NX, i = it_ - sg * NX, t = t0 + sg;
+                        if (rd < nrx && it_ < nst * NX) {
+                            const int i = (it_ * mdiv) >> 20, sg = it_ - i * nst, t = t0 + sg;
                             const float* r = stage + sg * RS;
                             double dx = 0.0;
 #pragma unroll
                             for (int j = 0; j < NP; ++j) dx = fma((double)r[R::X + i * NP + j], dth[j], dx);
-                            dxb[it_] = dx;
+                            if (!recp) dxb[sg * NX + i] = dx;
                             corr_upd(dx, xv[rd]);
                             s0[i * TS + t + 1] = xv[rd] + dx;
+                            if (recp) s0[OL + i * TS + t] = lv[rd];
                         }
                     }
 #pragma unroll
                     for (int rd = 0; rd < RDU; ++rd) {
                         const int it_ = lane + 64 * rd;
-                        if (it_ < nst * NU) {
-                            const int sg = it_ / NU, iu = it_ - sg * NU, t = t0 + sg;
+                        if (rd < nru && it_ < nst * NU) {
+                            const int iu = (it_ * mdiv) >> 20, sg = it_ - iu * nst, t = t0 + sg;
                             const float* r = stage + sg * RS;
                             double du = 0.0;
 #pragma unroll
@@ -534,30 +610,36 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         }
                     }
                     wave_lds_sync();
+                    if (!recp) {
 #pragma unroll
-                    for (int rd = 0; rd < RD; ++rd) {
-                        const int it_ = lane + 64 * rd;
-                        if (it_ < nst * NX) {
-                            const int sg = it_ / NX, i = it_ - sg * NX, t = t0 + sg;
-                            const float* r = stage + sg * RS;
-                            double dl = 0.0;
-                            if (!recp) {
+                        for (int rd = 0; rd < RD; ++rd) {
+                            const int it_ = lane + 64 * rd;
+                            if (rd < nrx && it_ < nst * NX) {
+                                const int i = (it_ * mdiv) >> 20, sg = it_ - i * nst, t = t0 + sg;
+                                const float* r = stage + sg * RS;
+                                double dl = 0.0;
 #pragma unroll
                                 for (int j = 0; j < NP; ++j) dl = fma((double)r[R::W + i * NP + j], dth[j], dl);
 #pragma unroll
                                 for (int k = 0; k < NX; ++k) dl = fma((double)r[R::P + R::tri(i, k)], dxb[sg * NX + k], dl);
+                                s0[OL + i * TS + t] = lv[rd] + dl;
                             }
-                            s0[OL + i * TS + t] = lv[rd] + dl;
                         }
                     }
                     wave_lds_sync();
+#ifdef PDP_MS_TIMING
+                    tkc += __builtin_readcyclecounter() - tb1_;
+#endif
                 }
             } else if (!pred) {
                 if (warm) {
+#ifdef PDP_MS_TIMING
+                    tkp = __builtin_readcyclecounter() - tk0;
+#endif
                     for (int i = lane; i < NX; i += 64) s0[i * TS] = x0[(int64_t)b * NX + i];
-                    tr_in(xb, (T + 1) * NX, TagNX{}, s0, 1);
-                    tr_in(ub, T * NU, TagNU{}, s0 + OU, 0);
-                    tr_in(lb, T * NX, TagNX{}, s0 + OL, 0);
+                    rows_in(xb, T + 1, TagNX{}, s0, 1, scratch);
+                    rows_in(ub, T, TagNU{}, s0 + OU, 0, scratch);
+                    rows_in(lb, T, TagNX{}, s0 + OL, 0, scratch);
                 } else {
                 for (int q = lane; q < (T + 1) * NX; q += 64) { const int t = q / NX, i = q - t * NX; s0[i * TS + t] = t == 0 ? x0[(int64_t)b * NX + i] : 0.0; }
                 for (int q = lane; q < T * NU; q += 64) { const int t = q / NU, i = q - t * NU; s0[OU + i * TS + t] = 0.0; }
@@ -1010,9 +1092,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             // (profiles/r02_probe_two_waves_per_simd.txt).  The sums stay in registers (PART 3); the residual arrays of set 1 are written as by any other pass.
             double* s1 = Pt(1);
             for (int i = lane; i < NX; i += 64) s1[i * TS] = x0[(int64_t)b * NX + i];
-            tr_in(xb, (T + 1) * NX, TagNX{}, s1, 1);
-            tr_in(ub, T * NU, TagNU{}, s1 + OU, 0);
-            tr_in(lb, T * NX, TagNX{}, s1 + OL, 0);
+            rows_in(xb, T + 1, TagNX{}, s1, 1, scratch);
+            rows_in(ub, T, TagNU{}, s1 + OU, 0, scratch);
+            rows_in(lb, T, TagNX{}, s1 + OL, 0, scratch);
             __threadfence_block();
             trial_pass(PartKeep{}, 0.0, 1, 1);
             g_f = a_f; g_th = a_th; g_pr = a_pr; g_du = a_du; g_z = a_z; g_l = a_l; g_lc = a_lc; g_fin = fin_all;
@@ -1262,9 +1344,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         {                                               // the iterate, stage-minor in the workspace, into the API arrays
             __threadfence_block();
             const double* sc = Pt(cur);
-            tr_out(sc, (T + 1) * NX, TagNX{}, xb);
-            tr_out(sc + OU, T * NU, TagNU{}, ub);
-            tr_out(sc + OL, T * NX, TagNX{}, lb);
+            rows_out(sc, T + 1, TagNX{}, xb, scratch);
+            rows_out(sc + OU, T, TagNU{}, ub, scratch);
+            rows_out(sc + OL, T, TagNX{}, lb, scratch);
         }
         if (lane == 0) {
             if (cost) cost[b] = f_cur;
@@ -1290,7 +1372,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             const long long tk4 = __builtin_readcyclecounter();
             double* row = iter_log + ((int64_t)b * op.log_rows + op.log_rows / 2 - 1) * 8;
             row[0] = (double)(tk1 - tk0); row[1] = (double)(tk2 - tk1); row[2] = (double)(tk3 - tk2); row[3] = (double)(tk4 - tk3); row[4] = (double)(tk4 - tk0);
-            row[5] = (double)(__builtin_amdgcn_s_memrealtime()); row[6] = (double)tk0; row[7] = (double)tk4;
+            row[5] = (double)tkp; row[6] = (double)tkw; row[7] = (double)tkc;
         }
 #endif
     } else {
@@ -1298,6 +1380,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         __builtin_amdgcn_s_setprio(0);
         bool dead = false;
         int last = 0;
+        // (this wave's own copies of the launch constants its row offsets derive from: see sopaque)
+        const int TSe = sopaque(TS), OUe = NX * TSe, OLe = (NX + NU) * TSe;
+        double* const stpe = sopaque(stp);
 #ifdef PDP_MS_TIMING      // cumulative cycles of the evaluator: trial passes | updates | backward chunk evaluations | forward chunk evaluations | dlam | terminal | waits inside a sweep | number of trial passes
         long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et0 = 0;
 #define MS2_E0() et0 = __builtin_readcyclecounter()
@@ -1313,12 +1398,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             double* __restrict__ ps = Pt(cur);
             double xr[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xr[i] = uni(ps[i * TS]);
+            for (int i = 0; i < NX; ++i) xr[i] = uni(ps[i * TSe]);
             for (int base = 0; base < T; base += 64) {
                 const int tl_ = base + lane < T ? base + lane : T - 1;
                 double ul[NU];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) ul[i] = ps[OU + i * TS + tl_];
+                for (int i = 0; i < NU; ++i) ul[i] = ps[OUe + i * TSe + tl_];
                 const int cnt = T - base < 64 ? T - base : 64;
                 for (int s_ = 0; s_ < cnt; ++s_) {
                     double uc[NU], v[NX];
@@ -1326,10 +1411,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     for (int i = 0; i < NU; ++i) uc[i] = readlane_f64(ul[i], s_);
                     Mdl::dyn(xr, uc, th, pc, v);
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { xr[i] = v[i]; if (lane == 0) ps[i * TS + base + s_ + 1] = v[i]; }
+                    for (int i = 0; i < NX; ++i) { xr[i] = v[i]; if (lane == 0) ps[i * TSe + base + s_ + 1] = v[i]; }
                 }
             }
-            for (int q = lane; q < NX * TS; q += 64) ps[OL + q] = 0.0;
+            for (int q = lane; q < NX * TSe; q += 64) ps[OLe + q] = 0.0;
             __threadfence_block();
         };
         // multiplier step of the stages [t0, t0 + cnt): dlam_t = P_{t+1} dx_{t+1} + W_{t+1}   (PDP.py:604), lane = stage.  `pp`: the stage's (P, W) record,
@@ -1375,10 +1460,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const unsigned o8 = 8u * (unsigned)t;
                 double d[NX], acc[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) d[i] = sm_ld(stp + i * TS, o8 + 8u);
+                for (int i = 0; i < NX; ++i) d[i] = sm_ld(stpe + i * TSe, o8 + 8u);
                 dlam_row(pw + (int64_t)t * PWSZ, d, acc);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) sm_st(stp + OL + i * TS, o8, acc[i]);
+                for (int i = 0; i < NX; ++i) sm_st(stpe + OLe + i * TSe, o8, acc[i]);
             }
         };
         // route 2 (four trajectories per CU): the records of a block of stages are contiguous in the workspace - they are copied into a free pool buffer
@@ -1400,7 +1485,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) { const int idx = lane + 64 * q; v[q] = src[idx < n ? idx : 0]; }
 #pragma unroll
-                for (int q = 0; q < NQD; ++q) { const int k = lane + 64 * q, kk = k < nd ? k : 0, j = kk / nb, sidx = kk - j * nb; w[q] = stp[j * TS + t0 + s0 + sidx + 1]; }
+                for (int q = 0; q < NQD; ++q) { const int k = lane + 64 * q, kk = k < nd ? k : 0, j = kk / nb, sidx = kk - j * nb; w[q] = stpe[j * TSe + t0 + s0 + sidx + 1]; }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -1417,7 +1502,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     for (int i = 0; i < NX; ++i) d[i] = dl[lane * NX + i];
                     dlam_row(sbuf + lane * PSTR, d, acc);
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) sm_st(stp + OL + i * TS, o8, acc[i]);
+                    for (int i = 0; i < NX; ++i) sm_st(stpe + OLe + i * TSe, o8, acc[i]);
                 }
             }
             wave_lds_sync();
@@ -1451,7 +1536,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 const int sw = type == MS2_CMD_SWEEP ? cur : dst;          // the set the sweep linearises at
                 const double* __restrict__ ps = Pt(sw);
                 const double* __restrict__ rd = Rs(sw);
-                const double* __restrict__ cdef = (type == MS2_CMD_SWEEP && csrc) ? csoc : rd + OL;       // defects of the point, or the constraint block of a second-order correction
+                const double* __restrict__ cdef = (type == MS2_CMD_SWEEP && csrc) ? csoc : rd + OLe;       // defects of the point, or the constraint block of a second-order correction
                 bool aborted = false;
                 auto stop = [&]() { aborted = aborted || ms2_load(ctl + MS2_ABORT) == last; return aborted || dead; };
                 // terminal stage: hxx(x_T) entries and the terminal gradient
@@ -1461,7 +1546,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     PDP_MS2_PAR();
                     double xT[NX];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TS + T]; dlT[i] = rd[i * TS + T]; }      // (one lane: plain indexing)
+                    for (int i = 0; i < NX; ++i) { xT[i] = ps[i * TSe + T]; dlT[i] = rd[i * TSe + T]; }      // (one lane: plain indexing)
                     PackedSink s{fin + L::NCFIN};
                     Mdl::eval_fin(xT, nullptr, nullptr, th, pc, s);
                 }
@@ -1486,9 +1571,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         // (every load of the stage first, then the LDS stores: interleaved, each store waits for its loads - a trip to memory per component)
                         double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); lc[i] = sm_ld(ps + OL + i * TS, o8); cc[i] = sm_ld(cdef + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8); }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TSe, o8); lc[i] = sm_ld(ps + OLe + i * TSe, o8); cc[i] = sm_ld(cdef + i * TSe, o8); gx[i] = sm_ld(rd + i * TSe, o8); }
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
+                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OUe + i * TSe, o8); gu[i] = sm_ld(rd + OUe + i * TSe, o8); }
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NX; ++i) { row[L::C0 + i] = cc[i]; row[L::RX + i] = gx[i]; }
@@ -1524,9 +1609,9 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                         double* row = pool + (g & 1) * L::BUF + lane * FS;
                         double cc[NX], gx[NX], gu[NU];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TS, o8); cc[i] = sm_ld(cdef + i * TS, o8); gx[i] = sm_ld(rd + i * TS, o8 + 8u); }
+                        for (int i = 0; i < NX; ++i) { xc[i] = sm_ld(ps + i * TSe, o8); cc[i] = sm_ld(cdef + i * TSe, o8); gx[i] = sm_ld(rd + i * TSe, o8 + 8u); }
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OU + i * TS, o8); gu[i] = sm_ld(rd + OU + i * TS, o8); }
+                        for (int i = 0; i < NU; ++i) { uc[i] = sm_ld(ps + OUe + i * TSe, o8); gu[i] = sm_ld(rd + OUe + i * TSe, o8); }
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int i = 0; i < NX; ++i) { row[L::FC0 + i] = cc[i]; row[L::FRX + i] = gx[i]; }

@@ -37,6 +37,7 @@ for system, B, T in (("quadrotor", 1024, 50), ("cartpole", 256, 50)):
     cl = lambda: tuple(a.clone() for a in warm)
     cases = (("plain warm start", lambda m, **kw: m.oc_solve_ms(x0d, theta1, T, warm=cl(), consume_warm=True, **kw)),
              ("predicted start (record), guarded", lambda m, **kw: m.oc_solve_ms(x0d, theta1, T, warm=cl(), consume_warm=True, predict=dict(dtheta=dth, record=sens0["predict_record"]), **kw)),
+             ("predicted start (X | U part of the record), guarded", lambda m, **kw: m.oc_solve_ms(x0d, theta1, T, warm=cl(), consume_warm=True, predict=dict(dtheta=dth, record=sens0["predict_record"], primal=True), **kw)),
              ("predicted start (record), guard off", lambda m, **kw: m.oc_solve_ms(x0d, theta1, T, warm=cl(), consume_warm=True, predict=dict(dtheta=dth, record=sens0["predict_record"], guard=False), **kw)))
     for label, call in cases:
         for _ in range(2):
@@ -48,13 +49,11 @@ for system, B, T in (("quadrotor", 1024, 50), ("cartpole", 256, 50)):
         row = log[:, LR // 2 - 1, :]
         ok = it < LR // 2 - 1
         med = np.median(row[ok], axis=0)
-        span = row[ok][:, 7].max() - row[ok][:, 6].min()
         per_it = np.median(np.array([log[b, :it[b], 7].mean() for b in range(B) if ok[b] and it[b] > 0]))
         print("%s %s B=%d: timing build %.4f ms, product build %.4f ms; iterations mean %.2f max %d" % (system, label, B, ms, prod, it.mean(), it.max()))
         print("   runner, median over the batch (cycles): entry -> start loaded %d | -> first residuals (+ guard) %d | iteration loop %d (per iteration %d) | -> results written %d | total %d"
               % (med[0], med[1], med[2], per_it, med[3], med[4]))
-        print("   first entry -> last exit over the batch: %d cycles = %.3f GHz against the event time; entry spread %d, exit spread %d"
-              % (span, span / (ms * 1e-3) / 1e9, row[ok][:, 6].max() - row[ok][:, 6].min(), row[ok][:, 7].max() - row[ok][:, 7].min()))
+        print("   record prologue: %d cycles before the first batch | %d waiting for the batches' loads | %d computing" % (med[5], med[6], med[7]))
         for k in (3, 2):
             sel = ok & (it == k)
             if sel.any():
