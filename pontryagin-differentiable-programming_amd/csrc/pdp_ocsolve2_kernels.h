@@ -77,8 +77,8 @@ struct Ms2Layout {
     static constexpr int NCFIN = 1 + Mdl::FIN_NCONST;
     static constexpr int PAR = FIN + NCFIN + Mdl::FIN_NVAR;               // theta (NP) | theta-only precomputed values (NPC)
     static constexpr int DLT = PAR + NP + Mdl::NPC;                       // NX: terminal gradient h_x(x_T) - lambda_T
-    static constexpr int CTL = (DLT + NX + 1) & ~1;                       // mailbox: 16 ints | 24 doubles
-    static constexpr int POOL = CTL + 32;
+    static constexpr int CTL = (DLT + NX + 1) & ~1;                       // mailbox: 16 ints | 32 doubles
+    static constexpr int POOL = CTL + 40;                              // (mailbox: 16 ints | 32 doubles)
     static constexpr int SLICE = 160 * 1024 / 8 / 4;
     static constexpr int BUF = (SLICE - POOL) / 2;
     static constexpr int ROWS = BUF / BSTRIDE < 64 ? BUF / BSTRIDE : 64;
@@ -127,13 +127,16 @@ __host__ __device__ constexpr bool ms2_ok() {
 enum { MS2_SEQ = 0, MS2_TYPE = 1, MS2_PROD = 2, MS2_CONS = 3, MS2_DONE = 4, MS2_ABORT = 5, MS2_DEAD = 6, MS2_CUR = 7, MS2_DST = 8, MS2_TDONE = 9,
        MS2_PDONE = 10,         // PDONE: the runner's (primal) half of a line-search trial is in memory
        MS2_CSRC = 11,          // SWEEP: 1 = the defect column of the LQ problem comes from the c_soc array (second-order correction) instead of the residual set
-       MS2_SOCM = 12, MS2_SOCN = 13 };      // the runner's own: a correction is under way / corrected points tried in this iteration (see the line search)
+       MS2_SOCM = 12, MS2_SOCN = 13,        // the runner's own: a correction is under way / corrected points tried in this iteration (see the line search)
+       MS2_GDONE = 14,         // the evaluator's pass over the previous solution (prediction guard), done while the runner forms the prediction, is in the mailbox
+       MS2_PARS = 15 };        // theta and its precomputed values are in LDS (the evaluator's guard pass starts before the first command)
 // SWEEP: chunks of the iterate in set CUR.  TRIAL: residuals of CUR + alpha step -> set DST.  TRIAL_SWEEP: the same trial, then - speculating that the
 // runner accepts the point - straight on with the sweep of set DST (the runner aborts it otherwise)
 // RESTORE: the states of set CUR replaced by the rollout of its controls, its multipliers by zero, then the residuals of that point (as TRIAL with alpha = 0)
 enum { MS2_CMD_EXIT = 0, MS2_CMD_SWEEP = 1, MS2_CMD_TRIAL = 2, MS2_CMD_TRIAL_SWEEP = 3, MS2_CMD_RESTORE = 4 };
 enum { MS2_ALPHA = 0, MS2_F = 1, MS2_TH = 2, MS2_PR = 3, MS2_DU = 4, MS2_Z = 5, MS2_L = 6, MS2_LC = 7, MS2_FIN = 8,
-       MS2_S_GD = 9, MS2_S_AMIN = 10, MS2_S_THOLD = 11 };      // the line search's state while the sweep of a correction runs (slots 12 .. 19: timing builds)
+       MS2_S_GD = 9, MS2_S_AMIN = 10, MS2_S_THOLD = 11,        // the line search's state while the sweep of a correction runs (slots 12 .. 19: timing builds)
+       MS2_G0 = 24 };          // slots 24 .. 31: the guard pass's copy of MS2_F .. MS2_FIN
 
 // Mailbox values come out of LDS in vector registers although every lane reads the same word: said explicitly (v_readfirstlane), or every pointer and
 // branch derived from them would be treated as divergent - 64-bit per-lane addresses for each of the trial pass's ~100 loads, masked branches in the
@@ -248,10 +251,11 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     if (b >= B) return;
     const d4 z = zero4();
     const int tlane = small_transpose_lane(lane);
+    // theta and the theta-only precomputed values are read from LDS where the generated code uses them (broadcast reads): copied into registers in front of every pass they
+    // were 2 (NP + NPC) vector registers holding uniform values across the whole pass - 64 for the quadrotor, 52 for the rocket, in passes that sit on the register limit
 #define PDP_MS2_PAR()                                                     \
-    double th[NP > 0 ? NP : 1], pc[Mdl::NPC];                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) th[i_] = par[i_];  \
-    _Pragma("unroll") for (int i_ = 0; i_ < Mdl::NPC; ++i_) pc[i_] = par[NP + i_]
+    const double* th = par;                                               \
+    const double* pc = par + NP
     double* xb = x + (int64_t)b * (T + 1) * NX;            // API arrays (stage-major): read at the start (warm), written at the end
     double* ub = u + (int64_t)b * T * NU;
     double* lb = lam + (int64_t)b * T * NX;
@@ -490,6 +494,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #pragma unroll
                 for (int i = 0; i < Mdl::NPC; ++i) par[NP + i] = pc0[i];
             }
+            f3_signal(ctl + MS2_PARS, 1);
         }
         // ---- starting point: the caller's (x, u, lambda) [PDP_MS_WARM], or IPOPT's: w0 = 0 (PDP.py:155,166), x_0 = ini_state
         const bool warm = (op.flags & PDP_MS_WARM) != 0;
@@ -519,7 +524,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 // lanes busy: twice as slow.)  Same sums in the same order as before (and as oc_predict_kernel).
                 using R = PredRec<Mdl>;
                 constexpr int RD = NX, RDU = NU;                    // rounds of 64 items a batch of 64 stages needs
-                const int RS = recp ? R::P : R::SIZE;               // floats per stage in LDS (PDP_MS_PREDICT_PRIMAL: the X | U part of every record only)
+                constexpr int QP = (R::P + 3) / 4;                  // 16-byte words that cover the X | U part of a record
+                const int RS = recp ? 4 * QP : R::SIZE;             // floats per stage in LDS (PDP_MS_PREDICT_PRIMAL: the X | U part of every record only, rounded up to whole 16-byte words)
                 const int chcap_ = (4 * L::BUF - 320) / (RS + (recp ? 0 : 2 * NX));      // (256 floats of slack behind the records: the last load instruction of a batch writes a whole kilobyte)
                 const int chcap = chcap_ < 64 ? chcap_ : 64;
                 const int nbat = (T + chcap - 1) / chcap, CH = (T + nbat - 1) / nbat;
@@ -538,13 +544,13 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
 #endif
                     const int nst = min(CH, T - t0), nd = nst * RS;
                     const float* s_ = rec + ((int64_t)b * T + t0) * R::SIZE;
-                    if (recp) {
-                        for (int k0 = 0; k0 < nd; k0 += 64) {
-                            int idx = k0 + lane;
-                            idx = idx < nd ? idx : 0;
-                            const int si = idx / R::P;
-                            idx = si * R::SIZE + (idx - si * R::P);
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + idx), (__attribute__((address_space(3))) void*)(stage + k0), 4, 0, 0);
+                    if (recp) {                                     // 16 bytes per lane here too: lane -> (stage, word) - a wave has 63 loads in flight at most, and as 120
+                        for (int k0 = 0; k0 < nst * QP; k0 += 64) {  // dword loads per batch the X | U parts came in at 3 TB/s, chip-wide
+                            int iq = k0 + lane;
+                            iq = iq < nst * QP ? iq : 0;
+                            const int si = iq / QP;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_ + si * R::SIZE + 4 * (iq - si * QP)),
+                                                             (__attribute__((address_space(3))) void*)(stage + 4 * k0), 16, 0, 0);      // (the last word of a stage may reach into its P part: inside the record)
                         }
                     } else {                                        // whole records: 16 bytes per lane and instruction (global_load_lds_dwordx4, gfx950)
                         for (int k0 = 0; k0 < nd; k0 += 256) {
@@ -1087,17 +1093,15 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         else if constexpr (SPLIT0) issue(MS2_CMD_TRIAL, 0.0, cur, cur);      // (small systems: a TRIAL_SWEEP's pass is shared between the two waves - the line search only)
         else issue(MS2_CMD_TRIAL_SWEEP, 0.0, cur, cur);
         if (guard) {
-            // ... and while the evaluator is on the predicted point, THIS wave evaluates the previous solution (round 6; until then both passes ran on the evaluator,
-            // one behind the other, with the runner asleep: +13 us per solve at C3, now +10).  Two VALU-bound waves on one SIMD take ~1.4 x the time of one, not 2 x
-            // (profiles/r02_probe_two_waves_per_simd.txt).  The sums stay in registers (PART 3); the residual arrays of set 1 are written as by any other pass.
-            double* s1 = Pt(1);
-            for (int i = lane; i < NX; i += 64) s1[i * TS] = x0[(int64_t)b * NX + i];
-            rows_in(xb, T + 1, TagNX{}, s1, 1, scratch);
-            rows_in(ub, T, TagNU{}, s1 + OU, 0, scratch);
-            rows_in(lb, T, TagNX{}, s1 + OL, 0, scratch);
-            __threadfence_block();
-            trial_pass(PartKeep{}, 0.0, 1, 1);
-            g_f = a_f; g_th = a_th; g_pr = a_pr; g_du = a_du; g_z = a_z; g_l = a_l; g_lc = a_lc; g_fin = fin_all;
+            // The previous solution has been evaluated by the EVALUATOR while this wave was forming the prediction (see its prologue: the pass starts at kernel entry, on
+            // the strength of the flags alone - whether the correction is small enough to be trusted unseen is not known before the prediction exists; a pass nobody asks
+            // for costs an idle wave nothing).  Rounds 5 / 6 ran it behind, then beside the pass over the predicted point: +13 / +10 us per solve at C3.
+            __builtin_amdgcn_s_setprio(0);
+            if (!ms2_wait_ge(ctl + MS2_GDONE, 1, ctl)) dead = true;
+            __builtin_amdgcn_s_setprio(3);
+            wave_lds_sync();
+            g_f = uni(res[MS2_G0 + 0]); g_th = uni(res[MS2_G0 + 1]); g_pr = uni(res[MS2_G0 + 2]); g_du = uni(res[MS2_G0 + 3]); g_z = uni(res[MS2_G0 + 4]); g_l = uni(res[MS2_G0 + 5]);
+            g_lc = uni(res[MS2_G0 + 6]); g_fin = uni(res[MS2_G0 + 7]) != 0.0;
             g_err = g_primal ? g_pr / (1.0 + g_z) : fmax(g_pr / (1.0 + g_z), g_du / (1.0 + g_l));
         }
         if (from_u || SPLIT0) wait_done();
@@ -1345,8 +1349,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             __threadfence_block();
             const double* sc = Pt(cur);
             rows_out(sc, T + 1, TagNX{}, xb, scratch);
-            rows_out(sc + OU, T, TagNU{}, ub, scratch);
-            rows_out(sc + OL, T, TagNX{}, lb, scratch);
+            if (dead) {                                 // (the evaluator writes the controls and the multipliers on its way out - unless it is not there any more)
+                rows_out(sc + OU, T, TagNU{}, ub, scratch);
+                rows_out(sc + OL, T, TagNX{}, lb, scratch);
+            }
         }
         if (lane == 0) {
             if (cost) cost[b] = f_cur;
@@ -1383,6 +1389,23 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // (this wave's own copies of the launch constants its row offsets derive from: see sopaque)
         const int TSe = sopaque(TS), OUe = NX * TSe, OLe = (NX + NU) * TSe;
         double* const stpe = sopaque(stp);
+        // PDP_MS_PREDICT_GUARD, this wave's part: the previous solution - the caller's arrays as they are - into point set 1 and through the residual pass, while the
+        // runner forms the prediction in set 0 (same conditions as the runner's `guard`, short of the size of the correction, which does not exist yet)
+        if ((op.flags & PDP_MS_WARM) != 0 && (op.flags & PDP_MS_FROM_CONTROLS) == 0 && (op.flags & PDP_MS_PREDICT) != 0 && (op.flags & PDP_MS_PREDICT_GUARD) != 0 && op.dtheta &&
+            (op.predict_record || (op.dxdp && op.dudp))) {
+            double* s1 = Pt(1);
+            for (int i = lane; i < NX; i += 64) s1[i * TSe] = x0[(int64_t)b * NX + i];
+            rows_in(xb, T + 1, TagNX{}, s1, 1, scratch);        // (the LDS scratch is the runner's, who has no use for it before its first sweep)
+            rows_in(ub, T, TagNU{}, s1 + OUe, 0, scratch);
+            rows_in(lb, T, TagNX{}, s1 + OLe, 0, scratch);
+            __threadfence_block();
+            if (!ms2_wait_ge(ctl + MS2_PARS, 1, ctl)) dead = true;
+            trial_pass(PartAll{}, 0.0, 1, 1);
+            wave_lds_sync();
+            if (lane == 0) { for (int k_ = 0; k_ < 8; ++k_) res[MS2_G0 + k_] = res[MS2_F + k_]; }
+            __threadfence_block();
+            f3_signal(ctl + MS2_GDONE, 1);
+        }
 #ifdef PDP_MS_TIMING      // cumulative cycles of the evaluator: trial passes | updates | backward chunk evaluations | forward chunk evaluations | dlam | terminal | waits inside a sweep | number of trial passes
         long long et[8] = {0, 0, 0, 0, 0, 0, 0, 0}, et0 = 0;
 #define MS2_E0() et0 = __builtin_readcyclecounter()
@@ -1515,7 +1538,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             wave_lds_sync();
             const int type = uni(ctl[MS2_TYPE]), cur = uni(ctl[MS2_CUR]), dst = uni(ctl[MS2_DST]), csrc = uni(ctl[MS2_CSRC]);
             const double alpha = uni(res[MS2_ALPHA]);
-            if (type == MS2_CMD_EXIT) break;
+            if (type == MS2_CMD_EXIT) {                 // its share of the result: u and lambda of the final iterate into the API arrays (the runner writes x)
+                const double* sc = Pt(cur);
+                rows_out(sc + OUe, T, TagNU{}, ub, pool);
+                rows_out(sc + OLe, T, TagNX{}, lb, pool);
+                break;
+            }
             MS2_E0();
             if (type == MS2_CMD_RESTORE) restore(cur);
             if (type == MS2_CMD_TRIAL || type == MS2_CMD_TRIAL_SWEEP || type == MS2_CMD_RESTORE) {
