@@ -22,6 +22,10 @@ def setup(golden_dir, name):
     return d, oc, zoo.get(name, "irl")
 
 
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
 def solve_at(mdl, x0, th, T):
     sol = mdl.oc_solve_ms(x0, th, T, tol=1e-11)
     assert bool(sol["converged"].all())
@@ -392,3 +396,46 @@ def test_prediction_guard_changes_nothing_where_the_prediction_is_good(golden_di
         assert bool(on["converged"].all()) and int((on["status"] & 512).sum()) == 0 and bool((on["status"] == off["status"]).all())
         for k in ("state", "control", "costate", "cost", "iterations", "log"):
             assert bool((on[k] == off[k]).all()), (sorted(pred), k)
+
+
+@pytest.mark.parametrize("primal", [False, True])
+def test_record_prediction_at_a_long_horizon(primal):
+    """Rocket, T = 100 (C4's horizon): more than 64 nodes - the solver's residual pass runs in two lane groups that overlap by a node, the record prediction in several
+    pool-sized batches, the prediction guard's pass over the previous solution on the evaluator while the runner forms the prediction (round 6).  The solve that applies the
+    packed fp32 record inside the launch must start from the very point pdp_oc_predict_record_batched writes and therefore take the same iterations to the same
+    optimum, with the guard (default) and without it; and it must agree with the solve from the plain warm start."""
+    from pdp_amd import zoo, runtime as rt
+    mdl = zoo.get("rocket", "irl")
+    rng = np.random.default_rng(11)
+    B, T = 6, 100
+    th = np.array([0.5, 1, 1, 1, 1, 1, 1, 50, 1, 1.0])
+    x0 = np.zeros((B, 13))
+    x0[:, 0:3] = np.array([10, -8, 5.0]) + 0.5 * rng.standard_normal((B, 3))
+    x0[:, 3] = -0.5
+    ang = 0.5 + 0.1 * rng.standard_normal(B)
+    x0[:, 6], x0[:, 8], x0[:, 9] = np.cos(ang / 2), np.sin(ang / 2) / np.sqrt(2), -np.sin(ang / 2) / np.sqrt(2)
+    sol = mdl.oc_solve_ms(x0, th, T)
+    assert bool(sol["converged"].all())
+    warm = (sol["state"], sol["control"], sol["costate"])
+    want = "primal" if primal else True
+    rec = mdl.oc_pdp_grad(sol["control"], th, sol["state"], sol["control"], x=sol["state"], lam=sol["costate"], want_predict_record=want)["predict_record"]
+    th1 = th[None] * (1 + 0.01 * rng.uniform(-1, 1, (B, th.size)))
+    dth = th1 - th[None]
+    kw = dict(primal=True) if primal else {}
+    xp, up, lp = mdl.oc_predict_from_record(sol["state"], sol["control"], sol["costate"], dth, rec, **kw)
+    pre = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=(xp, up, lp))
+    plain = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm)
+    assert bool(pre["converged"].all()) and bool(plain["converged"].all())
+    for guard in (True, False):
+        inl = mdl.oc_solve_ms(x0, th1, T, tol=1e-10, warm=warm, predict=dict(dtheta=dth, record=rec, guard=guard, **kw))
+        assert bool(inl["converged"].all())
+        kept = (npy(inl["status"]) & 512) == 0                      # (a prediction the guard dropped starts from the previous solution: compared with the plain warm start)
+        assert guard or bool(kept.all())
+        for i in range(B):
+            ref = pre if kept[i] else plain
+            assert int(inl["iterations"][i]) == int(ref["iterations"][i]), (guard, i)
+            for k in ("state", "control", "costate"):
+                a, b_ = npy(inl[k][i]), npy(ref[k][i])
+                assert np.abs(a - b_).max() <= 1e-12 * max(1.0, np.abs(b_).max()), (guard, i, k)
+        for k in ("state", "control"):
+            assert np.abs(npy(inl[k]) - npy(plain[k])).max() <= 1e-7 * max(1.0, np.abs(npy(plain[k])).max())
