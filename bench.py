@@ -190,8 +190,8 @@ def oc_solve_model(n, m, T, newton_iterations, residual_passes, B, ms):
       backward (homogeneous Riccati step, NA = n + 1 rows): P~F~ and F~'(P~F~) 2 x 2 NA^3, P~G~, G~'(P~F~) and Qux~'K~ 3 x 2 NA^2 m, G'PG and Quu^-1 Qux~ 2 x 2 NA m^2,
                 the m x m inverse 2 m^3, the symmetrisation NA^2;
       forward:  K~x~ 2 m NA, F~x~ and x~'P~ 2 x 2 NA^2, G(K~x~) 2 n m, the directional derivative 2 (n + m).
-    Executed on the matrix pipe (tiles padded to 16): 13 + 5 v_mfma_f64_16x16x4 (2048 flop, 64 cycles of issue) and 9 + 8 v_mfma_f64_4x4x4_4b (512 flop, ~28 cycles) per stage
-    for 4 < n < 16; 10 + 3 of the small form alone for n <= 4.
+    Executed on the matrix pipe (tiles padded to 16): 9 + 5 v_mfma_f64_16x16x4 (2048 flop, 64 cycles of issue) and 10 + 8 v_mfma_f64_4x4x4_4b (512 flop, ~28 cycles) per stage
+    for 4 < n < 16 (round 6: P~G~ and G'(P~G~) on the four-row form - 13 + 9 before); 10 + 3 of the small form alone for n <= 4.
     Bytes (fp64, every array of the solver's workspace read or written once per use, per iteration): the chunk evaluations read the point and its residuals (2 groups of
     (2 n + m)(T + 1)), the forward sweep writes the step (1 group), the residual pass of the line search reads point + step and writes the trial point + its residuals
     (4 groups), the sweeps write and re-read the per-stage records (gains m NA + upper triangle of P~ NA (NA + 1) / 2); each further residual pass (starting point, guard)
@@ -205,7 +205,7 @@ def oc_solve_model(n, m, T, newton_iterations, residual_passes, B, ms):
     if small:
         mfma_flop_it, mfma_cycles_it = T * 13 * 512, T * 13 * 28
     else:
-        mfma_flop_it, mfma_cycles_it = T * ((13 + 5) * 2048 + (9 + 8) * 512), T * ((13 + 5) * 64 + (9 + 8) * 28)
+        mfma_flop_it, mfma_cycles_it = T * ((9 + 5) * 2048 + (10 + 8) * 512), T * ((9 + 5) * 64 + (10 + 8) * 28)
     grp = (2 * n + m) * (T + 1)
     rec = T * (m * NA + NA * (NA + 1) // 2)
     bytes_it = 8 * (7 * grp + 2 * rec)
