@@ -549,7 +549,7 @@ def scaling_configs(torch, dist, world, rank, steps, verify=False):
         b = hi - lo
         rng = np.random.default_rng(1234)                     # every rank draws the full batch and keeps its shard: shards do not depend on N
         unit = make_unit(rng, B_total, lo, hi)
-        og = parallel.OverlappedGather(b, p + 1) if (distributed and B_total % world == 0) else None
+        og = parallel.OverlappedGather(b, p + 1, depth=4) if (distributed and B_total % world == 0) else None      # (four buffer pairs: profiles/r06_exchange_policies.txt)
 
         def step():
             if og is not None:
@@ -758,46 +758,128 @@ def main():
     x0, u, dx, du = (torch.as_tensor(a, device="cuda") for a in synth_inputs(B, 1000 + rank))
     theta = torch.tensor(THETA, dtype=torch.float64, device="cuda")
     bufs = {}
-    og = parallel.OverlappedGather(B, N_PAR + 1) if distributed else None
+    # (four packed / gathered buffer pairs in rotation and two step streams: with a collective kernel that needs a CU for 20 us, one stream x two buffers costs a step
+    # +33 us, two streams x four buffers +1.3 us - probes/exchange_policies.py, profiles/r06_exchange_policies.txt)
+    DEPTH = 4
+    og = parallel.OverlappedGather(B, N_PAR + 1, depth=DEPTH) if distributed else None
     # The step as a PREPARED call (runtime.oc_pdp_grad_prepared): the 19 arguments of pdp_oc_pdp_grad_batched marshalled once, one foreign call per step.  Through the general
     # wrapper (tensor conversions, buffer dictionary, ctypes marshalling: 25 - 60 us of Python per call) the driver's boxes measured 0.104 - 0.109 ms per step around a 0.097 -
     # 0.099 ms kernel: on a busy host the wrapper does not always fit under the kernel it should hide behind.  Same kernel, same arguments, same buffers - checked below.
     # (N > 1: one prepared call per exchange buffer; the kernel writes its [B, p+1] rows straight into the buffer the all-gather of that step sends.)
+    # Two (N > 1: four) prepared calls, each with its own outputs and workspace, and the steps issued on TWO HIP streams in alternation (parallel.StepStreams says why:
+    # whatever a step puts behind its kernel in the kernel's own queue - the event the side stream waits for, the wait for the collective that last read the buffer - is
+    # a barrier packet, and a kernel that holds every CU leaves RCCL room only where a launch ends.  With a stand-in collective that needs a CU for 20 us,
+    # profiles/r06_exchange_policies.txt: one stream x two buffers +33 us per step, two streams x four buffers +1.3 us).  The steps of this benchmark are independent (same
+    # inputs every step); PDP_BENCH_ONE_STREAM=1 keeps them on one stream (the launch scheme of rounds 1 - 5).
+    # WHICH two streams: HIP streams share a few hardware queues (4 by default; more made it worse), handed out in creation order, and two of the three busy streams
+    # (step streams, side stream) - or one of them and RCCL's own stream - in one queue serialise what was meant to overlap: +17 ... +47 us per step in the same
+    # experiment (profiles/r06_exchange_policies_queues.txt).  Nothing in HIP names a queue, so the placement is CALIBRATED: a handful of candidate pairs out of six
+    # streams, and the single stream, each timed over CAL_STEPS real steps (real collectives included, the same number on every rank); the fastest is used.
+    one_stream = os.environ.get("PDP_BENCH_ONE_STREAM", "0") == "1" or args.graph
     if distributed:
-        prepared = [mdl.oc_pdp_grad_prepared(u, theta, dx, du, x0, packed_out=og.buffers[i]) for i in range(2)]
+        prepared = [mdl.oc_pdp_grad_prepared(u, theta, dx, du, x0, packed_out=og.buffers[i]) for i in range(DEPTH)]
     else:
-        prepared = [mdl.oc_pdp_grad_prepared(u, theta, dx, du, x0)]
+        prepared = [mdl.oc_pdp_grad_prepared(u, theta, dx, du, x0) for i in range(1 if one_stream else 2)]
     out = prepared[0][1]
     ref_rows = mdl.oc_pdp_grad(u, theta, dx, du, x0=x0, buffers=bufs, packed=True)["packed"]
-    prepared[0][0]()
-    if not torch.equal(out["packed"], ref_rows):
-        raise SystemExit("the prepared call does not reproduce runtime.oc_pdp_grad bit for bit")
+    for call_, out_ in prepared:
+        call_()
+        if not torch.equal(out_["packed"], ref_rows):
+            raise SystemExit("the prepared call does not reproduce runtime.oc_pdp_grad bit for bit")
+    torch.cuda.synchronize()
+    main_stream = torch.cuda.current_stream()
+    pool = [] if one_stream else [torch.cuda.Stream() for _ in range(6)]
+    for s_ in pool:                     # (first use creates the HIP stream and binds it to a hardware queue: in this order)
+        with torch.cuda.stream(s_):
+            torch.zeros(8, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
+    sel = {"streams": None, "k": 0}     # the step streams in use (None: the caller's stream), and the step counter of the undistributed case
 
-    def step():
+    def check_outputs():
+        for _c, out_ in prepared:
+            if int(out_["status"].sum()) != 0 or not bool(torch.isfinite(out_["grad"]).all()):
+                raise SystemExit("benchmark inputs produced numerical trouble (status flags set)")
+            if not torch.equal(out_["packed"], ref_rows):
+                raise SystemExit("steps issued on alternating streams do not reproduce the single call bit for bit")
+    check_outputs()
+
+    def issue():
         if distributed:
-            i = og.k % 2
+            i = og.k % DEPTH
             og.next_buffer()            # (the collective that last read buffer i has completed before the kernel overwrites it)
             prepared[i][0]()
             og.submit()
             return prepared[i][1]
-        prepared[0][0]()
-        return out
+        i = sel["k"] % len(prepared)
+        sel["k"] += 1
+        prepared[i][0]()
+        return prepared[i][1]
 
-    for _ in range(args.warmup):
-        out = step()
-    if distributed:
-        og.drain()
-    torch.cuda.synchronize()
-    if int(out["status"].sum()) != 0 or not bool(torch.isfinite(out["grad"]).all()):
-        raise SystemExit("benchmark inputs produced numerical trouble (status flags set)")
+    def step():
+        if sel["streams"] is None:
+            return issue()
+        k = og.k if distributed else sel["k"]       # (buffers / prepared calls 0, 2 belong to step stream 0, 1 and 3 to step stream 1)
+        with torch.cuda.stream(sel["streams"][k % 2]):
+            return issue()
 
-    # ---- kernel-only timing with HIP events on the launch stream (roofline.achieved)
-    kern_ms = _event_ms(torch, prepared[0][0], reps=min(max(args.steps, 5), 20), warm=0)
-    headline_window = kern_ms.wins[0]
+    def finish():                       # everything the steps have issued - kernels on both streams, every exchange - is ordered before what follows on the caller's stream
+        if sel["streams"] is not None:
+            for s_ in sel["streams"]:
+                main_stream.wait_stream(s_)
+        if distributed:
+            og.drain()
+
+    def use(streams):                   # switch the placement: what has been issued so far is ordered before the first step on the new streams
+        finish()
+        torch.cuda.synchronize()
+        sel["streams"] = streams
+        if streams is not None:
+            for s_ in streams:
+                s_.wait_stream(main_stream)
+
     exch_us = None
     if distributed:       # the exchange alone, blocking, on the compute stream: what a non-overlapped step would add
         pk = og.buffers[0]
         exch_us = 1e3 * _event_ms(torch, lambda: parallel.gather_packed(pk, out=og.gathered[0]), reps=10, warm=2)
+    # ---- kernel-only timing with HIP events on the launch stream (roofline.achieved): the median over KERNEL_SAMPLES isolated launches.  It comes BEFORE the warm-up
+    # steps and the timed region (rounds 1 - 5: between them, 20 samples): 200 launches are 20 ms of sustained load, and a process whose GPU has been busy for 3 ms
+    # measures its first 20 steps 7 % slower than the same steps 15 ms later (launch_diagnostics.timed_region_repeated_ms_per_step of the round-6 lines: 0.0986, 0.0966,
+    # 0.0940, 0.0922 ms per step for four consecutive regions of 20 steps - the clocks of an idle GPU ramp over tens of milliseconds).  The headline is a sustained rate.
+    KERNEL_SAMPLES = max(200, args.steps)
+    kern_ms = _event_ms(torch, prepared[0][0], reps=KERNEL_SAMPLES, warm=2)
+    headline_window = kern_ms.wins[0]
+
+    placement = None
+    if pool:
+        CAL_STEPS = 32
+        cands = [("one stream", None)] + [("streams %d, %d of six" % (a_, b_), [pool[a_], pool[b_]]) for a_, b_ in ((0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (0, 2), (1, 3))]
+        tried = []
+        for name_, st_ in cands:
+            use(st_)
+            for _ in range(4):
+                step()
+            finish()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(CAL_STEPS):
+                step()
+            finish()
+            torch.cuda.synchronize()
+            tried.append((time.perf_counter() - t_) / CAL_STEPS * 1e3)
+        best_ = int(np.argmin(tried))
+        use(cands[best_][1])
+        placement = {"candidates": [c_[0] for c_ in cands], "ms_per_step": tried, "chosen": cands[best_][0], "steps_per_candidate": CAL_STEPS,
+                     "what": "HIP streams share a few hardware queues in creation order; which pair of step streams keeps the kernels, the side stream and RCCL's stream "
+                             "in different queues is found by timing the real step on each candidate before the warm-up steps (per rank; every rank issues the same "
+                             "number of collectives)"}
+
+    for _ in range(args.warmup):
+        out = step()
+    finish()
+    torch.cuda.synchronize()
+    # (nothing between the warm-up steps and the timed region but this synchronize: 5 ms with the GPU idle cost the next 20 steps 5 %, 20 ms cost them 9 %
+    # - profiles/r06_cold_region.txt.  The outputs are checked BEHIND the timed region, on what the timed steps wrote; check_outputs() has run once above, so that
+    # its torch kernels are loaded.)
 
     # ---- --graph (single GPU): the step recorded once as a hipGraph (one kernel node, same arguments, same buffers) and replayed K times, as pdp_amd.irl.IRLLoop /
     # GDLoop do for the loops of the reference's drivers.  Round-5 verdict, item 4, asked whether that recovers the gap between the driver's ms_per_step and the kernel
@@ -839,14 +921,36 @@ def main():
     else:
         for _ in range(args.steps):
             step()
-    if distributed:
-        og.drain()                      # every exchange of the K steps has completed inside the timed region
+    finish()                            # every kernel and every exchange of the K steps has completed inside the timed region
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
     WINDOWS.append({"window": len(WINDOWS), "reps": args.steps, "event_ms_median": dt / args.steps * 1e3, "t0": c0, "t1": _clocks(), "what": "the timed region (K steps)"})
+    check_outputs()                     # what the timed steps wrote: status flags clear, finite, the single call's rows bit for bit
     timed_window = len(WINDOWS) - 1
+    # (after the fact, not part of `value`: the same K steps again - is the first timed region of a process slower than the ones behind it? - and, for the record, the K
+    # steps on ONE stream, the launch scheme of rounds 1 - 5)
+    launch_diag = None
+    if graph is None:
+        def region(fn, fin):
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            fin()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / args.steps * 1e3
+        reps = [region(step, finish) for _ in range(3)]
+        ones = None
+        if sel["streams"] is not None:
+            chosen_ = sel["streams"]
+            use(None)
+            ones = [region(step, finish) for _ in range(3)]
+            use(chosen_)
+        launch_diag = {"timed_region_repeated_ms_per_step": reps, "one_stream_ms_per_step": ones, "stream_placement": placement}
     per_rank = None
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -858,14 +962,14 @@ def main():
         dt = float(tmax.item())
         if args.verify_exchange:
             # the headline exchange: block r of the gathered rows == the kernel run here on rank r's inputs (weak scaling: rank r owns synth_inputs(B, 1000 + r))
-            rows = og.result((og.k - 1) % 2).clone()
+            rows = og.result((og.k - 1) % DEPTH).clone()
             ok, worst = True, 0.0
             for r in range(world):
                 xr, ur, dxr, dur = (torch.as_tensor(a, device="cuda") for a in synth_inputs(B, 1000 + r))
                 ref = mdl.oc_pdp_grad(ur, theta, dxr, dur, x0=xr, packed=True)["packed"]
                 ok = ok and bool(torch.equal(rows[r * B:(r + 1) * B], ref))
                 worst = max(worst, float((rows[r * B:(r + 1) * B] - ref).abs().amax() / ref.abs().amax()))
-            mean_ar = parallel.allreduce_mean_packed(og.buffers[(og.k - 1) % 2], world * B)
+            mean_ar = parallel.allreduce_mean_packed(og.buffers[(og.k - 1) % DEPTH], world * B)
             mref = rows.mean(dim=0)
             chk = torch.tensor([1.0 if ok else 0.0, worst, float(((mean_ar - mref).abs() / mref.abs().clamp_min(1e-300)).amax())], dtype=torch.float64, device="cuda")
             allc = torch.empty((world, 3), dtype=torch.float64, device="cuda")
@@ -918,9 +1022,15 @@ def main():
             "dtype": "f64", "data": "synthetic (seeded random initial poses and near-hover thrust sequences; no dataset exists for this path)",
             "config": {"workload": "C3: quadrotor OC/IRL unit n=13 m=4 p=9 T=50, batch=%d trajectories per GPU, shared theta" % B,
                        "batch_per_gpu": B, "horizon": T,
-                       "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the next step's kernel" %
+                       "exchange": ("all_gather([B,10] gradient|loss rows) over %s on a side stream, overlapped with the following steps' kernels (four buffer pairs in rotation)" %
                                     ("RCCL" if backend == "nccl" else backend + " (staged through host memory: test mode)")) if distributed else "none (1 GPU)",
-                       "launch": "hipGraph replay (one kernel node per step)" if graph is not None else "one C-ABI call per step from Python (prepared call: arguments marshalled once)",
+                       "launch": "hipGraph replay (one kernel node per step)" if graph is not None else
+                                 ("one C-ABI call per step from Python (prepared call: arguments marshalled once)" +
+                                  ("" if sel["streams"] is None else "; the steps are independent and alternate between TWO HIP streams (two prepared calls, each with its own outputs and "
+                                   "workspace): a CU takes a workgroup of step k + 1 the moment its workgroup of step k retires, and the events / waits of the exchange are "
+                                   "barrier packets in a queue that is idle until step k + 2 - so ms_per_step may undercut roofline.kernel_ms, the event-bracketed duration "
+                                   "of ONE isolated launch (first workgroup in to last workgroup out); profiles/r06_exchange_overlap.txt")),
+                       "launch_diagnostics": launch_diag,
                        "launch_modes": ({"eager_ms_per_step": eager_ms_per_step, "graph_replay_ms_per_step": dt / args.steps * 1e3} if graph is not None else None),
                        "dist_backend": backend if distributed else None, "ranks_share_one_device": bool(same_device and world > 1),
                        "collectives_forced_at_world_size_1": bool(distributed and world == 1)},
@@ -929,7 +1039,7 @@ def main():
                          "traffic_collected_at": traffic_at, "traffic_collected_on_these_kernel_sources": traffic_current,
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
                                            "(probes/profile_r06.sh; counter values scaled by the factors measured on known byte counts in this repository's access "
-                                           "shapes, probes/pmc_calibrate.hip: `traffic_calibration`), not collected in this run", "kernel_ms": float(kern_ms),
+                                           "shapes, probes/pmc_calibrate.hip: `traffic_calibration`), not collected in this run", "kernel_ms": float(kern_ms), "kernel_ms_samples": KERNEL_SAMPLES,
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B, "timing_windows": [headline_window], "timed_region_window": timed_window,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,
                                                                "frac": FLOP_PER_TRAJ_SCHUR * B / (kern_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

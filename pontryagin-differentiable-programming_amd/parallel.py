@@ -153,6 +153,48 @@ def gather_packed(packed, n_total=None, out=None):
     return all_gather_into(out, packed.contiguous())
 
 
+class StepStreams:
+    """INDEPENDENT steps of a loop issued on n HIP streams in rotation (n = 2: even steps on one queue, odd steps on the other).
+
+    Why (probes/exchange_overlap.py, profiles/r06_exchange_overlap.txt): the fused OC unit at 1024 trajectories holds every CU for the whole launch (one workgroup per
+    CU, all of its LDS), so RCCL's kernel finds room only where a launch ends - and everything a step puts behind its kernel in the SAME queue (the event the side
+    stream waits for, the wait for the collective that last read the buffer) is a barrier packet: the next kernel is not dispatched before the previous one has
+    drained completely, and the collective then runs in the gap.  Measured through a one-rank RCCL group: 0.0898 ms per step for the kernel alone, 0.1008 ms with the
+    all-gather "overlapped" on a side stream (+11 us; 2, 3 or 4 buffers alike), 0.0993 ms with the all-gather simply on the same stream.  With the steps alternating
+    between two queues the barrier packets of step k sit in a queue that has nothing else to do until step k + 2: the kernel of step k + 1 moves into each CU the moment
+    a workgroup of step k leaves it, the collective takes the first CU that frees (its cost is spread over 256 CUs instead of stalling all of them): 0.0891 ms with
+    the all-gather, 0.0882 ms without.  The steps must not share anything they write (outputs, workspace): one prepared call per stream.
+    Not for dependent steps (a gradient-descent loop): there the exchange sits on the critical path whatever the stream."""
+
+    def __init__(self, n=2):
+        self.main = torch.cuda.current_stream()
+        self.streams = [torch.cuda.Stream() for _ in range(int(n))]
+        self.k = 0
+        self.fork()
+
+    def fork(self):
+        """the step streams wait for what the caller's stream has issued so far (inputs, warm-up)"""
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def index(self):
+        """index of the stream the next step will use"""
+        return self.k % len(self.streams)
+
+    def next(self):
+        """context manager: the next step's stream as the current stream"""
+        s = self.streams[self.k % len(self.streams)]
+        self.k += 1
+        return torch.cuda.stream(s)
+
+    def join(self):
+        """the caller's stream waits for every step issued so far"""
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
 class OverlappedGather:
     """The exchange step of the data-parallel iteration, off the critical path: the all-gather of step k runs on a side stream
     while the kernels of step k+1 run on the compute stream (the per-sample rows of step k are consumed one step later - a
@@ -161,26 +203,29 @@ class OverlappedGather:
     an event on the compute stream, and enqueues the collective on the side stream behind it; `wait(k)` makes the compute stream
     wait for the collective of step k.  On CPU tensors (gloo tests) it degenerates to the blocking collective."""
 
-    def __init__(self, rows, cols, dtype=torch.float64, device="cuda"):
+    def __init__(self, rows, cols, dtype=torch.float64, device="cuda", depth=2, priority=0):
+        """depth: number of packed / gathered buffer pairs in rotation (2 = the rows of step k are complete before the kernel of step k + 2 starts);
+        priority: stream priority of the side stream (negative = higher; probes/exchange_overlap.py measures what either buys)"""
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.active = exchange_active()
         self.cuda = torch.device(device).type == "cuda"
-        self.buffers = [torch.zeros((rows, cols), dtype=dtype, device=device) for _ in range(2)]
-        self.gathered = [torch.zeros((self.world * rows, cols), dtype=dtype, device=device) for _ in range(2)]
-        self.side = torch.cuda.Stream() if self.cuda else None
-        self.done = [None, None]
+        self.depth = int(depth)
+        self.buffers = [torch.zeros((rows, cols), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.gathered = [torch.zeros((self.world * rows, cols), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.side = torch.cuda.Stream(priority=priority) if self.cuda else None
+        self.done = [None] * self.depth
         self.k = 0
 
     def next_buffer(self):
         """the packed buffer the next step's kernel should write (its previous collective has been waited for)"""
-        i = self.k % 2
+        i = self.k % self.depth
         if self.cuda and self.done[i] is not None:
             torch.cuda.current_stream().wait_event(self.done[i])
         return self.buffers[i]
 
     def submit(self):
         """enqueue the all-gather of the buffer handed out by the last next_buffer(); returns the index of the gathered tensor"""
-        i = self.k % 2
+        i = self.k % self.depth
         self.k += 1
         if not self.active:
             self.gathered[i] = self.buffers[i]

@@ -5,7 +5,15 @@ C5's 8192 cut into N contiguous shards, BASELINE.json configs[3], configs[4]) an
 ONE-rank process group, PDP_DIST_FORCE_COLLECTIVE=1: launch + enqueue + the copy kernel, no wire).  What it cannot measure is the wire: the prediction carries it as
 an explicit assumption (`assumed`), so that the first measured curve can be judged against the parts separately.
 
-    step time(N)  =  max(kernel(shard(N)), exchange(N))     the exchange of step k runs on a side stream under the kernel of step k + 1 (parallel.OverlappedGather)
+    step time(N)  =  kernel(shard(N)), back to back  +  exposed(exchange(N))
+                     Rounds 2 - 5 wrote max(kernel, exchange) here - "the exchange hides under the next kernel".  It does not where the kernel holds every CU (the fused OC
+                     unit from 1024 trajectories per GPU on: one workgroup per CU with all of its LDS): RCCL's kernel needs a CU, finds one only where a launch ends, and
+                     every event / wait of the exchange is a barrier packet in the kernel's queue.  Measured with a stand-in collective of RCCL's footprint
+                     (probes/exchange_policies.py, profiles/r06_exchange_policies.txt), excess per step over the kernel alone for a collective busy 20 / 40 us:
+                         one step stream x two buffers (rounds 2 - 5)   +33 / +62 us        one x four   +14 / +24 us        TWO x four (bench.py now)   +1.3 / +4.8 us
+                     `exposed` below is the linear fit through those pairs, on the collective's assumed time on the GPU (10 us + wire); shards that leave CUs free
+                     (everything but the fused OC unit at >= 1024 per GPU) are taken as hidden.  bench.py's headline uses two step streams x four buffers with a
+                     calibrated stream placement, its scaling_configs one stream x four buffers.
     step time, not overlapped  =  kernel + exchange         (what a driver that consumes the rows at once would see)
     exchange(N)   =  software floor + (N - 1) x assumed per-peer latency + block bytes / assumed per-link bandwidth
                      (an MI355X node is FULLY CONNECTED - 7 xGMI links per GPU, one to each peer: a rank's block travels to its N - 1 peers over N - 1 links at once, so
@@ -110,6 +118,15 @@ def main():
             total = batch * N if scaling == "weak" else batch
             unit = make(b)
             k_ms = event_ms(unit, reps=10 if b <= 2048 else 5)
+            # back to back (what a loop sees: 0.090 ms per step where the event-bracketed isolated launch takes 0.098)
+            for _ in range(20):
+                unit()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(50):
+                unit()
+            torch.cuda.synchronize()
+            kb_ms = (time.perf_counter() - t0_) / 50 * 1e3
             # software floor of the exchange: the collective itself in a one-rank group, on this rank's [b, p + 1] rows
             rows = torch.zeros((b, p + 1), dtype=torch.float64, device="cuda")
             out = torch.empty_like(rows)
@@ -119,9 +136,18 @@ def main():
             wire_us = ((N - 1) * ASSUMED["xgmi_per_peer_latency_us"] + blk / (ASSUMED["xgmi_per_link_GBps_effective"] * 1e3)) if N > 1 else 0.0
             ex_us = ag_us + wire_us
             ar_wire_us = 2 * (N - 1) * ASSUMED["xgmi_per_peer_latency_us"] if N > 1 else 0.0
-            step_ov, step_no = max(k_ms, ex_us * 1e-3), k_ms + ex_us * 1e-3
-            step_ar = k_ms + (ar_us + ar_wire_us) * 1e-3
-            row = {"shard_per_gpu": b, "total_batch": total, "kernel_ms_measured": k_ms, "exchange_bytes_per_rank": blk, "allgather_software_floor_us_measured": ag_us,
+            on_gpu_us = (10.0 + wire_us) if N > 1 else 0.0          # assumed time RCCL's kernel holds its CUs
+            fills = name.startswith(("C3_quadrotor_oc_unit", "C4_rocket_oc_unit")) and b >= 1024
+            if N == 1 or not fills:
+                exposed_us = 0.0
+            elif "headline" in name:
+                exposed_us = max(0.0, 0.175 * on_gpu_us - 2.2)         # two step streams x four buffers
+            else:
+                exposed_us = 0.525 * on_gpu_us + 3.2                    # one step stream x four buffers
+            step_ov, step_no = max(kb_ms, ex_us * 1e-3 if not fills else 0.0) + exposed_us * 1e-3, kb_ms + ex_us * 1e-3
+            step_ar = kb_ms + (ar_us + ar_wire_us) * 1e-3
+            row = {"shard_per_gpu": b, "total_batch": total, "kernel_ms_measured": k_ms, "kernel_ms_back_to_back_measured": kb_ms, "exchange_exposed_us_predicted": exposed_us,
+                   "shard_fills_every_cu": bool(fills), "exchange_bytes_per_rank": blk, "allgather_software_floor_us_measured": ag_us,
                    "allreduce_software_floor_us_measured": ar_us, "allgather_wire_us_assumed": wire_us, "predicted_ms_per_step_overlapped": step_ov,
                    "predicted_ms_per_step_not_overlapped": step_no, "predicted_ms_per_step_allreduce_form_blocking": step_ar,
                    "predicted_traj_per_s_overlapped": total / (step_ov * 1e-3), "predicted_traj_per_s_not_overlapped": total / (step_no * 1e-3)}
@@ -139,8 +165,9 @@ def main():
         print(name, scaling)
         for N in (1, 2, 4, 8):
             r = e["rows"][str(N)]
-            print("   N=%d shard %5d kernel %.4f ms  all-gather %6.1f us floor + %6.1f us wire (assumed)  -> %.4f ms/step overlapped, %8.2f M traj/s, x%.2f (%.0f %%)%s" %
-                  (N, r["shard_per_gpu"], r["kernel_ms_measured"], r["allgather_software_floor_us_measured"], r["allgather_wire_us_assumed"], r["predicted_ms_per_step_overlapped"],
+            print("   N=%d shard %5d kernel %.4f ms (%.4f back to back)  all-gather %6.1f us floor + %6.1f us wire (assumed), %4.1f us exposed  -> %.4f ms/step overlapped, %8.2f M traj/s, x%.2f (%.0f %%)%s" %
+                  (N, r["shard_per_gpu"], r["kernel_ms_measured"], r["kernel_ms_back_to_back_measured"], r["allgather_software_floor_us_measured"], r["allgather_wire_us_assumed"],
+                   r["exchange_exposed_us_predicted"], r["predicted_ms_per_step_overlapped"],
                    r["predicted_traj_per_s_overlapped"] / 1e6, r["predicted_speedup_vs_1_gpu"], 100 * r["predicted_scaling_efficiency"],
                    "  frac %.3f" % r["predicted_frac_of_fp64_mfma_peak_per_gpu"] if "predicted_frac_of_fp64_mfma_peak_per_gpu" in r else ""))
     res["collected"] = {"device": torch.cuda.get_device_name(0), "rccl": list(torch.cuda.nccl.version()), "time": time.strftime("%Y-%m-%d %H:%M:%S")}
