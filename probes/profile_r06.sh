@@ -27,8 +27,9 @@ hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate probes/pmc_calibrate.hip >
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o p -- /tmp/pmc_calibrate 1024 4 > $O/calib_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o p -- /tmp/pmc_calibrate 1024 4 > $O/calib_write.log 2>&1
 BENCH2="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scaling-configs"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $BENCH2 > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $BENCH2 > $O/write.log 2>&1
+# (counter passes: bytes per launch do not depend on the clocks - without the 200 launches of load bench.py puts in front of every event-timed entry)
+PDP_BENCH_NO_PREHEAT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $BENCH2 > $O/fetch.log 2>&1
+PDP_BENCH_NO_PREHEAT=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $BENCH2 > $O/write.log 2>&1
 python probes/pmc_traffic.py $O > $O/traffic_summary.txt 2>&1
 tail -40 $O/rocprof_match.txt
 tail -30 $O/traffic_summary.txt
