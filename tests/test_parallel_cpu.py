@@ -59,6 +59,15 @@ def _worker(rank, world, port, n_total, q):
             i = og.submit()
             assert torch.equal(og.result(i), rows * (k + 1))
         og.drain()
+        og4 = parallel.OverlappedGather(pk.shape[0], pk.shape[1], device="cpu", depth=4)       # four buffer pairs in rotation (bench.py's headline): a result stays valid
+        idx = []                                                                                # until the buffer comes round again
+        for k in range(6):
+            og4.next_buffer().copy_(pk * (k + 1))
+            idx.append(og4.submit())
+            if k >= 2:
+                assert torch.equal(og4.result(idx[k - 2]), rows * (k - 1))
+        assert idx == [0, 1, 2, 3, 0, 1] and len(og4.buffers) == 4 and len(og4.gathered) == 4
+        og4.drain()
     q.put((rank, L.numpy(), G.numpy(), float(Lm), Gm.numpy(), L2.numpy(), tuple(xs.shape)))
     dist.destroy_process_group()
 
