@@ -46,13 +46,13 @@ def test_two_step_streams_four_buffers_reproduce_the_single_call():
         if done[i] is not None and k >= 2 * DEPTH:          # the rows of step k - DEPTH, checked on the host before their buffer is written again
             done[i].synchronize()
             seen.append(bool(torch.equal(gath[i], ref[i])))
-            gath[i].zero_()
         assert ss.index() == k % 2
         with ss.next():
             s = torch.cuda.current_stream()
             if done[i] is not None:
                 s.wait_event(done[i])
-            bufs[i].zero_()                                  # (a collective that ran before its kernel would copy zeros)
+            bufs[i].zero_()                                  # (a collective that ran before its kernel would copy zeros; one that did not run leaves zeros)
+            gath[i].zero_()
             calls[i]()
             ready = torch.cuda.Event()
             ready.record(s)
