@@ -20,8 +20,13 @@ python probes/rocprof_match.py $O/stats $O/windows.json $O/bench_line_unprofiled
 echo "rocprof_match exit $?" >> $O/rocprof_match.txt
 for f in $(find $O/stats -name 'p_kernel_stats.csv'); do cp $f $O/bench_full_kernel_stats.csv; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-scaling-configs > $O/stats_headline.log 2>&1
-for f in $(find $O/stats_headline -name 'p_kernel_stats.csv'); do cp $f $O/bench_kernel_stats.csv; done
+for f in $(find $O/stats_headline -name 'p_kernel_stats.csv'); do cp $f $O/bench_kernel_stats_two_streams.csv; done
 grep '^{' $O/stats_headline.log | tail -1 > $O/bench_line_headline_under_rocprof.json
+# the same command with every step on ONE stream: every dispatch of the headline kernel isolated, so that the AVERAGE of the stats summary is the duration of a launch
+# (with the default two step streams a dispatch begins when it reaches the head of its queue, while the previous step still holds the CUs: begin to end it spans two steps)
+PDP_BENCH_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline1 -o p -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-scaling-configs > $O/stats_headline1.log 2>&1
+for f in $(find $O/stats_headline1 -name 'p_kernel_stats.csv'); do cp $f $O/bench_kernel_stats.csv; done
+grep '^{' $O/stats_headline1.log | tail -1 > $O/bench_line_headline_one_stream_under_rocprof.json
 hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calibrate probes/pmc_calibrate.hip > $O/calib_build.log 2>&1
 /tmp/pmc_calibrate 1024 4 > $O/calib_truth.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o p -- /tmp/pmc_calibrate 1024 4 > $O/calib_fetch.log 2>&1
