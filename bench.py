@@ -999,6 +999,14 @@ def main():
         except Exception as ex:              # the headline line must survive a failure of the side measurements (all ranks fail alike: no collective is left half-way)
             scal = {"error": repr(ex)}
 
+    if distributed:                     # every rank empties its C stdout (RCCL's banner) before rank 0 writes the line: the JSON line is the last line of the job
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        dist.barrier()
     if rank == 0:
         value = world * B * args.steps / dt
         traffic, traffic_cal, traffic_at, traffic_current = None, None, None, None
@@ -1082,7 +1090,15 @@ def main():
                 res["other_configs"] = other_configs(torch)
             except Exception as ex:          # the headline line must survive a failure of the side measurements
                 res["other_configs"] = {"error": repr(ex)}
-        print(json.dumps(res))
+        # (RCCL writes its version banner to the C stdout, which is block-buffered on a pipe and would land BEHIND the line at exit: flushed first, so that the JSON
+        # line is the last line this process writes)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
         if os.environ.get("PDP_BENCH_WINDOWS"):
             json.dump({"windows": WINDOWS, "line": res}, open(os.environ["PDP_BENCH_WINDOWS"], "w"))
     if distributed:
