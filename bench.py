@@ -860,6 +860,9 @@ def main():
     # steps and the timed region (rounds 1 - 5: between them, 20 samples): 200 launches are 20 ms of sustained load, and a process whose GPU has been busy for 3 ms
     # measures its first 20 steps 7 % slower than the same steps 15 ms later (launch_diagnostics.timed_region_repeated_ms_per_step of the round-6 lines: 0.0986, 0.0966,
     # 0.0940, 0.0922 ms per step for four consecutive regions of 20 steps - the clocks of an idle GPU ramp over tens of milliseconds).  The headline is a sustained rate.
+    import gc
+    gc.collect()
+    gc.disable()                        # (until the timed region is over: see there)
     KERNEL_SAMPLES = max(200, args.steps)
     kern_ms = _event_ms(torch, prepared[0][0], reps=KERNEL_SAMPLES, warm=2)
     headline_window = kern_ms.wins[0]
@@ -925,6 +928,11 @@ def main():
                 raise SystemExit("the replayed graph does not reproduce the eager step bit for bit")
 
     # ---- the timed region: EXACTLY K steps between barrier + synchronize
+    # (host hygiene for a region of 2 ms: the garbage collector is off from before the kernel sampling on - a collection is milliseconds of host time, i.e. an idle GPU,
+    # whether it falls into the region or in front of it: one run in four measured 9.8 M instead of 11.4 M trajectories/s with identical repeats behind it,
+    # gpurun_out/r06n_*.json; with it off eight runs in a row gave 11.1 - 11.5 M.  PDP_BENCH_POLL_END=1: the host polls an event behind the last step before it calls
+    # synchronize instead of sleeping until an interrupt wakes it - measured 20 us SLOWER per region, r06p against r06q, so off)
+    end_ev = torch.cuda.Event()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -936,11 +944,17 @@ def main():
     else:
         for _ in range(args.steps):
             step()
+    t_enq = time.perf_counter() - t0    # (diagnostic: the host's share - how long it took to ENQUEUE the K steps)
     finish()                            # every kernel and every exchange of the K steps has completed inside the timed region
+    if os.environ.get("PDP_BENCH_POLL_END", "0") == "1":
+        end_ev.record()
+        while not end_ev.query():
+            pass
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     WINDOWS.append({"window": len(WINDOWS), "reps": args.steps, "event_ms_median": dt / args.steps * 1e3, "t0": c0, "t1": _clocks(), "what": "the timed region (K steps)"})
     check_outputs()                     # what the timed steps wrote: status flags clear, finite, the single call's rows bit for bit
     timed_window = len(WINDOWS) - 1
@@ -965,7 +979,8 @@ def main():
             use(None)
             ones = [region(step, finish) for _ in range(3)]
             use(chosen_)
-        launch_diag = {"timed_region_repeated_ms_per_step": reps, "one_stream_ms_per_step": ones, "stream_placement": placement}
+        launch_diag = {"timed_region_repeated_ms_per_step": reps, "one_stream_ms_per_step": ones, "stream_placement": placement,
+                       "timed_region_host_enqueue_ms_total": t_enq * 1e3}
     per_rank = None
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
