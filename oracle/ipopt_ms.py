@@ -136,7 +136,7 @@ def least_squares_multipliers(ev, n, m):
     return dl if ok else np.full((T, n), np.nan)          # (a non-finite point: the callers then start from zero multipliers, as for an estimate above constr_mult_init_max)
 
 
-def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None, soc=False):
+def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=None, restoration=True, u_init=None, warm=None, soc=False, watchdog=False):
     """ocSolver's NLP (PDP.py:131-182) solved the way IPOPT does.  Returns the reference's result fields plus `iterations` and `restorations`.
     log: optional list receiving one dict per iteration (objective, inf_pr, inf_du, dw, alpha, step type).
     restoration: what happens when the line search falls below alpha_min, where IPOPT switches to its feasibility restoration phase.  IPOPT's own
@@ -150,7 +150,13 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     warm = (state [T+1, n], control [T, m], costate [T, n]): start the iteration AT that point (x_0 replaced by ini_state, no least-squares multiplier estimate) -
     what PDP_MS_WARM does in the kernel; with the point predict_start below returns, the start of an IRL loop's next solve.
     soc: second-order correction (PDP_MS_WITH_SOC in the kernel; the header says why it is off by default); the log rows carry `soc` = the number of corrections tried in
-    the iteration and `soc_taken`; the result the total `soc_steps`."""
+    the iteration and `soc_taken`; the result the total `soc_steps`.
+    watchdog (round 6, EXPERIMENT - not in the kernels, parity unpinned: restated from the structure of IPOPT's BacktrackingLineSearch as remembered, no source or
+    run of IPOPT to check it against): after watchdog_shortened_iter_trigger = 10 consecutive iterations whose accepted step was shortened the current iterate and
+    direction are stored; for up to watchdog_trial_iter_max = 3 iterations the FULL step is taken whether acceptable or not, each tested against the stored point's
+    (theta, phi, grad(phi)'d) and the filter; the first acceptable one ends the procedure, otherwise the stored iterate comes back and is searched along its stored
+    direction from alpha = 1/2.  The log rows carry `wd` ("start", "trial", "success", "stop"); the result `watchdog_starts` / `watchdog_successes`.
+    probes/watchdog_experiment.py asks what it does to the cold rocket solves at T = 100 that crawl with steps of 1e-3."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
@@ -181,6 +187,7 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     it = 0
     n_rest = 0
     n_soc_total = 0
+    in_wd, wd_short, wd_trial, wd, n_wd, n_wd_ok = False, 0, 0, None, 0, 0
     for it in range(max_iter + 1):
         f, theta = ev["f"], ev["theta"]
         inf_pr_it, inf_du_it = ev["inf_pr"], ev["inf_du"]
@@ -192,6 +199,7 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
             raise RuntimeError("ipopt_ms: no convergence in %d iterations" % max_iter)
         # ---- search direction with inertia correction (Algorithm IC)
         dw = 0.0
+        wd_fell_back = False
         while True:
             dx, du, dl, ok = kkt_step(ev, dw, n, m)
             if ok:
@@ -201,7 +209,18 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
             else:
                 dw *= o["perturb_inc_fact_first"] if dw_last == 0.0 else o["perturb_inc_fact"]
             if dw > o["max_hessian_perturbation"]:
+                if in_wd:
+                    # a free watchdog trial landed where the iteration cannot go on (not finite, or no perturbation succeeds): the procedure ends, the stored iterate
+                    # comes back and the iteration goes on from it as a regular one (direction computed anew); one log row and one iteration are spent
+                    if log is not None:
+                        log.append(dict(it=it, f=wd["f"], inf_pr=wd["ev"]["inf_pr"], inf_du=wd["ev"]["inf_du"], dw=dw, alpha=0.0, ftype=False, gd=wd["gd"], theta=wd["theta"],
+                                        soc=0, soc_taken=False, wd="fallback"))
+                    xs, us, lam, ev = wd["xs"], wd["us"], wd["lam"], wd["ev"]
+                    in_wd, wd_short, wd_fell_back = False, 0, True
+                    break
                 raise RuntimeError("ipopt_ms: inertia correction failed")
+        if wd_fell_back:
+            continue
         if dw > 0.0:
             dw_last = dw
         # grad phi' d = rd' d + lam' c   (A d = -c)
@@ -215,15 +234,51 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
         else:
             amin = o["gamma_theta"]
         amin *= o["alpha_min_frac"]
-        def acceptable(ft, tht, a):
-            """(accepted, f-type) of a trial point with objective ft and violation tht, tested with the step length a (steps A-5.3, A-5.4)"""
+        def acceptable(ft, tht, a, ref=None):
+            """(accepted, f-type) of a trial point with objective ft and violation tht, tested with the step length a (steps A-5.3, A-5.4); ref = (f, theta, gd) of the
+            point the test refers to (the iterate; in a watchdog procedure the stored point)"""
+            f_, theta_, gd_ = (f, theta, gd) if ref is None else ref
             if not (np.isfinite(ft) and np.isfinite(tht) and tht <= theta_max and all(not (tht >= th_f and ft >= f_f) for th_f, f_f in filt)):
                 return False, False
-            switching = gd < 0.0 and a * (-gd) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
-            if theta <= theta_min and switching:
-                ok_ = ft <= f + o["eta_phi"] * a * gd + 10.0 * np.finfo(float).eps * abs(f)
+            switching = gd_ < 0.0 and a * (-gd_) ** o["s_phi"] > o["delta"] * theta_ ** o["s_theta"]
+            if theta_ <= theta_min and switching:
+                ok_ = ft <= f_ + o["eta_phi"] * a * gd_ + 10.0 * np.finfo(float).eps * abs(f_)
                 return ok_, ok_
-            return (tht <= (1.0 - o["gamma_theta"]) * theta or ft <= f - o["gamma_phi"] * theta), False
+            return (tht <= (1.0 - o["gamma_theta"]) * theta_ or ft <= f_ - o["gamma_phi"] * theta_), False
+
+        if watchdog and not in_wd and wd_short >= 10:
+            in_wd, wd_trial, n_wd = True, 0, n_wd + 1
+            wd = dict(xs=xs.copy(), us=us.copy(), lam=lam.copy(), ev=ev, dx=dx, du=du, dl=dl, gd=gd, f=f, theta=theta, dw=dw, amin=amin, started=True)
+        if in_wd:
+            ref = (wd["f"], wd["theta"], wd["gd"])
+            xt, ut = xs + dx, us + du
+            ft, tht, ct = objective_and_violation(oc, xt, ut, e, defects=True)
+            ok_wd, ftype_wd = acceptable(ft, tht, 1.0, ref)
+            fin_wd = bool(np.isfinite(ft) and np.isfinite(tht))
+            tag = None
+            if ok_wd:
+                in_wd, wd_short, n_wd_ok, tag = False, 0, n_wd_ok + 1, "success"
+                if not ftype_wd:
+                    filt.append(((1.0 - o["gamma_theta"]) * ref[1], ref[0] - o["gamma_phi"] * ref[1]))
+            else:
+                wd_trial += 1
+                if fin_wd and wd_trial <= 3:
+                    tag = "start" if wd.pop("started", False) else "trial"
+            if tag is not None:         # the full step is taken (acceptable, or one of the three free trials)
+                wd.pop("started", None)
+                if log is not None:
+                    log.append(dict(it=it, f=f, inf_pr=ev["inf_pr"], inf_du=ev["inf_du"], dw=dw, alpha=1.0, ftype=False, gd=gd, theta=theta, soc=0, soc_taken=False, wd=tag))
+                xs, us, lam = xt, ut, lam + dl
+                ev = evaluate(oc, xs, us, lam, e)
+                continue
+            # the procedure failed: back to the stored iterate, regular backtracking along the stored direction, the full step known to fail
+            xs, us, lam, ev = wd["xs"], wd["us"], wd["lam"], wd["ev"]
+            dx, du, dl, gd, f, theta, dw, amin = wd["dx"], wd["du"], wd["dl"], wd["gd"], wd["f"], wd["theta"], wd["dw"], wd["amin"]
+            inf_pr_it, inf_du_it = ev["inf_pr"], ev["inf_du"]
+            in_wd, wd_short = False, 0
+            alpha = o["alpha_red_factor"]
+            if log is not None:
+                log.append(dict(it=it, f=f, inf_pr=inf_pr_it, inf_du=inf_du_it, dw=dw, alpha=0.0, ftype=False, gd=gd, theta=theta, soc=0, soc_taken=False, wd="stop"))
 
         n_soc, soc_taken = 0, False
         dl_step = dl
@@ -275,18 +330,20 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
             lam = lam0 if (np.all(np.isfinite(lam0)) and np.abs(lam0).max() <= o["constr_mult_init_max"]) else np.zeros((T, n))
             ev = evaluate(oc, xs, us, lam, e)
             n_rest += 1
+            wd_short = 0
             if log is not None:
                 log.append(dict(it=it, f=f, inf_pr=inf_pr_it, inf_du=inf_du_it, dw=dw, alpha=0.0, ftype=False, gd=gd, theta=theta, restoration=True, soc=n_soc, soc_taken=False))
             continue
         if not ftype:
             filt.append(((1.0 - o["gamma_theta"]) * theta, f - o["gamma_phi"] * theta))
+        wd_short = 0 if (alpha == 1.0 or soc_taken) else wd_short + 1          # consecutive iterations with a shortened step (the watchdog's trigger)
         if log is not None:
             log.append(dict(it=it, f=f, inf_pr=ev["inf_pr"], inf_du=ev["inf_du"], dw=dw, alpha=alpha, ftype=ftype, gd=gd, theta=theta,
                             dx=dx, du=du, dlam=dl, soc=n_soc, soc_taken=soc_taken))
         xs, us, lam = xt, ut, lam + alpha * dl_step             # (a corrected step is a full one: alpha = 1 there)
         ev = evaluate(oc, xs, us, lam, e)
     return {"state_traj_opt": xs, "control_traj_opt": us, "costate_traj_opt": lam, "cost": ev["f"], "iterations": it, "restorations": n_rest, "soc_steps": n_soc_total,
-            "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"]}
+            "inf_pr": ev["inf_pr"], "inf_du": ev["inf_du"], "watchdog_starts": n_wd, "watchdog_successes": n_wd_ok}
 
 
 def predict_start(oc, state, control, costate, auxvar_value, dtheta, with_costate=True):

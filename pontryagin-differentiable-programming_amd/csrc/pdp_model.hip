@@ -278,13 +278,13 @@ int64_t oc_solve_ms_ws_bytes(int B, int T, int max_iter) {
         return a > c ? a : c;                       // either variant may serve the call
     } else return 0;
 }
-template <class Mdl, int TPW>
+template <class Mdl, int TPW, bool WD = false>
 int oc_solve_ms2_launch(int B, int T, const pdp_oc_ms_opts* op, const double* x0, const double* th, int tb, double* x, double* u, double* lam, double* cost,
                         double* resid, int32_t* converged, int32_t* iterations, int32_t* status, double* gains, double* iter_log, void* ws, void* st) {
     constexpr int lds = TPW * Ms2Layout<Mdl>::SLICE * (int)sizeof(double);
-    (void)hipFuncSetAttribute((const void*)oc_solve_ms2_kernel<Mdl, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)oc_solve_ms2_kernel<Mdl, TPW, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     PDP_CLEAR();
-    hipLaunchKernelGGL((oc_solve_ms2_kernel<Mdl, TPW>), dim3((B + TPW - 1) / TPW), dim3(128 * TPW), lds, S(st), B, T, *op, x0, th, tb, x, u, lam, cost, resid,
+    hipLaunchKernelGGL((oc_solve_ms2_kernel<Mdl, TPW, WD>), dim3((B + TPW - 1) / TPW), dim3(128 * TPW), lds, S(st), B, T, *op, x0, th, tb, x, u, lam, cost, resid,
                        converged, iterations, status, gains, op->log_rows > 0 ? iter_log : (double*)nullptr, (double*)ws);
     return launched();
 }
@@ -297,6 +297,8 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         if (op->max_iter < 0 || wsb < oc_solve_ms_ws_bytes<Mdl>(B, T, op->max_iter)) return PDP_E_ARG;
         const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
         if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
+        const bool watchdog = (op->flags & PDP_MS_WITH_WATCHDOG) != 0;
+        if (watchdog && (op->flags & PDP_MS_WITH_SOC)) return PDP_E_ARG;       // (the stored direction of a watchdog procedure waits where a correction keeps the plain step)
         const bool predict = (op->flags & PDP_MS_PREDICT) != 0;
         if ((op->flags & PDP_MS_PREDICT_PRIMAL) && (!predict || !op->predict_record)) return PDP_E_ARG;
         if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || (!op->predict_record && (!op->dxdp || !op->dudp)))) return PDP_E_ARG;
@@ -319,12 +321,17 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
                 // trajectories per workgroup: 4 (runner and evaluator of a trajectory share a SIMD) once the batch fills the chip that way; smaller
                 // batches spread over the CUs with the two waves of a trajectory on different SIMDs
                 const int cus = device_cu_count();
+                // PDP_MS_WITH_WATCHDOG: the instantiations with the watchdog, one / two trajectories per workgroup whatever the batch (see the kernel's template line)
+                if (watchdog) {
+                    if (B <= cus) return oc_solve_ms2_launch<Mdl, 1, true>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
+                    return oc_solve_ms2_launch<Mdl, 2, true>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
+                }
                 if (B <= cus) return oc_solve_ms2_launch<Mdl, 1>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
                 if (B <= 2 * cus) return oc_solve_ms2_launch<Mdl, 2>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
                 return oc_solve_ms2_launch<Mdl, 4>(B, T, op, x0, th, tb, x, u, lam, cost, resid, converged, iterations, status, gains, iter_log, ws, st);
             }
         }
-        if (needs_pair) return PDP_E_SIZE;
+        if (needs_pair || watchdog) return PDP_E_SIZE;      // (only the runner / evaluator kernel restores, and only it has the watchdog)
         const size_t lds = ms_lds_bytes<Mdl>();
         if (lds > 160 * 1024) return PDP_E_SIZE;
         { const int rc = predict_first(); if (rc != 0) return rc; }

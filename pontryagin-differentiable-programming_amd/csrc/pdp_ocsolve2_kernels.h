@@ -112,7 +112,7 @@ struct Ms2Layout {
     __host__ __device__ static constexpr bool predict_fits(int T) { return (int64_t)(T + 1) * NX + PRED_STG <= 2 * BUF; }
     __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
-        return 7 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1);
+        return 7 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1) + group_doubles(T);      // (the last group: the watchdog's stored iterate)
     }
 };
 
@@ -220,7 +220,9 @@ PDP_DEV double ms2_up1(double v) { return ms2_dpp<0x138>(v, v); }
 PDP_DEV double sm_ld(const double* row, unsigned off8) { return *(const double*)((const char*)row + off8); }
 PDP_DEV void sm_st(double* row, unsigned off8, double v) { *(double*)((char*)row + off8) = v; }
 
-template <class Mdl, int TPW>
+// WD: IPOPT's watchdog in the line search (PDP_MS_WITH_WATCHDOG; see the main loop).  A template constant, so that the instantiations without it are the code they were:
+// the four-trajectory instantiation sits on its 256 registers, and the watchdog is only instantiated for one / two trajectories per workgroup (512 registers per wave).
+template <class Mdl, int TPW, bool WD = false>
 __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, pdp_oc_ms_opts op, const double* __restrict__ x0, const double* __restrict__ theta,
                                                                   int tb, double* __restrict__ x, double* __restrict__ u, double* __restrict__ lam,
                                                                   double* __restrict__ cost, double* __restrict__ resid, int32_t* __restrict__ converged,
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     double* pw = gw + (int64_t)T * GSZ;                      // P_{t+1}, W_{t+1}, T x PWSZ
     double* fth = pw + (int64_t)T * PWSZ;                    // filter: theta entries (at most one per iteration) ...
     double* fph = fth + (op.max_iter + 1);                   //         ... and phi entries
+    double* wdp = fph + (op.max_iter + 1);                   // watchdog: the stored iterate (one group; the stored direction waits in stpb)
     // chunks: backward chunk g (0 = last stages) covers [t0, t0 + cnt); forward chunks follow in the same numbering
     const int nchunk = (T + L::ROWS - 1) / L::ROWS;
     const int ch = (T + nchunk - 1) / nchunk;
@@ -1127,11 +1130,52 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
         // What the line search must remember across the sweep of a correction (directional derivative, alpha_min, theta of the attempt before, the two counters) waits
         // in the mailbox, not in registers: held live across the sweeps, those few values were exactly what the 256-register instantiation then spilled.
         const bool soc_on = (op.flags & PDP_MS_WITH_SOC) != 0;
+        // Watchdog (IPOPT's BacktrackingLineSearch: watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; PDP_MS_WITH_WATCHDOG, instantiations WD only).  After ten
+        // consecutive iterations whose accepted step was shortened (alpha < 1) the iterate and its direction are stored; for up to three iterations the FULL step is then
+        // taken whether acceptable or not, each trial point tested against the STORED point's (theta, phi, grad(phi)'d) and the filter; the first acceptable one ends the
+        // procedure (the filter is augmented from the stored point's values), otherwise the stored iterate and direction come back and the regular search continues from
+        // alpha = 1/2.  oracle/ipopt_ms.py: solve(watchdog=True) is the same, restated from memory of IPOPT's structure - no IPOPT here to pin it on, hence opt-in; why it
+        // exists at all: profiles/r06_solver_iterlog_stats.txt (cold rocket solves at T = 100 crawl with steps of 1e-3 for hundreds of iterations; the trigger is met in 199
+        // of 256) and profiles/r06_watchdog_experiment.txt (the restatement with it: 15 of 16 within 300 iterations instead of 12, the same optima).
+        const bool wd_on = WD && (op.flags & PDP_MS_WITH_WATCHDOG) != 0;
+        bool in_wd = false;
+        int wd_short = 0, wd_trial = 0;
+        double w_f = 0.0, w_th = 0.0, w_gd = 0.0, w_dw = 0.0, w_amin = 0.0, w_pr = 0.0, w_du = 0.0;
+        // A free watchdog trial may land where the iteration cannot go on (not finite, or no inertia correction below 1e20 succeeds: 33 of 512 cold rocket solves at
+        // T = 100 ended that way before this existed): the procedure ends, the stored iterate comes back, its residuals are evaluated again, and the iteration goes on
+        // from there as a regular one (the direction is computed anew: the regularisation history has moved on).  One log row (alpha = 0) and one iteration are spent.
+        auto wd_fallback = [&](double& dw_, int cur_) {
+            __threadfence_block();
+            double* __restrict__ sp = Pt(cur_);
+            for (int q = lane; q < (int)GRP; q += 64) sp[q] = wdp[q];
+            __threadfence_block();
+            in_wd = false; wd_short = 0;
+            issue(MS2_CMD_TRIAL, 0.0, cur_, cur_);
+            wait_done();
+            read_res();
+#ifndef PDP_MS_TIMING
+            if (iter_log && it < op.log_rows && lane == 0) {
+                double* row = iter_log + ((int64_t)b * op.log_rows + it) * 8;
+                row[0] = it; row[1] = w_f; row[2] = w_pr; row[3] = w_du; row[4] = dw_; row[5] = 0.0; row[6] = w_gd; row[7] = w_th;
+            }
+#endif
+            dw_ = 0.0;
+            gains_ok = false;
+            ++it;
+        };
 #ifdef PDP_MS_TIMING
         const long long tk1 = tmi, tk2 = __builtin_readcyclecounter();
 #endif
         for (;;) {
             if (dead) break;
+            if constexpr (WD) {
+                if (in_wd && phase == 1 && dw == 0.0 && !finite) {      // a free watchdog trial that is not finite on the dual side
+                    if (pending) { abort_sweep(); pending = false; }
+                    if (dead) break;
+                    wd_fallback(dw, cur);
+                    continue;
+                }
+            }
             const int soc_sweep = uni(ctl[MS2_SOCM]);   // this pass of the loop computes a correction of the step, not a step
             bool soc_fail = false;
             if (phase == 1 && dw == 0.0 && !soc_sweep) { // a new iterate: converged?  (a sweep follows only if not - or once more for the gains output)
@@ -1162,11 +1206,17 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             } else if (soc_sweep) {
                 soc_fail = !(pd && PWfinite);           // (the matrix of a step that has just been accepted by the inertia test: cannot happen short of a non-finite c_soc)
             } else {
-                if (!PWfinite) { st |= PDP_STATUS_NONFINITE; break; }
+                if (!PWfinite) {
+                    if constexpr (WD) { if (in_wd) { wd_fallback(dw, cur); continue; } }
+                    st |= PDP_STATUS_NONFINITE; break;
+                }
                 if (!pd) {                              // Algorithm IC (defaults: 1e-4 first, x100 / x8 up, /3 down, 1e20 max)
                     if (dw == 0.0) dw = dw_last == 0.0 ? 1e-4 : fmax(1e-20, dw_last * (1.0 / 3.0));
                     else dw *= dw_last == 0.0 ? 100.0 : 8.0;
-                    if (dw > 1e20) { st |= PDP_MS_INERTIA; break; }
+                    if (dw > 1e20) {
+                        if constexpr (WD) { if (in_wd) { wd_fallback(dw, cur); continue; } }
+                        st |= PDP_MS_INERTIA; break;
+                    }
                     continue;
                 }
                 if (dw > 0.0) dw_last = dw;
@@ -1195,7 +1245,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 phase = 1; hs = 1.0; dw = 0.0;
                 continue;
             }
-            const double f = f_cur, theta = th_cur;
+            double f = f_cur, theta = th_cur;
             // backtracking filter line search (Algorithm A): alpha_min below which IPOPT would enter the restoration phase
             int soc_mode = soc_sweep, soc_n = 0;
             double alpha = 1.0, amin = 1e-5, soc_th_old = 0.0;
@@ -1220,6 +1270,19 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             }
             double ft = 0.0, tht = 0.0;
             bool accepted = false, ftype = false, fin_p = true, to_soc = false;
+            bool wd_free = false;                       // a watchdog trial taken although it is not acceptable
+            double rf = f, rth = theta;                 // the point the accepting test referred to (the filter is augmented from it)
+            if constexpr (WD) {
+                if (wd_on && !in_wd && wd_short >= 10) {        // start: the iterate into wdp, its direction into stpb
+                    __threadfence_block();
+                    const double* __restrict__ sp = Pt(cur);
+                    for (int q = lane; q < (int)GRP; q += 64) { wdp[q] = sp[q]; stpb[q] = stp[q]; }
+                    __threadfence_block();
+                    in_wd = true; wd_trial = 0;
+                    w_f = f; w_th = theta; w_gd = gd; w_dw = dw; w_amin = amin; w_pr = inf_pr; w_du = inf_du;
+                    st |= PDP_MS_WATCHDOG;
+                }
+            }
             while (soc_mode || (alpha >= amin && alpha > 1e-300)) {      // (the second bound only guards against amin = 0)
                 const double a_try = soc_mode ? 1.0 : alpha;           // (a corrected step is taken in full: no bounds, no fraction-to-the-boundary rule)
                 issue(MS2_CMD_TRIAL_SWEEP, a_try, cur, cur ^ 1);
@@ -1240,11 +1303,35 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                     for (int e = lane; e < nfilt; e += 64) dominated = dominated || (tht >= fth[e] && ft >= fph[e]);
                     okf = !__any(dominated);
                 }
+                double rgd = gd;
+                rf = f; rth = theta;
+                if constexpr (WD) { if (in_wd) { rf = w_f; rth = w_th; rgd = w_gd; } }      // (a watchdog trial is judged from the stored point)
                 if (okf) {
-                    const bool switching = gd < 0.0 && alpha * pow(-gd, 2.3) > pow(theta, 1.1);
-                    if (theta <= theta_min && switching) {
-                        if (ft <= f + 1e-8 * alpha * gd + 10.0 * 2.220446049250313e-16 * fabs(f)) { accepted = true; ftype = true; }
-                    } else if (tht <= (1.0 - 1e-5) * theta || ft <= f - 1e-8 * theta) accepted = true;
+                    const bool switching = rgd < 0.0 && alpha * pow(-rgd, 2.3) > pow(rth, 1.1);
+                    if (rth <= theta_min && switching) {
+                        if (ft <= rf + 1e-8 * alpha * rgd + 10.0 * 2.220446049250313e-16 * fabs(rf)) { accepted = true; ftype = true; }
+                    } else if (tht <= (1.0 - 1e-5) * rth || ft <= rf - 1e-8 * rth) accepted = true;
+                }
+                if constexpr (WD) {
+                    if (in_wd) {
+                        if (accepted) { in_wd = false; wd_short = 0; }                                  // the procedure succeeded
+                        else {
+                            ++wd_trial;
+                            if (fabs(ft) <= 1.7e308 && fabs(tht) <= 1.7e308 && wd_trial <= 3) { accepted = true; wd_free = true; }      // taken all the same
+                            else {                      // failed: back to the stored iterate, the regular search along its direction, the full step known to fail
+                                abort_sweep();
+                                if (dead) break;
+                                __threadfence_block();
+                                double* __restrict__ sp = Pt(cur);
+                                for (int q = lane; q < (int)GRP; q += 64) { sp[q] = wdp[q]; stp[q] = stpb[q]; }
+                                __threadfence_block();
+                                f = w_f; theta = w_th; gd = w_gd; dw = w_dw; amin = w_amin; inf_pr = w_pr; inf_du = w_du;
+                                in_wd = false; wd_short = 0;
+                                alpha = 0.5;
+                                continue;
+                            }
+                        }
+                    }
                 }
                 if (accepted) break;
                 abort_sweep();                          // (the evaluator went on with the sweep of the rejected point)
@@ -1299,6 +1386,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
                 ++nfilt;
                 __threadfence_block();
+                wd_short = 0;
                 issue(MS2_CMD_RESTORE, 0.0, cur, cur);
                 wait_done();
                 if (dead) break;
@@ -1309,11 +1397,12 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                 ++it;
                 continue;
             }
-            if (!ftype) {                               // (at most one entry per iteration: the workspace holds max_iter + 1)
-                if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * theta; fph[nfilt] = f - 1e-8 * theta; }
+            if (!ftype && !wd_free) {                   // (at most one entry per iteration: the workspace holds max_iter + 1; a free watchdog trial adds none)
+                if (lane == 0) { fth[nfilt] = (1.0 - 1e-5) * rth; fph[nfilt] = rf - 1e-8 * rth; }
                 ++nfilt;
                 __threadfence_block();
             }
+            if constexpr (WD) { if (!in_wd) wd_short = (alpha == 1.0 || soc_taken) ? 0 : wd_short + 1; }       // consecutive shortened iterations: the watchdog's trigger
             // the accepted trial's residuals are the new iterate's: the primal side from this wave's half of the pass, the dual side from the evaluator's
             if constexpr (SPLIT) {
                 f_cur = a_f; th_cur = a_th; inf_pr = a_pr; zmax = a_z; lamc = a_lc;

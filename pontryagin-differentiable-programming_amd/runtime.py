@@ -381,8 +381,9 @@ class ModelLib:
         return out
 
     def oc_solve_ms(self, x0, theta, T, tol=1e-10, max_iter=300, warm=None, want_gains=False, log_rows=0, restoration=True, u_init=None, consume_warm=False, predict=None,
-                    soc=False):
-        """The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
+                    soc=False, watchdog=False):
+        """watchdog=True: IPOPT's watchdog in the line search (PDP_MS_WITH_WATCHDOG, include/pdp_hip.h: opt-in, not together with soc) - for cold solves that crawl.
+        The reference's multiple-shooting NLP (PDP.py:131-182) solved by IPOPT's algorithm from its all-zero initial guess
         (pdp_oc_solve_ms_batched: a persistent pair of wavefronts per trajectory, all iterations in one launch).  warm = (x, u, lam) starts
         from a given point instead (x[:, 0] is replaced by x0).  restoration=False: a line search that falls below alpha_min ends the trajectory with
         PDP_MS_RESTORATION instead of entering the feasibility restoration (include/pdp_hip.h).  u_init [B, T, m] (instead of warm): start from these
@@ -424,7 +425,7 @@ class ModelLib:
         nbytes = self.lib.pdp_oc_solve_ms_workspace_bytes(B, T, int(max_iter))
         ws = torch.empty((max(nbytes, 8) // 8,), **f64)
         log = torch.zeros((B, int(log_rows), 8), **f64) if log_rows > 0 else None
-        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0) | (128 if soc else 0), int(log_rows))
+        opts = PdpOcMsOpts(float(tol), int(max_iter), (1 if warm is not None else 0) | (0 if restoration else 2) | (9 if u_init is not None else 0) | (128 if soc else 0) | (256 if watchdog else 0), int(log_rows))
         keep = None
         if predict is not None:
             assert warm is not None, "predict needs the previous solution as the warm point"

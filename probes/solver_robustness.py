@@ -87,6 +87,20 @@ def main():
                                                                 "status_bits": {BITS.get(b, str(b)): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 64, 128, 1024) if ((st & b) != 0).any()}}
                 print("%-24s max_iter %-5d converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  %.1f ms  status %s" %
                       (name, mi, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), ms, entry["kernel"]["tol_1e-08_max_iter_%d" % mi]["status_bits"]))
+        # PDP_MS_WITH_WATCHDOG (round 6, third session): IPOPT's watchdog in the kernel's line search, at this solver's limit and at the longer leashes
+        for mi in ((300, 1000, 3000) if system == "rocket" else (300,)):
+            s = mdl.oc_solve_ms(x0, th, T, tol=1e-8, max_iter=mi, watchdog=True)
+            conv = s["converged"].cpu().numpy().astype(bool)
+            it = s["iterations"].cpu().numpy()
+            st = s["status"].cpu().numpy()
+            ms = float(bench._event_ms(torch, lambda: mdl.oc_solve_ms(x0, th, T, tol=1e-8, max_iter=mi, watchdog=True), reps=1, warm=0))
+            key = "tol_1e-08_max_iter_%d_watchdog" % mi
+            entry["kernel"][key] = {"converged": int(conv.sum()), "of": B, "rate": float(conv.mean()), "ms": ms,
+                                    "iterations": {"mean": float(it.mean()), "median": float(np.median(it)), "p95": float(np.percentile(it, 95)), "max": int(it.max())},
+                                    "watchdog_procedures_started_in": int(((st & 2048) != 0).sum()),
+                                    "status_bits": {BITS.get(b, str(b)): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 64, 128, 1024) if ((st & b) != 0).any()}}
+            print("%-24s max_iter %-5d WATCHDOG converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  %.1f ms  started in %d  status %s" %
+                  (name, mi, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), ms, entry["kernel"][key]["watchdog_procedures_started_in"], entry["kernel"][key]["status_bits"]))
         # the class surface's route (what a user of OCSys.ocSolver_batch gets): kernel, then single shooting for the rows it left unconverged
         oc = make_oc(system)
         sol = ocsolver.solve_batch(oc, x0, T, th, tol=1e-9)

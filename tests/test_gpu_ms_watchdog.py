@@ -1,0 +1,96 @@
+"""GPU: PDP_MS_WITH_WATCHDOG - IPOPT's watchdog in the solver kernel's line search (oc_solve_ms2_kernel<Mdl, TPW, true>) against the restatement's
+(oracle/ipopt_ms.py: solve(watchdog=True)) on the cold rocket solves at T = 100 it was built for (probes/solver_iterlog_stats.py, probes/watchdog_experiment.py:
+problems 4, 7, 15 of the C4 robustness set need 259, 307, 116 iterations without it, 106, 105, 65 with it).  The restatement itself is unpinned (no IPOPT here): what
+is tested is kernel == restatement, convergence to the same optimum as without the watchdog, and that nothing changes where the trigger is never met."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems():
+    from oracle import models
+    rng = np.random.default_rng(0)
+    rng.uniform(-0.5, 0.5, 256); rng.uniform(-0.45, 0.45, (256, 7))          # (the draws probes/solver_robustness.py makes before its rocket case)
+    x0 = np.zeros((512, 13))
+    x0[:, :3] = np.array([10, -8, 5.0]) + rng.standard_normal((512, 3))
+    x0[:, 3] = -0.1
+    x0[:, 6:10] = models.to_quaternion(1.5, [0, 0, 1])
+    return x0, np.array([0.5, 1, 1, 1, 1, 1, 1, 50, 1, 1.0])
+
+
+def _oracle_oc():
+    from oracle import models, pdp_oracle as po
+    st = models.IRL_SETUP["rocket"]
+    return po.make_oc(models.REGISTRY["rocket"](**st["kwargs"]), st["dt"])
+
+
+@pytest.mark.parametrize("b,it_plain,it_wd", [(4, 259, 106), (15, 116, 65)])
+def test_watchdog_kernel_follows_the_restatement(b, it_plain, it_wd):
+    from oracle import ipopt_ms
+    from pdp_amd import zoo
+    x0, th = _problems()
+    T = 100
+    log = []
+    ref = ipopt_ms.solve(_oracle_oc(), x0[b], T, th, tol=1e-8, max_iter=400, log=log, watchdog=True)
+    assert ref["iterations"] == it_wd and ref["watchdog_starts"] >= 1
+    last = {}
+    for l in log:                                   # (a failed procedure logs its "stop" row and the regular step under the same iteration number: the step counts)
+        last[l["it"]] = l
+    mdl = zoo.get("rocket", "irl")
+    out = mdl.oc_solve_ms(x0[b:b + 1], th, T, tol=1e-8, max_iter=400, log_rows=400, watchdog=True)
+    kl = out["log"][0].cpu().numpy()
+    assert bool(out["converged"][0]) and (int(out["status"][0]) & 2048) != 0
+    # row by row while the two floating-point paths stay together (hundreds of non-convex iterations: rounding eventually takes them apart): the iterations up to and
+    # including the first watchdog procedure
+    first_wd = min(l["it"] for l in log if l.get("wd"))
+    rows = first_wd + 6
+    for r in range(rows):
+        l = last[r]
+        a_ref = 0.0 if l.get("restoration") else l["alpha"]
+        assert kl[r, 0] == l["it"] and kl[r, 5] == a_ref, (r, kl[r], l["alpha"], l.get("wd"))
+        assert abs(kl[r, 1] - l["f"]) <= 1e-6 * max(1.0, abs(l["f"])) and abs(kl[r, 4] - l["dw"]) <= 1e-9 * max(1e-20, l["dw"]), (r, kl[r], l["f"], l["dw"])
+    assert any(last[r].get("wd") for r in range(rows))
+    # the same optimum, in far fewer iterations than without the watchdog
+    plain = mdl.oc_solve_ms(x0[b:b + 1], th, T, tol=1e-8, max_iter=400)
+    assert bool(plain["converged"][0]) and abs(int(plain["iterations"][0]) - it_plain) <= 3 and (int(plain["status"][0]) & 2048) == 0
+    assert int(out["iterations"][0]) <= 0.75 * int(plain["iterations"][0]) and abs(int(out["iterations"][0]) - it_wd) <= 0.15 * it_wd
+    assert abs(float(out["cost"][0]) - ref["cost"]) <= 1e-6 * abs(ref["cost"]) and abs(float(out["cost"][0]) - float(plain["cost"][0])) <= 1e-6 * abs(ref["cost"])
+
+
+def test_watchdog_changes_nothing_where_its_trigger_is_never_met(golden_dir):
+    """the stored demonstrations of the five systems from the zero guess: no run of ten shortened iterations, so the flag changes neither the iteration count nor - bit for
+    bit - the solution, in one and in two trajectories per workgroup; PDP_MS_WITH_SOC beside it is refused"""
+    from pdp_amd import zoo
+    for name in ("pendulum", "cartpole", "robotarm", "quadrotor", "rocket"):
+        d = np.load(os.path.join(golden_dir, "demos_%s.npz" % name))
+        mdl = zoo.get(name, "irl")
+        T = d["control"].shape[1]
+        for B in (2, 300):
+            x0 = np.repeat(d["state"][0:1, 0], B, axis=0)
+            a = mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10)
+            w = mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10, watchdog=True)
+            assert bool(w["converged"].all()) and (w["iterations"] == a["iterations"]).all() and (w["status"] == a["status"]).all(), name
+            for k in ("state", "control", "costate"):
+                assert np.array_equal(w[k].cpu().numpy(), a[k].cpu().numpy()), (name, B, k)
+    with pytest.raises(Exception):
+        mdl.oc_solve_ms(x0, d["true_parameter"], T, tol=1e-10, watchdog=True, soc=True)
+
+
+def test_watchdog_at_batch_scale():
+    """the first 128 problems of the C4 robustness set, 300 iterations: more of them converge with the watchdog than without, none ends non-finite, and those that converge
+    both ways agree on the optimum"""
+    from pdp_amd import zoo
+    x0, th = _problems()
+    mdl = zoo.get("rocket", "irl")
+    a = mdl.oc_solve_ms(x0[:128], th, 100, tol=1e-8, max_iter=300)
+    w = mdl.oc_solve_ms(x0[:128], th, 100, tol=1e-8, max_iter=300, watchdog=True)
+    ca, cw = a["converged"].cpu().numpy().astype(bool), w["converged"].cpu().numpy().astype(bool)
+    assert cw.sum() >= ca.sum() + 5 and cw.sum() >= 0.78 * 128          # (measured: 105 against 96)
+    assert ((w["status"].cpu().numpy() & 1) == 0).all()
+    both = ca & cw
+    fa, fw = a["cost"].cpu().numpy()[both], w["cost"].cpu().numpy()[both]
+    assert (np.abs(fa - fw) <= 1e-6 * np.abs(fa)).mean() >= 0.95          # (a non-convex problem: a different path may end in a different stationary point)
+    assert np.median(w["iterations"].cpu().numpy()) < np.median(a["iterations"].cpu().numpy())
