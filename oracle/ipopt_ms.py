@@ -156,7 +156,10 @@ def solve(oc, ini_state, horizon, auxvar_value, tol=1e-10, max_iter=300, log=Non
     direction are stored; for up to watchdog_trial_iter_max = 3 iterations the FULL step is taken whether acceptable or not, each tested against the stored point's
     (theta, phi, grad(phi)'d) and the filter; the first acceptable one ends the procedure, otherwise the stored iterate comes back and is searched along its stored
     direction from alpha = 1/2.  The log rows carry `wd` ("start", "trial", "success", "stop"); the result `watchdog_starts` / `watchdog_successes`.
-    probes/watchdog_experiment.py asks what it does to the cold rocket solves at T = 100 that crawl with steps of 1e-3."""
+    probes/watchdog_experiment.py asks what it does to the cold rocket solves at T = 100 that crawl with steps of 1e-3.  Checked once against the one stored case that
+    tells mechanisms apart (cart-pole, first row of the stored IRL trace, tests/test_oracle_soc.py): the watchdog alone is never armed on those five solves and the stored
+    loss is reproduced (3.8e-11); together with the second-order correction demonstration 4 still ends in 1513.67 where IPOPT's run ended in 623.79 - the restated PAIR is
+    not what IPOPT ran, so neither default moved."""
     o = OPT
     e = _vec(auxvar_value)
     n, m, T = oc.n, oc.m, int(horizon)
