@@ -1078,6 +1078,9 @@ def main():
                          "traffic_source": "recorded: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/traffic.json "
                                            "(probes/profile_r06.sh; counter values scaled by the factors measured on known byte counts in this repository's access "
                                            "shapes, probes/pmc_calibrate.hip: `traffic_calibration`), not collected in this run", "kernel_ms": float(kern_ms), "kernel_ms_samples": KERNEL_SAMPLES,
+                         "kernel_ms_is": "the HIP-event-bracketed duration of ONE isolated launch (first workgroup in to last workgroup out, plus ~2 us of event overhead), median of "
+                                         "kernel_ms_samples; ms_per_step of the timed region is a THROUGHPUT figure over back-to-back launches - a CU takes the next launch's "
+                                         "workgroup the moment its own retires - and may therefore be smaller (config.launch, config.launch_diagnostics, DESIGN.md section 6)",
                          "clocks": "sustained: every event-timed figure of this line is taken behind 20 ms of load (bench._event_ms)" if PREHEAT is not None else "cold (PDP_BENCH_NO_PREHEAT=1)",
                          "algorithmic_flop_per_launch": FLOP_PER_TRAJ * B, "timing_windows": [headline_window], "timed_region_window": timed_window,
                          "arithmetic_of_the_formulation_run": {"flop_per_launch": FLOP_PER_TRAJ_SCHUR * B,
