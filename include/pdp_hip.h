@@ -249,7 +249,7 @@ int pdp_oc_solve_batched(int B, int T, const double* x0, const double* theta, in
 #define PDP_MS_PREDICT_REJECTED 512 /* status, informational: PDP_MS_PREDICT_GUARD preferred the previous solution to its prediction */
 #define PDP_MS_WITH_SOC 128         /* opts.flags: second-order correction in the line search (see above; off by default) */
 #define PDP_MS_SOC 1024             /* status, informational: at least one iteration accepted a second-order-corrected step */
-#define PDP_MS_WITH_WATCHDOG 256    /* opts.flags (runner / evaluator kernel; not together with PDP_MS_WITH_SOC): IPOPT's watchdog in the line search - after 10 consecutive iterations
+#define PDP_MS_WITH_WATCHDOG 256    /* opts.flags (runner / evaluator kernel; with PDP_MS_WITH_SOC beside it: IPOPT's default pair, as restated): IPOPT's watchdog in the line search - after 10 consecutive iterations
                                      * with a shortened step the iterate and its direction are stored and up to 3 full steps are taken whether acceptable or not, each judged from the
                                      * stored point; the first acceptable one ends the procedure, otherwise the stored iterate comes back and is searched from alpha = 1/2.  IPOPT has it
                                      * on by default (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3) and the reference takes IPOPT's defaults (PDP/PDP.py:178-182);

@@ -298,7 +298,6 @@ int oc_solve_ms(int B, int T, const double* x0, const double* th, int tb, double
         const bool needs_pair = (op->flags & PDP_MS_FROM_CONTROLS) != 0;       // (the one-wave kernel has no restoration pass to start from)
         if (needs_pair && !(op->flags & PDP_MS_WARM)) return PDP_E_ARG;
         const bool watchdog = (op->flags & PDP_MS_WITH_WATCHDOG) != 0;
-        if (watchdog && (op->flags & PDP_MS_WITH_SOC)) return PDP_E_ARG;       // (the stored direction of a watchdog procedure waits where a correction keeps the plain step)
         const bool predict = (op->flags & PDP_MS_PREDICT) != 0;
         if ((op->flags & PDP_MS_PREDICT_PRIMAL) && (!predict || !op->predict_record)) return PDP_E_ARG;
         if (predict && (!(op->flags & PDP_MS_WARM) || needs_pair || !op->dtheta || (!op->predict_record && (!op->dxdp || !op->dudp)))) return PDP_E_ARG;

@@ -112,7 +112,7 @@ struct Ms2Layout {
     __host__ __device__ static constexpr bool predict_fits(int T) { return (int64_t)(T + 1) * NX + PRED_STG <= 2 * BUF; }
     __host__ __device__ static constexpr int64_t group_doubles(int T) { return (int64_t)(2 * NX + NU) * (T + 1); }
     __host__ __device__ static constexpr int64_t ws_doubles(int T, int max_iter) {
-        return 7 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1) + group_doubles(T);      // (the last group: the watchdog's stored iterate)
+        return 7 * group_doubles(T) + (int64_t)T * GSZ + (int64_t)T * PWSZ + 2 * (int64_t)(max_iter + 1) + 2 * group_doubles(T);      // (the last two groups: the watchdog's stored iterate and direction)
     }
 };
 
@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
     double* pw = gw + (int64_t)T * GSZ;                      // P_{t+1}, W_{t+1}, T x PWSZ
     double* fth = pw + (int64_t)T * PWSZ;                    // filter: theta entries (at most one per iteration) ...
     double* fph = fth + (op.max_iter + 1);                   //         ... and phi entries
-    double* wdp = fph + (op.max_iter + 1);                   // watchdog: the stored iterate (one group; the stored direction waits in stpb)
+    double* wdp = fph + (op.max_iter + 1);                   // watchdog: the stored iterate ...
+    double* wds = wdp + GRP;                                 //           ... and its direction
     // chunks: backward chunk g (0 = last stages) covers [t0, t0 + cnt); forward chunks follow in the same numbering
     const int nchunk = (T + L::ROWS - 1) / L::ROWS;
     const int ch = (T + nchunk - 1) / nchunk;
@@ -1273,10 +1274,10 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
             bool wd_free = false;                       // a watchdog trial taken although it is not acceptable
             double rf = f, rth = theta;                 // the point the accepting test referred to (the filter is augmented from it)
             if constexpr (WD) {
-                if (wd_on && !in_wd && wd_short >= 10) {        // start: the iterate into wdp, its direction into stpb
+                if (wd_on && !in_wd && !soc_mode && wd_short >= 10) {        // start (once per iteration, not in the pass of a correction): the iterate into wdp, its direction into wds
                     __threadfence_block();
                     const double* __restrict__ sp = Pt(cur);
-                    for (int q = lane; q < (int)GRP; q += 64) { wdp[q] = sp[q]; stpb[q] = stp[q]; }
+                    for (int q = lane; q < (int)GRP; q += 64) { wdp[q] = sp[q]; wds[q] = stp[q]; }
                     __threadfence_block();
                     in_wd = true; wd_trial = 0;
                     w_f = f; w_th = theta; w_gd = gd; w_dw = dw; w_amin = amin; w_pr = inf_pr; w_du = inf_du;
@@ -1323,7 +1324,7 @@ __global__ void __launch_bounds__(128 * TPW) oc_solve_ms2_kernel(int B, int T, p
                                 if (dead) break;
                                 __threadfence_block();
                                 double* __restrict__ sp = Pt(cur);
-                                for (int q = lane; q < (int)GRP; q += 64) { sp[q] = wdp[q]; stp[q] = stpb[q]; }
+                                for (int q = lane; q < (int)GRP; q += 64) { sp[q] = wdp[q]; stp[q] = wds[q]; }
                                 __threadfence_block();
                                 f = w_f; theta = w_th; gd = w_gd; dw = w_dw; amin = w_amin; inf_pr = w_pr; inf_du = w_du;
                                 in_wd = false; wd_short = 0;

@@ -101,6 +101,18 @@ def main():
                                     "status_bits": {BITS.get(b, str(b)): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 64, 128, 1024) if ((st & b) != 0).any()}}
             print("%-24s max_iter %-5d WATCHDOG converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  %.1f ms  started in %d  status %s" %
                   (name, mi, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), ms, entry["kernel"][key]["watchdog_procedures_started_in"], entry["kernel"][key]["status_bits"]))
+        if system == "rocket":              # both switches: IPOPT's default pair, as restated
+            for mi in (300, 1000):
+                s = mdl.oc_solve_ms(x0, th, T, tol=1e-8, max_iter=mi, watchdog=True, soc=True)
+                conv = s["converged"].cpu().numpy().astype(bool)
+                it = s["iterations"].cpu().numpy()
+                st = s["status"].cpu().numpy()
+                key = "tol_1e-08_max_iter_%d_watchdog_soc" % mi
+                entry["kernel"][key] = {"converged": int(conv.sum()), "of": B, "rate": float(conv.mean()),
+                                        "iterations": {"mean": float(it.mean()), "median": float(np.median(it)), "p95": float(np.percentile(it, 95)), "max": int(it.max())},
+                                        "status_bits": {BITS.get(b, str(b)): int(((st & b) != 0).sum()) for b in (1, 2, 4, 8, 16, 64, 128, 1024) if ((st & b) != 0).any()}}
+                print("%-24s max_iter %-5d WATCHDOG + SOC converged %4d / %4d  iterations mean %.1f median %.0f p95 %.0f max %d  status %s" %
+                      (name, mi, conv.sum(), B, it.mean(), np.median(it), np.percentile(it, 95), it.max(), entry["kernel"][key]["status_bits"]))
         # the class surface's route (what a user of OCSys.ocSolver_batch gets): kernel, then single shooting for the rows it left unconverged
         oc = make_oc(system)
         sol = ocsolver.solve_batch(oc, x0, T, th, tol=1e-9)

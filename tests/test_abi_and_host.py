@@ -249,10 +249,10 @@ def test_ocsolver_recognises_finite_bounds_and_new_entry_points_validate_argumen
     B, T = 7, 30
     n0, n1 = m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 0), m.lib.pdp_oc_solve_ms_workspace_bytes(B, T, 100)
     # either kernel variant may serve a call: the larger of the two layouts.  One-wave kernel: dx du dlam c gradx gradu gains P,W; runner / evaluator
-    # kernel: eight stage-minor groups of (2 n + m) (T + 1) doubles (two point sets, the step, two residual sets, c_soc, the step kept during corrections / a watchdog
-    # procedure, the watchdog's stored iterate) + gains (K | k) + (P | W)
+    # kernel: nine stage-minor groups of (2 n + m) (T + 1) doubles (two point sets, the step, two residual sets, c_soc, the step kept during corrections, the watchdog's
+    # stored iterate and direction) + gains (K | k) + (P | W)
     per1 = (T + 1) * 2 + T * 1 + T * 2 + T * 2 + (T + 1) * 2 + T * 1 + T * (2 * 1 + 1 + 1) + T * (4 + 2 + 1)
-    per2 = 8 * (2 * 2 + 1) * (T + 1) + T * (2 * 1 + 1) + T * (4 + 2)
+    per2 = 9 * (2 * 2 + 1) * (T + 1) + T * (2 * 1 + 1) + T * (4 + 2)
     assert n0 == 8 * B * (max(per1, per2) + 2) and n1 - n0 == 8 * B * 2 * 100
     opts = runtime.PdpOcMsOpts(1e-10, 100, 0, 0)
     import ctypes
