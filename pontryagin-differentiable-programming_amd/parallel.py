@@ -166,9 +166,10 @@ class StepStreams:
     the all-gather, 0.0882 ms without.  The steps must not share anything they write (outputs, workspace): one prepared call per stream.
     Not for dependent steps (a gradient-descent loop): there the exchange sits on the critical path whatever the stream."""
 
-    def __init__(self, n=2):
-        self.main = torch.cuda.current_stream()
-        self.streams = [torch.cuda.Stream() for _ in range(int(n))]
+    def __init__(self, n=2, streams=None):
+        """streams: use these (e.g. a pair found by timing a few candidates, as bench.py does: HIP streams share 4 hardware queues in creation order, and a step stream
+        that lands in the queue of the side stream - or both step streams in one - loses what the scheme gains); default: n new streams"""
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream() for _ in range(int(n))]
         self.k = 0
         self.fork()
 
