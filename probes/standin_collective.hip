@@ -3,6 +3,8 @@
 // workgroups (one per channel), each holding a CU slot, some LDS and registers for as long as the exchange lasts (tens of microseconds for 80 KB over xGMI).  This
 // kernel has that footprint and nothing else: `nwg` workgroups of 256 threads with `lds_bytes` of dynamic LDS spin for `us` microseconds on the 100 MHz wall clock,
 // then copy `n` doubles (the rows) from src to dst so that the ordering of the pipeline can be checked on the data.
+// The footprint is RCCL's: the gfx950 code object of librccl.so 2.26.6 (llvm-readelf --notes) holds 126 kernels, 114 of them with 4.7 - 21 KB of static LDS per workgroup
+// (rcclGenericKernel<1 | 2 | 4>: 19,744 bytes, max_flat_workgroup_size 256, 261 - 280 registers incl. AGPRs); oc_pdp_fused3_kernel<quadrotor, 4> leaves 0 bytes of a CU's LDS free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
